@@ -1,0 +1,159 @@
+/* trsim.h — C ABI of libtrsim.so, the MI355X-native batched env that replaces the
+ * per-car simulator bridge of Triton-AI/Triton-Racer-Sim.
+ *
+ * Every entry point states the reference interface it stands in for.  Paths are
+ * relative to /root/reference/TritonRacerSim/.  The reference is Python, so its
+ * "FFI" for this path is ctypes: the binding a maintainer would add is shown in
+ * INTEGRATION.md and shipped as triton-racer-sim_amd/_ffi.py.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success and a negative trs_status on error (never aborts, never throws);
+ * trs_last_error() gives the message of the last failing call on this thread.
+ * One handle = one GPU + one HIP stream; a handle is not re-entrant, different
+ * handles are independent.  "d_" parameters are device pointers on the handle's
+ * GPU, "h_" parameters are host pointers.
+ *
+ * The CPU oracle (oracle/libtrsim_oracle.so, test infrastructure only) exports
+ * the same signatures with the prefix trso_ instead of trs_.
+ */
+#ifndef TRSIM_H
+#define TRSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trs_env trs_env;
+
+typedef enum trs_status {
+    TRS_OK = 0,
+    TRS_ERR_ARG = -1,      /* bad argument / bad config */
+    TRS_ERR_STATE = -2,    /* call order (e.g. step before load_track) */
+    TRS_ERR_DEVICE = -3,   /* no GPU, HIP error */
+    TRS_ERR_NOMEM = -4,
+    TRS_ERR_LIMIT = -5     /* track / image too large for the LDS-resident layout */
+} trs_status;
+
+/* Replaces the `gym_config` dict of GymInterface.__init__ (components/gyminterface.py:16-51;
+ * keys img_w/img_h/sim_latency of core/config.py:8-9,98) plus the free parameters of
+ * SURVEY.md Appendix B.  Fill with trs_default_config() first, then override. */
+typedef struct trs_config {
+    uint32_t struct_size;      /* = sizeof(trs_config), checked */
+    int32_t  n_envs;           /* envs in THIS shard (one shard per GPU) */
+    int32_t  env_id_base;      /* global id of local env 0 (RNG + start pose are keyed by global id) */
+    int32_t  img_h, img_w;     /* config.py:8-9 -> 120, 160; img_w % 4 == 0 */
+    int32_t  render;           /* 0 = physics only (BASELINE config 2), 1 = RGB camera */
+    int32_t  auto_reset;       /* 1 = an env that finished (off track) restarts on its next step */
+    int32_t  reserved0;
+    uint64_t seed;             /* synthetic-control RNG seed, default 0x5EED */
+    /* physics (trsim_spec.h) */
+    float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
+    float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
+    /* track surface + camera (binary64: only used on the host to build tables) */
+    double road_half, edge_half, centre_half, dash_period, dash_on, map_margin;
+    double fov_v_deg, cam_h, cam_pitch_deg, z_far;
+} trs_config;
+
+/* Device-resident outputs of the last completed step: what GymInterface.step returns
+ * (components/gyminterface.py:76: last_image, pos_x, pos_y, pos_z, speed, cte) for every env,
+ * plus LocationTracker's integer index (components/track_data_process.py:89-101). */
+typedef struct trs_state_view {
+    int32_t n_envs, img_h, img_w, n_points;
+    const uint8_t* img;        /* uint8[n_envs][img_h][img_w][3] RGB, NULL when render == 0 */
+    const float*   pos_x;      /* 'gym/x'     */
+    const float*   pos_y;      /* 'gym/y'     */
+    const float*   pos_z;      /* 'gym/z'     */
+    const float*   speed;      /* 'gym/speed' = |v| */
+    const float*   cte;        /* 'gym/cte'   */
+    const float*   yaw;
+    const float*   vel;        /* signed longitudinal speed */
+    const int32_t* seg_idx;    /* LocationTracker index; 'loc/segment' = idx / n_points * 10 */
+    const float*   ep_return;  /* running return of the current episode */
+    const float*   last_return;/* return of the last finished episode */
+    const int32_t* ep_len;
+    const uint8_t* done;       /* 1 = this step ended the episode (off track / lost) */
+    uint64_t step_count;       /* steps taken since create */
+} trs_state_view;
+
+/* selectors for trs_copy_to_host */
+enum {
+    TRS_F_IMG = 0, TRS_F_POS_X, TRS_F_POS_Y, TRS_F_POS_Z, TRS_F_SPEED, TRS_F_CTE, TRS_F_YAW, TRS_F_VEL,
+    TRS_F_SEG_IDX, TRS_F_EP_RETURN, TRS_F_LAST_RETURN, TRS_F_EP_LEN, TRS_F_DONE,
+    TRS_F_MAP,       /* packed 2-bit class map, uint32[map_h][map_words] (parity checks) */
+    TRS_F_ROWTAB,    /* float[img_h][2]  (row_lz, row_k)  */
+    TRS_F_PALETTE,   /* uint32[img_h][4] 0x00BBGGRR       */
+    TRS_F_TANGENT,   /* float[n_points][2] (tx, tz)       */
+    TRS_F_STEER_FILT /* float[n_envs] synthetic low-pass state */
+};
+
+typedef struct trs_map_info {
+    int32_t map_w, map_h, map_words;   /* cells, cells, uint32 per map row */
+    double  cell, x0, z0;              /* world size of a cell, world coords of cell (0,0)'s corner */
+    int32_t n_points;
+    int32_t lds_bytes;                 /* dynamic LDS the step kernel is launched with */
+} trs_map_info;
+
+void trs_default_config(trs_config* cfg);
+
+/* GymInterface.__init__ (components/gyminterface.py:49-64): connect + state init, minus the
+ * TCP client, the scene load and the two 1 s sleeps (:121,:135).  `device` is a HIP device index. */
+int trs_create(const trs_config* cfg, int device, trs_env** out);
+
+/* GymInterface.onShutdown -> SDClient.stop (components/gyminterface.py:81-82). */
+int trs_destroy(trs_env* env);
+
+/* Replaces load_scene(scene_name) (components/gyminterface.py:54,166-169) and the JSON load of
+ * LocationTracker.__init__ (components/track_data_process.py:72-73): raw centre-line samples
+ * [x,y,z] (Unity, y up), duplicates kept.  Builds the class map and camera tables, uploads
+ * them, places every env on its start pose (point (37*gid) mod n). */
+int trs_load_track(trs_env* env, const double* h_xyz, int n_points);
+
+/* reset_car (components/gyminterface.py:171-174) for the masked envs (NULL = all); host mask. */
+int trs_reset(trs_env* env, const uint8_t* h_mask_or_null);
+
+/* GymInterface.step (components/gyminterface.py:66-76) + send_controls (:156-161) for the whole
+ * shard: steering/throttle in [-1,1], brake in [0,1] (NULL = 0, the `breaking is None` case :70),
+ * reset truthy = restart that env (:73-74; NULL = none).  n_steps > 1 holds the controls.
+ * Device pointers; asynchronous on the handle's stream. */
+int trs_step(trs_env* env, const float* d_steering, const float* d_throttle,
+             const float* d_brake, const uint8_t* d_reset, int n_steps);
+
+/* Same with host arrays (the N = 1 Component path); copies the controls, then trs_step. */
+int trs_step_host(trs_env* env, const float* h_steering, const float* h_throttle,
+                  const float* h_brake, const uint8_t* h_reset, int n_steps);
+
+/* Benchmark driver: controls come from the counter-based generator of trsim_spec.h
+ * (SURVEY.md §8d), evaluated inside the step kernel.  steps_per_launch >= 1. */
+int trs_step_synthetic(trs_env* env, int n_steps, int steps_per_launch);
+
+/* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
+int trs_get_state(trs_env* env, trs_state_view* out);
+
+/* Synchronising copy of one field to host memory (`which` = TRS_F_*). `bytes` must match. */
+int trs_copy_to_host(trs_env* env, int which, void* h_dst, size_t bytes);
+
+/* Overwrite env pose (x, y, z, yaw, v) from host arrays of n_envs floats — test hook. */
+int trs_set_pose(trs_env* env, const float* h_x, const float* h_y, const float* h_z,
+                 const float* h_yaw, const float* h_v);
+
+/* LocationTracker.step / __find_closest for a batch of binary64 query points
+ * (components/track_data_process.py:81-101): h_idx_out[i] = integer nearest-point index. */
+int trs_locate(trs_env* env, const double* h_xyz, int n_queries, int32_t* h_idx_out);
+
+int trs_map_info_get(trs_env* env, trs_map_info* out);
+
+/* stream control + device-side timing (HIP events on the handle's stream) */
+int trs_sync(trs_env* env);
+int trs_event_record(trs_env* env, int slot);                 /* slot 0..7 */
+int trs_event_elapsed_ms(trs_env* env, int slot_a, int slot_b, float* ms_out);
+int trs_device_count(int* out);
+
+const char* trs_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRSIM_H */

@@ -1,0 +1,540 @@
+/* trsim_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (triton-racer-sim_amd/) never does and fails loudly without its
+ * HIP extension.
+ *
+ * What it restates, and how it is pinned:
+ *   - trso_locate / the nearest-point search: a plain-C restatement of the reference's
+ *     LocationTracker.__find_closest / __distance
+ *     (/root/reference/TritonRacerSim/components/track_data_process.py:89-104).
+ *     PINNED by tests/golden/locate_*.json, captured from the reference itself
+ *     (tests/golden/gen_golden.py).
+ *   - bicycle-model step, cross-track error, class map, camera: there is NO reference
+ *     implementation (the reference talks to a closed Unity binary,
+ *     components/gyminterface.py:47-104).  These follow the text of
+ *     include/trsim_spec.h.  PARITY UNPINNED against the reference for these parts.
+ *
+ * Scalar, one env at a time, written for clarity; `#pragma omp` over envs only so the
+ * CPU baseline can use all host cores.  Exports the trsim.h ABI with prefix trso_.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/trsim.h"
+#include "../include/trsim_spec.h"
+
+#define EXPORT __attribute__((visibility("default")))
+
+static __thread char g_err[256];
+static int fail(int code, const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
+
+struct trs_env {
+    trs_config cfg;
+    int n, H, W;
+    int threads;
+    /* track */
+    int np;
+    double *px, *py, *pz;      /* raw points, binary64 */
+    float *tang;               /* [np][2] */
+    float *start_yaw;          /* [np] */
+    /* map + tables */
+    trs_map_info mi;
+    uint32_t* map;
+    float* rowtab;             /* [H][2] */
+    uint32_t* pal;             /* [H][4] */
+    float map_x0f, map_z0f, inv_cellf;
+    /* state */
+    float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
+    int32_t *seg_idx, *ep_len;
+    uint8_t *done, *pending;
+    uint8_t* img;
+    uint64_t step_count;
+};
+
+/* ------------------------------------------------------------------ spec pieces */
+
+static void spec_sincos(float a, float* so, float* co)
+{
+    float q = rintf(a * TRS_TWO_OVER_PI);
+    float r = fmaf(q, -TRS_PIO2_HI, a);
+    r = fmaf(q, -TRS_PIO2_LO, r);
+    float z = r * r;
+    float ps = fmaf(fmaf(TRS_S0, z, TRS_S1), z, TRS_S2);
+    float s = fmaf(r * z, ps, r);
+    float pc = fmaf(fmaf(TRS_C0, z, TRS_C1), z, TRS_C2);
+    float c = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    switch (((int)q) & 3) {
+    case 0: *so = s;  *co = c;  break;
+    case 1: *so = c;  *co = -s; break;
+    case 2: *so = -s; *co = -c; break;
+    default: *so = -c; *co = s; break;
+    }
+}
+
+static float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
+
+/* track_data_process.py:89-104: sequential scan, best = 100, strict '<'. */
+static int l1_nearest(const struct trs_env* e, double qx, double qy, double qz, double* best_out)
+{
+    int sel = 0;
+    double best = TRS_LOST_L1;
+    for (int i = 0; i < e->np; ++i) {
+        double d = fabs(qx - e->px[i]) + fabs(qy - e->py[i]) + fabs(qz - e->pz[i]);
+        if (d < best) { sel = i; best = d; }
+    }
+    if (best_out) *best_out = best;
+    return sel;
+}
+
+static void synth_controls(uint64_t seed, uint32_t gid, uint32_t step, float* sf, float* steer, float* thr)
+{
+    uint64_t z = seed + (((uint64_t)gid << 32) | (uint64_t)step) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    float us = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+    float ut = (float)(uint32_t)((z >> 16) & 0xFFFFFFu) * 5.9604644775390625e-08f;
+    float raw = us * 2.0f - 1.0f;
+    float nsf = *sf + TRS_SYNTH_ALPHA * (raw - *sf);
+    *sf = nsf;
+    *steer = nsf;
+    *thr = TRS_SYNTH_THR_LO + TRS_SYNTH_THR_SPAN * ut;
+}
+
+/* one env, one step; returns heading (s, c) for the camera */
+static void step_env(struct trs_env* e, int i, float steer, float thr, float brk, int reset_in, float* hs, float* hc)
+{
+    const trs_config* k = &e->cfg;
+    int do_reset = e->pending[i] || reset_in || (k->auto_reset && e->done[i]);
+    float x1, z1, yaw1, v2, s, c;
+    if (do_reset) {
+        int gid = k->env_id_base + i;
+        int si = (int)(((int64_t)TRS_START_STRIDE * gid) % e->np);
+        e->last_return[i] = e->ep_return[i];
+        e->ep_return[i] = 0.0f;
+        e->ep_len[i] = 0;
+        e->steer_filt[i] = 0.0f;
+        e->pending[i] = 0;
+        x1 = (float)e->px[si]; e->y[i] = (float)e->py[si]; z1 = (float)e->pz[si];
+        yaw1 = e->start_yaw[si]; v2 = 0.0f;
+        spec_sincos(yaw1, &s, &c);
+    } else {
+        steer = clampf(steer, -1.0f, 1.0f);
+        thr = clampf(thr, -1.0f, 1.0f);
+        brk = clampf(brk, 0.0f, 1.0f);
+        float sd, cd;
+        spec_sincos(steer * k->max_steer, &sd, &cd);
+        float tan_d = sd / cd;
+        float v = e->v[i];
+        float a = thr * k->accel_max - k->drag_lin * v;
+        float v1 = v + a * k->dt;
+        float dv = (k->roll_res + brk * k->brake_max) * k->dt;
+        if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
+        else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
+        else v2 = 0.0f;
+        v2 = clampf(v2, -k->v_rev_max, k->v_max);
+        yaw1 = e->yaw[i] + ((v2 * tan_d) * k->inv_wheelbase) * k->dt;
+        if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
+        if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
+        spec_sincos(yaw1, &s, &c);
+        x1 = e->x[i] + (v2 * s) * k->dt;
+        z1 = e->z[i] + (v2 * c) * k->dt;
+    }
+    double best;
+    int idx = l1_nearest(e, (double)x1, (double)e->y[i], (double)z1, &best);
+    float y1 = (float)e->py[idx];
+    float cte = (x1 - (float)e->px[idx]) * e->tang[2 * idx + 1] - (z1 - (float)e->pz[idx]) * e->tang[2 * idx];
+    int lost = best >= TRS_LOST_L1;
+    int done = (fabsf(cte) > k->offtrack_cte) || lost;
+    if (do_reset) {
+        /* first observation of the new episode: no reward */
+    } else {
+        int d = idx - e->seg_idx[i];
+        int half = e->np / 2;
+        if (d >= e->np - half) d -= e->np;       /* wrap to [-n/2, n/2) */
+        if (d < -half) d += e->np;
+        float reward = (float)d - (done ? k->offtrack_penalty : 0.0f);
+        e->ep_return[i] = e->ep_return[i] + reward;
+        e->ep_len[i] += 1;
+    }
+    e->x[i] = x1; e->y[i] = y1; e->z[i] = z1; e->yaw[i] = yaw1; e->v[i] = v2;
+    e->speed[i] = fabsf(v2); e->cte[i] = cte; e->seg_idx[i] = idx; e->done[i] = (uint8_t)done;
+    *hs = s; *hc = c;
+}
+
+static void render_env(struct trs_env* e, int i, float s, float c)
+{
+    const trs_config* k = &e->cfg;
+    const int H = e->H, W = e->W, GW = e->mi.map_w, GH = e->mi.map_h, MW = e->mi.map_words;
+    float camx = ((e->x[i] + k->cam_fwd * s) - e->map_x0f) * e->inv_cellf;
+    float camz = ((e->z[i] + k->cam_fwd * c) - e->map_z0f) * e->inv_cellf;
+    uint8_t* out = e->img + (size_t)i * H * W * 3;
+    float half_w = (float)(W / 2);
+    for (int v = 0; v < H; ++v) {
+        float lz = e->rowtab[2 * v], kk = e->rowtab[2 * v + 1];
+        float ax = fmaf(lz, s, camx), az = fmaf(lz, c, camz);
+        float dx = kk * c, dz = -(kk * s);
+        const uint32_t* pal = e->pal + 4 * v;
+        for (int u = 0; u < W; ++u) {
+            float uf = (float)u + 0.5f - half_w;
+            float gx = fmaf(uf, dx, ax), gz = fmaf(uf, dz, az);
+            int ix = (int)floorf(gx), iz = (int)floorf(gz);
+            ix = ix < 0 ? 0 : (ix > GW - 1 ? GW - 1 : ix);
+            iz = iz < 0 ? 0 : (iz > GH - 1 ? GH - 1 : iz);
+            uint32_t w = e->map[(size_t)iz * MW + (ix >> 4)];
+            uint32_t cls = (w >> ((ix & 15) * 2)) & 3u;
+            uint32_t rgb = pal[cls];
+            out[0] = (uint8_t)(rgb & 255u); out[1] = (uint8_t)((rgb >> 8) & 255u); out[2] = (uint8_t)((rgb >> 16) & 255u);
+            out += 3;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ host-side table building */
+
+static int build_track_tables(struct trs_env* e)
+{
+    const trs_config* k = &e->cfg;
+    const int np = e->np;
+    /* tangents: next distinct minus previous distinct point in (x, z), closed loop */
+    for (int i = 0; i < np; ++i) {
+        int j = i, b = i, n;
+        for (n = 0; n < np; ++n) { j = (j + 1) % np; if (e->px[j] != e->px[i] || e->pz[j] != e->pz[i]) break; }
+        if (n == np) return fail(TRS_ERR_ARG, "track has no two distinct points");
+        for (n = 0; n < np; ++n) { b = (b + np - 1) % np; if (e->px[b] != e->px[i] || e->pz[b] != e->pz[i]) break; }
+        double tx = e->px[j] - e->px[b], tz = e->pz[j] - e->pz[b];
+        double len = sqrt(tx * tx + tz * tz);
+        if (len == 0.0) { tx = e->px[j] - e->px[i]; tz = e->pz[j] - e->pz[i]; len = sqrt(tx * tx + tz * tz); }
+        tx /= len; tz /= len;
+        e->tang[2 * i] = (float)tx; e->tang[2 * i + 1] = (float)tz;
+        e->start_yaw[i] = (float)atan2(tx, tz);
+    }
+    /* de-duplicated closed polyline */
+    double* qx = malloc(sizeof(double) * (np + 1)), *qz = malloc(sizeof(double) * (np + 1));
+    double* qs = malloc(sizeof(double) * (np + 1));
+    int m = 0;
+    for (int i = 0; i < np; ++i) {
+        if (m && qx[m - 1] == e->px[i] && qz[m - 1] == e->pz[i]) continue;
+        qx[m] = e->px[i]; qz[m] = e->pz[i]; ++m;
+    }
+    if (m > 1 && qx[m - 1] == qx[0] && qz[m - 1] == qz[0]) --m;
+    double xmin = qx[0], xmax = qx[0], zmin = qz[0], zmax = qz[0];
+    for (int i = 1; i < m; ++i) {
+        if (qx[i] < xmin) xmin = qx[i];
+        if (qx[i] > xmax) xmax = qx[i];
+        if (qz[i] < zmin) zmin = qz[i];
+        if (qz[i] > zmax) zmax = qz[i];
+    }
+    double cell = TRS_MAP_CELL_MIN;
+    int GW, GH, MW;
+    double x0, z0;
+    for (;;) {
+        x0 = floor((xmin - k->map_margin) / cell) * cell;
+        z0 = floor((zmin - k->map_margin) / cell) * cell;
+        GW = (int)ceil((xmax + k->map_margin - x0) / cell);
+        GH = (int)ceil((zmax + k->map_margin - z0) / cell);
+        MW = (GW + 15) / 16;
+        if ((size_t)MW * 4 * GH <= TRS_MAP_LDS_BUDGET) break;
+        cell *= 2.0;
+        if (cell > 64.0) { free(qx); free(qz); free(qs); return fail(TRS_ERR_LIMIT, "track too large for the map budget"); }
+    }
+    e->mi.map_w = GW; e->mi.map_h = GH; e->mi.map_words = MW; e->mi.cell = cell; e->mi.x0 = x0; e->mi.z0 = z0;
+    e->mi.n_points = np;
+    e->map_x0f = (float)x0; e->map_z0f = (float)z0; e->inv_cellf = (float)(1.0 / cell);
+
+    size_t ncell = (size_t)GW * GH;
+    double* D2 = malloc(sizeof(double) * ncell), *S = malloc(sizeof(double) * ncell);
+    for (size_t c = 0; c < ncell; ++c) { D2[c] = INFINITY; S[c] = 0.0; }
+    double reach = k->road_half + k->edge_half + cell;
+    double s_acc = 0.0;
+    for (int sgm = 0; sgm < m; ++sgm) {
+        double ax = qx[sgm], az = qz[sgm], bx = qx[(sgm + 1) % m], bz = qz[(sgm + 1) % m];
+        double abx = bx - ax, abz = bz - az;
+        double len2 = abx * abx + abz * abz, len = sqrt(len2);
+        qs[sgm] = s_acc;
+        int ix0 = (int)floor(((ax < bx ? ax : bx) - reach - x0) / cell), ix1 = (int)floor(((ax > bx ? ax : bx) + reach - x0) / cell);
+        int iz0 = (int)floor(((az < bz ? az : bz) - reach - z0) / cell), iz1 = (int)floor(((az > bz ? az : bz) + reach - z0) / cell);
+        if (ix0 < 0) ix0 = 0;
+        if (iz0 < 0) iz0 = 0;
+        if (ix1 > GW - 1) ix1 = GW - 1;
+        if (iz1 > GH - 1) iz1 = GH - 1;
+        for (int iz = iz0; iz <= iz1; ++iz)
+            for (int ix = ix0; ix <= ix1; ++ix) {
+                double cx = x0 + ((double)ix + 0.5) * cell, cz = z0 + ((double)iz + 0.5) * cell;
+                double apx = cx - ax, apz = cz - az;
+                double t = (apx * abx + apz * abz) / len2;
+                t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+                double ex = cx - (ax + t * abx), ez = cz - (az + t * abz);
+                double d2 = ex * ex + ez * ez;
+                size_t ci = (size_t)iz * GW + ix;
+                if (d2 < D2[ci]) { D2[ci] = d2; S[ci] = s_acc + t * len; }
+            }
+        s_acc += len;
+    }
+    e->map = calloc((size_t)MW * GH, sizeof(uint32_t));
+    for (int iz = 1; iz < GH - 1; ++iz)
+        for (int ix = 1; ix < GW - 1; ++ix) {
+            size_t ci = (size_t)iz * GW + ix;
+            if (!(D2[ci] < INFINITY)) continue;
+            double d = sqrt(D2[ci]);
+            uint32_t cls;
+            if (d <= k->centre_half && fmod(S[ci], k->dash_period) < k->dash_on) cls = TRS_CLS_CENTRE;
+            else if (fabs(d - k->road_half) <= k->edge_half) cls = TRS_CLS_EDGE;
+            else if (d < k->road_half) cls = TRS_CLS_ROAD;
+            else cls = TRS_CLS_GRASS;
+            e->map[(size_t)iz * MW + (ix >> 4)] |= cls << ((ix & 15) * 2);
+        }
+    free(D2); free(S); free(qx); free(qz); free(qs);
+
+    /* camera rows + palette */
+    static const int base[4][3] = { TRS_RGB_GRASS, TRS_RGB_ROAD, TRS_RGB_EDGE, TRS_RGB_CENTRE };
+    static const int fog[3] = TRS_RGB_FOG, sky_top[3] = TRS_RGB_SKY_TOP, sky_hor[3] = TRS_RGB_SKY_HOR;
+    const int H = e->H;
+    const double PI_D = 3.14159265358979323846;
+    double f = ((double)H / 2.0) / tan(k->fov_v_deg * PI_D / 180.0 / 2.0);
+    double pitch = k->cam_pitch_deg * PI_D / 180.0, cp = cos(pitch), sp = sin(pitch);
+    for (int v = 0; v < H; ++v) {
+        double yn = ((double)H / 2.0 - ((double)v + 0.5)) / f;
+        double dy = yn * cp - sp, dz = yn * sp + cp;
+        int rgb[4][3];
+        float lz = 0.0f, kk = 0.0f;
+        if (dy >= -1e-6) {
+            double g = ((double)v + 0.5) / ((double)H / 2.0);
+            if (g > 1.0) g = 1.0;
+            for (int ch = 0; ch < 3; ++ch) {
+                int val = (int)floor((double)sky_top[ch] + ((double)sky_hor[ch] - (double)sky_top[ch]) * g + 0.5);
+                for (int c = 0; c < 4; ++c) rgb[c][ch] = val;
+            }
+        } else {
+            double t = k->cam_h / (-dy);
+            double fwd = t * dz;
+            if (fwd > k->z_far) {
+                for (int ch = 0; ch < 3; ++ch) {
+                    int val = (int)floor((double)base[0][ch] * (1.0 - TRS_FOG_MAX) + (double)fog[ch] * TRS_FOG_MAX + 0.5);
+                    for (int c = 0; c < 4; ++c) rgb[c][ch] = val;
+                }
+            } else {
+                lz = (float)(fwd / cell);
+                kk = (float)((t / f) / cell);
+                double fw = TRS_FOG_MAX * (fwd / k->z_far);
+                for (int c = 0; c < 4; ++c)
+                    for (int ch = 0; ch < 3; ++ch)
+                        rgb[c][ch] = (int)floor((double)base[c][ch] * (1.0 - fw) + (double)fog[ch] * fw + 0.5);
+            }
+        }
+        e->rowtab[2 * v] = lz; e->rowtab[2 * v + 1] = kk;
+        for (int c = 0; c < 4; ++c)
+            e->pal[4 * v + c] = (uint32_t)rgb[c][0] | ((uint32_t)rgb[c][1] << 8) | ((uint32_t)rgb[c][2] << 16);
+    }
+    return TRS_OK;
+}
+
+/* ------------------------------------------------------------------ ABI */
+
+EXPORT void trso_default_config(trs_config* c)
+{
+    memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->n_envs = 1; c->env_id_base = 0; c->img_h = 120; c->img_w = 160; c->render = 1; c->auto_reset = 0;
+    c->seed = TRS_SYNTH_SEED;
+    c->dt = TRS_DEF_DT; c->max_steer = TRS_DEF_MAX_STEER; c->inv_wheelbase = TRS_DEF_INV_WHEELBASE;
+    c->accel_max = TRS_DEF_ACCEL_MAX; c->drag_lin = TRS_DEF_DRAG_LIN; c->roll_res = TRS_DEF_ROLL_RES;
+    c->brake_max = TRS_DEF_BRAKE_MAX; c->v_max = TRS_DEF_V_MAX; c->v_rev_max = TRS_DEF_V_REV_MAX;
+    c->offtrack_cte = TRS_DEF_OFFTRACK_CTE; c->offtrack_penalty = TRS_DEF_OFFTRACK_PENALTY; c->cam_fwd = TRS_DEF_CAM_FWD;
+    c->road_half = TRS_DEF_ROAD_HALF; c->edge_half = TRS_DEF_EDGE_HALF; c->centre_half = TRS_DEF_CENTRE_HALF;
+    c->dash_period = TRS_DEF_DASH_PERIOD; c->dash_on = TRS_DEF_DASH_ON; c->map_margin = TRS_DEF_MAP_MARGIN;
+    c->fov_v_deg = TRS_DEF_FOV_V_DEG; c->cam_h = TRS_DEF_CAM_H; c->cam_pitch_deg = TRS_DEF_CAM_PITCH_DEG; c->z_far = TRS_DEF_Z_FAR;
+}
+
+EXPORT int trso_create(const trs_config* cfg, int device, trs_env** out)
+{
+    (void)device;
+    if (!cfg || !out) return fail(TRS_ERR_ARG, "null argument");
+    if (cfg->struct_size != sizeof(trs_config)) return fail(TRS_ERR_ARG, "trs_config.struct_size mismatch");
+    if (cfg->n_envs < 1 || cfg->img_h < 2 || cfg->img_w < 4 || (cfg->img_w & 3) || cfg->env_id_base < 0)
+        return fail(TRS_ERR_ARG, "bad n_envs / image size (img_w must be a multiple of 4)");
+    struct trs_env* e = calloc(1, sizeof *e);
+    if (!e) return fail(TRS_ERR_NOMEM, "out of memory");
+    e->cfg = *cfg; e->n = cfg->n_envs; e->H = cfg->img_h; e->W = cfg->img_w; e->threads = 1;
+    int n = e->n;
+#define A(p, T) p = calloc((size_t)n, sizeof(T))
+    A(e->x, float); A(e->y, float); A(e->z, float); A(e->yaw, float); A(e->v, float); A(e->speed, float); A(e->cte, float);
+    A(e->ep_return, float); A(e->last_return, float); A(e->steer_filt, float); A(e->seg_idx, int32_t); A(e->ep_len, int32_t);
+    A(e->done, uint8_t); A(e->pending, uint8_t);
+#undef A
+    if (cfg->render) e->img = calloc((size_t)n * e->H * e->W * 3, 1);
+    e->rowtab = calloc((size_t)e->H * 2, sizeof(float));
+    e->pal = calloc((size_t)e->H * 4, sizeof(uint32_t));
+    *out = e;
+    return TRS_OK;
+}
+
+EXPORT int trso_destroy(trs_env* e)
+{
+    if (!e) return TRS_OK;
+    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal);
+    free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
+    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->img);
+    free(e);
+    return TRS_OK;
+}
+
+EXPORT int trso_load_track(trs_env* e, const double* xyz, int np)
+{
+    if (!e || !xyz || np < 2) return fail(TRS_ERR_ARG, "bad track");
+    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); e->map = NULL;
+    e->np = np;
+    e->px = malloc(sizeof(double) * np); e->py = malloc(sizeof(double) * np); e->pz = malloc(sizeof(double) * np);
+    e->tang = malloc(sizeof(float) * 2 * np); e->start_yaw = malloc(sizeof(float) * np);
+    for (int i = 0; i < np; ++i) { e->px[i] = xyz[3 * i]; e->py[i] = xyz[3 * i + 1]; e->pz[i] = xyz[3 * i + 2]; }
+    int rc = build_track_tables(e);
+    if (rc) return rc;
+    for (int i = 0; i < e->n; ++i) {
+        int gid = e->cfg.env_id_base + i;
+        int si = (int)(((int64_t)TRS_START_STRIDE * gid) % np);
+        e->x[i] = (float)e->px[si]; e->y[i] = (float)e->py[si]; e->z[i] = (float)e->pz[si];
+        e->yaw[i] = e->start_yaw[si]; e->v[i] = 0.0f; e->speed[i] = 0.0f; e->cte[i] = 0.0f;
+        e->seg_idx[i] = si; e->ep_return[i] = 0.0f; e->last_return[i] = 0.0f; e->ep_len[i] = 0;
+        e->steer_filt[i] = 0.0f; e->done[i] = 0; e->pending[i] = 1;
+    }
+    e->step_count = 0;
+    return TRS_OK;
+}
+
+EXPORT int trso_reset(trs_env* e, const uint8_t* mask)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    for (int i = 0; i < e->n; ++i) if (!mask || mask[i]) e->pending[i] = 1;
+    return TRS_OK;
+}
+
+static int do_steps(struct trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n_steps, int synth)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
+    if (!synth && (!st || !th)) return fail(TRS_ERR_ARG, "null controls");
+    for (int k = 0; k < n_steps; ++k) {
+        uint32_t t = (uint32_t)e->step_count;
+#pragma omp parallel for schedule(static) num_threads(e->threads)
+        for (int i = 0; i < e->n; ++i) {
+            float steer, thr, brk = 0.0f, s, c;
+            int reset_in = 0;
+            if (synth) {
+                /* the generator state advances only on steps that integrate; decide reset first */
+                int will_reset = e->pending[i] || (e->cfg.auto_reset && e->done[i]);
+                if (will_reset) { steer = 0.0f; thr = 0.0f; }
+                else synth_controls(e->cfg.seed, (uint32_t)(e->cfg.env_id_base + i), t, &e->steer_filt[i], &steer, &thr);
+            } else {
+                steer = st[i]; thr = th[i]; brk = br ? br[i] : 0.0f; reset_in = (rs && k == 0) ? rs[i] != 0 : 0;
+            }
+            step_env(e, i, steer, thr, brk, reset_in, &s, &c);
+            if (e->img) render_env(e, i, s, c);
+        }
+        e->step_count++;
+    }
+    return TRS_OK;
+}
+
+EXPORT int trso_step(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n)
+{ return do_steps(e, st, th, br, rs, n, 0); }
+EXPORT int trso_step_host(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n)
+{ return do_steps(e, st, th, br, rs, n, 0); }
+EXPORT int trso_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
+{ (void)steps_per_launch; return do_steps(e, NULL, NULL, NULL, NULL, n_steps, 1); }
+
+EXPORT int trso_get_state(trs_env* e, trs_state_view* o)
+{
+    if (!e || !o) return fail(TRS_ERR_ARG, "null argument");
+    o->n_envs = e->n; o->img_h = e->H; o->img_w = e->W; o->n_points = e->np;
+    o->img = e->img; o->pos_x = e->x; o->pos_y = e->y; o->pos_z = e->z; o->speed = e->speed; o->cte = e->cte;
+    o->yaw = e->yaw; o->vel = e->v; o->seg_idx = e->seg_idx; o->ep_return = e->ep_return; o->last_return = e->last_return;
+    o->ep_len = e->ep_len; o->done = e->done; o->step_count = e->step_count;
+    return TRS_OK;
+}
+
+EXPORT int trso_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
+{
+    if (!e || !dst) return fail(TRS_ERR_ARG, "null argument");
+    const void* src = NULL; size_t need = 0; size_t n = (size_t)e->n;
+    switch (which) {
+    case TRS_F_IMG: src = e->img; need = n * e->H * e->W * 3; break;
+    case TRS_F_POS_X: src = e->x; need = n * 4; break;
+    case TRS_F_POS_Y: src = e->y; need = n * 4; break;
+    case TRS_F_POS_Z: src = e->z; need = n * 4; break;
+    case TRS_F_SPEED: src = e->speed; need = n * 4; break;
+    case TRS_F_CTE: src = e->cte; need = n * 4; break;
+    case TRS_F_YAW: src = e->yaw; need = n * 4; break;
+    case TRS_F_VEL: src = e->v; need = n * 4; break;
+    case TRS_F_SEG_IDX: src = e->seg_idx; need = n * 4; break;
+    case TRS_F_EP_RETURN: src = e->ep_return; need = n * 4; break;
+    case TRS_F_LAST_RETURN: src = e->last_return; need = n * 4; break;
+    case TRS_F_EP_LEN: src = e->ep_len; need = n * 4; break;
+    case TRS_F_DONE: src = e->done; need = n; break;
+    case TRS_F_MAP: src = e->map; need = (size_t)e->mi.map_words * e->mi.map_h * 4; break;
+    case TRS_F_ROWTAB: src = e->rowtab; need = (size_t)e->H * 8; break;
+    case TRS_F_PALETTE: src = e->pal; need = (size_t)e->H * 16; break;
+    case TRS_F_TANGENT: src = e->tang; need = (size_t)e->np * 8; break;
+    case TRS_F_STEER_FILT: src = e->steer_filt; need = n * 4; break;
+    default: return fail(TRS_ERR_ARG, "unknown field");
+    }
+    if (!src) return fail(TRS_ERR_STATE, "field not available");
+    if (bytes != need) return fail(TRS_ERR_ARG, "byte count mismatch");
+    memcpy(dst, src, need);
+    return TRS_OK;
+}
+
+EXPORT int trso_set_pose(trs_env* e, const float* x, const float* y, const float* z, const float* yaw, const float* v)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    for (int i = 0; i < e->n; ++i) {
+        if (x) e->x[i] = x[i];
+        if (y) e->y[i] = y[i];
+        if (z) e->z[i] = z[i];
+        if (yaw) e->yaw[i] = yaw[i];
+        if (v) e->v[i] = v[i];
+        e->pending[i] = 0; e->done[i] = 0;
+    }
+    return TRS_OK;
+}
+
+EXPORT int trso_locate(trs_env* e, const double* xyz, int nq, int32_t* idx)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    if (nq < 0 || (nq && (!xyz || !idx))) return fail(TRS_ERR_ARG, "bad query");
+#pragma omp parallel for schedule(static) num_threads(e->threads)
+    for (int q = 0; q < nq; ++q) idx[q] = l1_nearest(e, xyz[3 * q], xyz[3 * q + 1], xyz[3 * q + 2], NULL);
+    return TRS_OK;
+}
+
+EXPORT int trso_map_info_get(trs_env* e, trs_map_info* o)
+{
+    if (!e || !o || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    *o = e->mi; o->lds_bytes = 0;
+    return TRS_OK;
+}
+
+EXPORT int trso_sync(trs_env* e) { (void)e; return TRS_OK; }
+EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return TRS_OK; }
+EXPORT int trso_event_elapsed_ms(trs_env* e, int a, int b, float* ms) { (void)e; (void)a; (void)b; if (ms) *ms = 0.0f; return TRS_OK; }
+EXPORT int trso_device_count(int* out) { if (out) *out = 0; return TRS_OK; }
+EXPORT const char* trso_last_error(void) { return g_err; }
+
+/* oracle-only: number of OpenMP threads used by step / locate (cpu_baseline "cores") */
+EXPORT int trso_set_threads(trs_env* e, int n)
+{
+    if (!e || n < 1) return fail(TRS_ERR_ARG, "bad thread count");
+#ifdef _OPENMP
+    int mx = omp_get_num_procs();
+    e->threads = n > mx ? mx : n;
+#else
+    e->threads = 1;
+#endif
+    return e->threads;
+}

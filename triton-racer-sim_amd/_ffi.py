@@ -1,0 +1,110 @@
+"""ctypes binding of the C ABI declared in ``include/trsim.h``.
+
+This is the reference-side stub a maintainer of Triton-Racer-Sim would add (the reference is
+Python, so its FFI is ctypes).  ``bind(cdll, prefix)`` types every entry
+point; ``load_hip_library()`` opens the in-tree HIP build and FAILS LOUDLY when it is missing —
+there is no CPU fallback in the product.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libtrsim.so")
+
+
+class TrsConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_envs", C.c_int32), ("env_id_base", C.c_int32),
+        ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("render", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint64),
+        ("dt", C.c_float), ("max_steer", C.c_float), ("inv_wheelbase", C.c_float), ("accel_max", C.c_float),
+        ("drag_lin", C.c_float), ("roll_res", C.c_float), ("brake_max", C.c_float),
+        ("v_max", C.c_float), ("v_rev_max", C.c_float), ("offtrack_cte", C.c_float),
+        ("offtrack_penalty", C.c_float), ("cam_fwd", C.c_float),
+        ("road_half", C.c_double), ("edge_half", C.c_double), ("centre_half", C.c_double),
+        ("dash_period", C.c_double), ("dash_on", C.c_double), ("map_margin", C.c_double),
+        ("fov_v_deg", C.c_double), ("cam_h", C.c_double), ("cam_pitch_deg", C.c_double), ("z_far", C.c_double),
+    ]
+
+
+class TrsStateView(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32), ("n_points", C.c_int32),
+        ("img", C.c_void_p),
+        ("pos_x", C.c_void_p), ("pos_y", C.c_void_p), ("pos_z", C.c_void_p), ("speed", C.c_void_p), ("cte", C.c_void_p),
+        ("yaw", C.c_void_p), ("vel", C.c_void_p), ("seg_idx", C.c_void_p),
+        ("ep_return", C.c_void_p), ("last_return", C.c_void_p), ("ep_len", C.c_void_p), ("done", C.c_void_p),
+        ("step_count", C.c_uint64),
+    ]
+
+
+class TrsMapInfo(C.Structure):
+    _fields_ = [
+        ("map_w", C.c_int32), ("map_h", C.c_int32), ("map_words", C.c_int32),
+        ("cell", C.c_double), ("x0", C.c_double), ("z0", C.c_double),
+        ("n_points", C.c_int32), ("lds_bytes", C.c_int32),
+    ]
+
+
+# selectors of trs_copy_to_host: name -> (enum value, numpy dtype string, per-env? shape tag)
+FIELDS = {
+    "img": 0, "pos_x": 1, "pos_y": 2, "pos_z": 3, "speed": 4, "cte": 5, "yaw": 6, "vel": 7,
+    "seg_idx": 8, "ep_return": 9, "last_return": 10, "ep_len": 11, "done": 12,
+    "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17,
+}
+
+# every symbol include/trsim.h declares (suffix after the prefix)
+SYMBOLS = [
+    "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic",
+    "get_state", "copy_to_host", "set_pose", "locate", "map_info_get", "sync", "event_record",
+    "event_elapsed_ms", "device_count", "last_error",
+]
+
+
+class Api:
+    """Typed function table of one loaded library (``trs_*`` for HIP, ``trso_*`` for the test oracle)."""
+
+    def __init__(self, cdll, prefix):
+        self.cdll, self.prefix = cdll, prefix
+        vp, i32, fp, u8p, dp = C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p
+        sigs = {
+            "default_config": (None, [C.POINTER(TrsConfig)]),
+            "create": (i32, [C.POINTER(TrsConfig), i32, C.POINTER(vp)]),
+            "destroy": (i32, [vp]),
+            "load_track": (i32, [vp, dp, i32]),
+            "reset": (i32, [vp, u8p]),
+            "step": (i32, [vp, fp, fp, fp, u8p, i32]),
+            "step_host": (i32, [vp, fp, fp, fp, u8p, i32]),
+            "step_synthetic": (i32, [vp, i32, i32]),
+            "get_state": (i32, [vp, C.POINTER(TrsStateView)]),
+            "copy_to_host": (i32, [vp, i32, vp, C.c_size_t]),
+            "set_pose": (i32, [vp, fp, fp, fp, fp, fp]),
+            "locate": (i32, [vp, dp, i32, vp]),
+            "map_info_get": (i32, [vp, C.POINTER(TrsMapInfo)]),
+            "sync": (i32, [vp]),
+            "event_record": (i32, [vp, i32]),
+            "event_elapsed_ms": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
+            "device_count": (i32, [C.POINTER(i32)]),
+            "last_error": (C.c_char_p, []),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(cdll, prefix + name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.last_error()
+            raise RuntimeError(f"{self.prefix}{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def load_hip_library(path=None):
+    """Open ``csrc/libtrsim.so`` (built by ``__graft_entry__.build()``); no fallback of any kind."""
+    path = path or HIP_LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The product has no CPU fallback.")
+    return Api(C.CDLL(path, mode=C.RTLD_LOCAL), "trs_")

@@ -1,0 +1,135 @@
+"""Drop-in parts for the reference's ``Car`` loop, backed by the HIP env.
+
+``HipGymInterface`` replaces ``GymInterface`` (reference ``components/gyminterface.py:47-104``): same
+constructor keywords, same port names, same return order and Python types — but the external Unity
+simulator, the TCP/JSON/JPEG round trip and the two 1 s start-up sleeps are gone: physics and camera run
+in-process on the GPU.  ``LocationTracker`` replaces ``components/track_data_process.py:68-107`` with the
+exact same integer index, computed by the HIP nearest-point kernel.
+
+Swap in ``car_templates/manage.py:72-75``::
+
+    from triton_racer_sim_amd.components import HipGymInterface as GymInterface
+"""
+import numpy as np
+
+from .core import Component
+from .env import BatchedEnv
+
+GYM_INPUTS = ["mux/steering", "mux/throttle", "mux/breaking", "usr/reset"]       # gyminterface.py:52
+GYM_OUTPUTS = ["cam/img", "gym/x", "gym/y", "gym/z", "gym/speed", "gym/cte"]     # gyminterface.py:52
+
+# keys of the reference's gym_config the env understands (gyminterface.py:16-45, core/config.py:8-9,94-101)
+DEFAULT_GYM_CONFIG = {
+    "img_w": 160, "img_h": 120, "scene_name": "generated_track", "sim_latency": 0,
+    "track_data_file": "track_data/generated_track.json", "hip_device": 0,
+}
+
+_SCENE_TRACKS = {"generated_track": "generated_track.json", "mountain_track": "mountain_track.json"}
+
+
+def _track_for(cfg):
+    scene = cfg.get("scene_name", "generated_track")
+    if scene in _SCENE_TRACKS:
+        return _SCENE_TRACKS[scene]
+    return cfg.get("track_data_file", "track_data/generated_track.json")
+
+
+class HipGymInterface(Component):
+    """One car (N = 1).  ``step(steering, throttle, breaking, reset) -> (img, x, y, z, speed, cte)``."""
+
+    def __init__(self, poll_socket_sleep_time=0.01, gym_config=None, _api=None):
+        self.gym_config = dict(DEFAULT_GYM_CONFIG)          # a private copy: the reference mutates its module-level
+        self.gym_config.update(gym_config or {})            # default in place (gyminterface.py:50-51) — not kept
+        Component.__init__(self, inputs=list(GYM_INPUTS), outputs=list(GYM_OUTPUTS), threaded=False)
+        self.latency = self.gym_config["sim_latency"]
+        self.env = BatchedEnv(n_envs=1, track=_track_for(self.gym_config), device=self.gym_config.get("hip_device", 0),
+                              img_h=int(self.gym_config["img_h"]), img_w=int(self.gym_config["img_w"]), render=True, _api=_api)
+        self.last_image = None
+        self.pos_x = self.pos_y = self.pos_z = self.speed = self.cte = 0.0
+        self.seg_idx = 0
+
+    def step(self, *args):
+        steering, throttle, breaking, reset = args[0], args[1], args[2], args[3]
+        if breaking is None:                                  # gyminterface.py:70
+            breaking = 0.0
+        if steering is None or throttle is None:              # first tick: the mux has not produced anything yet
+            steering, throttle = 0.0, 0.0
+        self.env.step(float(steering), float(throttle), float(breaking), reset=bool(reset))
+        # a fresh ndarray per frame, never overwritten by later steps (ownership rule of gyminterface.py:99)
+        self.last_image = self.env.fetch("img")[0]
+        self.pos_x = float(self.env.fetch("pos_x")[0])        # Python floats: json.dump needs them (gyminterface.py:100-104)
+        self.pos_y = float(self.env.fetch("pos_y")[0])
+        self.pos_z = float(self.env.fetch("pos_z")[0])
+        self.speed = float(self.env.fetch("speed")[0])
+        self.cte = float(self.env.fetch("cte")[0])
+        self.seg_idx = int(self.env.fetch("seg_idx")[0])
+        return self.last_image, self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte
+
+    def onStart(self):
+        print(f"HipGymInterface: in-process env on GPU {self.env.device}; artificial latency setting ignored ({self.latency}ms).")
+
+    def onShutdown(self):
+        self.env.close()
+
+    def getName(self):
+        return "Gym Interface"
+
+
+class BatchedGymInterface(Component):
+    """N cars per tick: the same ports carry arrays (controls: float32[N] or scalars; outputs stay on the
+    device — ``cam/img`` etc. are ``__cuda_array_interface__`` handles unless ``to_host=True``)."""
+
+    def __init__(self, n_envs, gym_config=None, to_host=False, auto_reset=True, env_id_base=0, _api=None):
+        self.gym_config = dict(DEFAULT_GYM_CONFIG)
+        self.gym_config.update(gym_config or {})
+        Component.__init__(self, inputs=list(GYM_INPUTS), outputs=list(GYM_OUTPUTS) + ["loc/index", "gym/done"], threaded=False)
+        self.to_host = to_host
+        self.env = BatchedEnv(n_envs=n_envs, track=_track_for(self.gym_config), device=self.gym_config.get("hip_device", 0),
+                              img_h=int(self.gym_config["img_h"]), img_w=int(self.gym_config["img_w"]), render=True,
+                              auto_reset=auto_reset, env_id_base=env_id_base, _api=_api)
+
+    def step(self, *args):
+        steering, throttle, breaking, reset = args
+        if steering is None or throttle is None:
+            steering, throttle = 0.0, 0.0
+        self.env.step(steering, throttle, breaking, reset=None if reset is None else reset)
+        names = ["img", "pos_x", "pos_y", "pos_z", "speed", "cte", "seg_idx", "done"]
+        if self.to_host:
+            return tuple(self.env.fetch(n) for n in names)
+        return tuple(self.env.device_array(n) for n in names)
+
+    def onShutdown(self):
+        self.env.close()
+
+    def getName(self):
+        return "Batched Gym Interface"
+
+
+class LocationTracker(Component):
+    """``gym/x, gym/y, gym/z -> loc/segment`` with the reference's exact index semantics
+    (``components/track_data_process.py:89-107``: L1 over all three coordinates in binary64, best = 100,
+    strict '<', first minimum wins), evaluated by the HIP nearest-point kernel."""
+
+    def __init__(self, track_data_path, min_map=0, max_map=10, device=0, _api=None):
+        Component.__init__(self, inputs=["gym/x", "gym/y", "gym/z"], outputs=["loc/segment"])
+        self.env = BatchedEnv(n_envs=1, track=track_data_path, device=device, render=False, _api=_api)
+        self.data = self.env.track
+        self.max = max_map
+        self.min = min_map
+
+    def localize_index(self, points):
+        return self.env.locate(points)
+
+    def localize(self, point):
+        idx = int(self.env.locate(np.asarray(point, dtype=np.float64).reshape(1, 3))[0])
+        return idx / float(len(self.data)) * (self.max - self.min) + self.min, 0.0
+
+    def step(self, *args):
+        segment, _ = self.localize((args[0], args[1], args[2]))   # raises TypeError on None like the reference
+        return segment,
+
+    def onShutdown(self):
+        self.env.close()
+
+    def getName(self):
+        return "Location Tracker"

@@ -1,0 +1,192 @@
+"""``BatchedEnv`` — one shard of N in-process envs on one MI355X, over the C ABI of ``include/trsim.h``.
+
+It is the batched form of what the reference's per-car ``GymInterface`` does for one car
+(``TritonRacerSim/components/gyminterface.py:49-104``): controls in, ``(image, x, y, z, speed, cte)``
+out, plus ``LocationTracker``'s index (``components/track_data_process.py:89-107``).  All outputs stay
+device-resident; host copies happen only on request (``fetch``).
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TRACK_DIR = os.path.join(_HERE, "track_data")
+
+_FIELD_DTYPES = {
+    "img": np.uint8, "pos_x": np.float32, "pos_y": np.float32, "pos_z": np.float32, "speed": np.float32,
+    "cte": np.float32, "yaw": np.float32, "vel": np.float32, "seg_idx": np.int32, "ep_return": np.float32,
+    "last_return": np.float32, "ep_len": np.int32, "done": np.uint8, "map": np.uint32, "rowtab": np.float32,
+    "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32,
+}
+
+
+def resolve_track(track):
+    """Accepts an ``(n,3)`` array, a JSON path, or a scene / file name as the reference configs use them
+    (``scene_name`` ``core/config.py:94``, ``track_data_file`` ``core/config.py:101``)."""
+    if isinstance(track, (list, tuple, np.ndarray)):
+        pts = np.asarray(track, dtype=np.float64)
+    else:
+        name = str(track)
+        candidates = [name, os.path.join(TRACK_DIR, name), os.path.join(TRACK_DIR, os.path.basename(name)),
+                      os.path.join(TRACK_DIR, os.path.splitext(os.path.basename(name))[0] + ".json")]
+        for c in candidates:
+            if os.path.isfile(c):
+                with open(c) as f:
+                    pts = np.asarray(json.load(f), dtype=np.float64)
+                break
+        else:
+            raise FileNotFoundError(f"no track data for {track!r} (looked in {TRACK_DIR})")
+    if pts.ndim != 2 or pts.shape[1] != 3 or pts.shape[0] < 2:
+        raise ValueError("track must be an (n>=2, 3) array of [x, y, z]")
+    return np.ascontiguousarray(pts)
+
+
+class _DevicePtr:
+    """Zero-copy view of a device array for torch / cupy (``__cuda_array_interface__`` v2)."""
+
+    def __init__(self, ptr, shape, dtype, owner):
+        self._owner = owner
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2, "strides": None,
+        }
+
+
+class BatchedEnv:
+    def __init__(self, n_envs=1, track="generated_track", device=0, img_h=120, img_w=160, render=True,
+                 auto_reset=False, env_id_base=0, seed=None, _api=None, **overrides):
+        # `_api` exists for tests only (they pass the oracle's function table to diff both through one
+        # wrapper); the product path always binds the HIP library and raises if it is not built.
+        self.api = _api if _api is not None else _ffi.load_hip_library()
+        cfg = _ffi.TrsConfig()
+        self.api.default_config(C.byref(cfg))
+        cfg.n_envs, cfg.env_id_base, cfg.img_h, cfg.img_w = int(n_envs), int(env_id_base), int(img_h), int(img_w)
+        cfg.render, cfg.auto_reset = int(bool(render)), int(bool(auto_reset))
+        if seed is not None:
+            cfg.seed = int(seed)
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown env parameter {k!r}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.n, self.H, self.W = int(n_envs), int(img_h), int(img_w)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        self.api.check(self.api.create(C.byref(cfg), self.device, C.byref(self._h)), "create")
+        self.track = None
+        self.map_info = None
+        if track is not None:
+            self.load_track(track)
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.api.destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_track(self, track):
+        pts = resolve_track(track)
+        self.api.check(self.api.load_track(self._h, pts.ctypes.data, int(pts.shape[0])), "load_track")
+        self.track = pts
+        mi = _ffi.TrsMapInfo()
+        self.api.check(self.api.map_info_get(self._h, C.byref(mi)), "map_info_get")
+        self.map_info = mi
+
+    @property
+    def n_points(self):
+        return 0 if self.track is None else int(self.track.shape[0])
+
+    # -- stepping ----------------------------------------------------------------------------
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if m is not None and m.shape != (self.n,):
+            raise ValueError("mask must have shape (n_envs,)")
+        self.api.check(self.api.reset(self._h, None if m is None else m.ctypes.data), "reset")
+
+    def _ctl(self, a, name, optional=False):
+        if a is None:
+            if optional:
+                return None
+            raise ValueError(f"{name} is required")
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (self.n,)))
+        return arr
+
+    def step(self, steering, throttle, brake=None, reset=None, n_steps=1):
+        """Host-array controls (numpy / scalars).  Asynchronous; ``fetch`` synchronises."""
+        st, th, br = self._ctl(steering, "steering"), self._ctl(throttle, "throttle"), self._ctl(brake, "brake", True)
+        rs = None if reset is None else np.ascontiguousarray(np.broadcast_to(np.asarray(reset).astype(bool), (self.n,)), dtype=np.uint8)
+        self.api.check(self.api.step_host(self._h, st.ctypes.data, th.ctypes.data, None if br is None else br.ctypes.data,
+                                          None if rs is None else rs.ctypes.data, int(n_steps)), "step_host")
+
+    def step_device(self, d_steering, d_throttle, d_brake=0, d_reset=0, n_steps=1):
+        """Raw device pointers (ints), e.g. ``tensor.data_ptr()`` of float32 / uint8 CUDA tensors."""
+        self.api.check(self.api.step(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
+                                     int(n_steps)), "step")
+
+    def step_synthetic(self, n_steps=1, steps_per_launch=1):
+        self.api.check(self.api.step_synthetic(self._h, int(n_steps), int(steps_per_launch)), "step_synthetic")
+
+    def sync(self):
+        self.api.check(self.api.sync(self._h), "sync")
+
+    # -- outputs -----------------------------------------------------------------------------
+    def _shape(self, name):
+        mi = self.map_info
+        return {
+            "img": (self.n, self.H, self.W, 3), "map": (mi.map_h, mi.map_words) if mi else None,
+            "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2),
+        }.get(name, (self.n,))
+
+    def fetch(self, name):
+        """Synchronising device→host copy of one output field as a fresh numpy array."""
+        shape = self._shape(name)
+        out = np.empty(shape, dtype=_FIELD_DTYPES[name])
+        self.api.check(self.api.copy_to_host(self._h, _ffi.FIELDS[name], out.ctypes.data, out.nbytes), f"copy_to_host({name})")
+        return out
+
+    def state_view(self):
+        sv = _ffi.TrsStateView()
+        self.api.check(self.api.get_state(self._h, C.byref(sv)), "get_state")
+        return sv
+
+    def device_array(self, name):
+        """Zero-copy handle (``__cuda_array_interface__``) on a device-resident output; use
+        ``torch.as_tensor(env.device_array('ep_return'), device='cuda')``."""
+        sv = self.state_view()
+        ptr = getattr(sv, name)
+        if not ptr:
+            raise RuntimeError(f"{name} is not available")
+        return _DevicePtr(ptr, self._shape(name), _FIELD_DTYPES[name], self)
+
+    def set_pose(self, x=None, y=None, z=None, yaw=None, v=None):
+        arrs = [None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (self.n,))) for a in (x, y, z, yaw, v)]
+        self.api.check(self.api.set_pose(self._h, *[None if a is None else a.ctypes.data for a in arrs]), "set_pose")
+
+    def locate(self, points):
+        """Batched ``LocationTracker.__find_closest`` (``track_data_process.py:89-101``) → int32 indices."""
+        q = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 3))
+        out = np.empty(q.shape[0], dtype=np.int32)
+        self.api.check(self.api.locate(self._h, q.ctypes.data, int(q.shape[0]), out.ctypes.data), "locate")
+        return out
+
+    def segment(self, idx, min_map=0.0, max_map=10.0):
+        """``LocationTracker.__map`` (``track_data_process.py:106-107``): index → 'loc/segment' float."""
+        return np.asarray(idx, dtype=np.float64) / float(self.n_points) * (max_map - min_map) + min_map
+
+    # -- timing (HIP events on the handle's stream) -------------------------------------------
+    def event_record(self, slot):
+        self.api.check(self.api.event_record(self._h, int(slot)), "event_record")
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.api.check(self.api.event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)), "event_elapsed_ms")
+        return float(ms.value)
