@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the fused physics + camera step on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 1024] [--steps-per-launch 1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over every env of every shard: bicycle-model integration, binary64
+nearest-point index, cte/done/return, and one 120x160 RGB frame per env written to HBM (inputs and
+outputs device-resident; controls from the counter-based generator of include/trsim_spec.h).
+Workload = BASELINE.json configs[2] (1024 envs, physics + 120x160 RGB pinhole rasteriser, one MI355X);
+with N GPUs every rank owns its own 1024-env shard (weak scaling) and the job ends with the single
+RCCL all-gather of episode returns.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(h, w, render):
+    # H*W*3 image bytes written once + 88 B of state / control / telemetry per env-step
+    return (h * w * 3 if render else 0) + 88
+
+
+def usable_cores():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU box grants a
+    16-CPU share of a 256-thread host; oversubscribing OpenMP there runs slower than one thread)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    cores = min(cores, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    cores = min(cores, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return min(cores, int(os.environ.get("TRS_CPU_BASELINE_THREADS", "16")))
+
+
+def cpu_baseline(n_envs, h, w, budget_s=12.0):
+    """Times the CPU oracle (kind "port": the reference has no dynamics/camera to run, and its Python cannot
+    travel) on this host, on a bounded sample of the same workload.  Checker code is only TIMED here."""
+    import numpy as np
+    from triton_racer_sim_amd import _ffi
+    from triton_racer_sim_amd.env import BatchedEnv
+    lib = os.path.join(ROOT, "oracle", "libtrsim_oracle.so")
+    if not os.path.exists(lib):
+        return None
+    api = _ffi.Api(ctypes.CDLL(lib), "trso_")
+    cores = usable_cores()
+    env = BatchedEnv(n_envs=n_envs, img_h=h, img_w=w, auto_reset=True, _api=api)
+    set_threads = api.cdll.trso_set_threads
+    set_threads.restype, set_threads.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
+    out = {}
+    for label, threads, budget in (("all", cores, budget_s * 0.6), ("one", 1, budget_s * 0.25)):
+        used = set_threads(env._h, threads)
+        env.step_synthetic(1, 1)
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            env.step_synthetic(2, 1)
+            steps += 2
+        dt = time.perf_counter() - t0
+        out[label] = (n_envs * steps / dt, used, steps)
+    env.close()
+    # what the reference itself executes per tick, minus the external simulator:
+    # Car-style tick + dict pool + pure-Python L1 nearest-point (oracle/pyref.py restates track_data_process.py:89-104)
+    py_rate = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyref
+        py_rate = pyref.time_reference_loop(budget_s * 0.15)
+    except Exception:
+        py_rate = None
+    v, used, steps = out["all"]
+    return {
+        "value": round(v, 1), "unit": "env-steps/s", "cores": used, "kind": "port",
+        "sample": f"oracle/libtrsim_oracle.so (scalar C + OpenMP over envs), {n_envs} envs x {steps} steps of the same workload",
+        "single_thread": round(out["one"][0], 1),
+        "python_reference_loop_1env": None if py_rate is None else round(py_rate, 1),
+        "reference_design_ceiling": "20 env-steps/s per car (car_templates/manage.py:38)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs-per-gpu", type=int, default=1024)
+    ap.add_argument("--img-h", type=int, default=120)
+    ap.add_argument("--img-w", type=int, default=160)
+    ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    from triton_racer_sim_amd.env import BatchedEnv
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = args.envs_per_gpu
+    render = not args.no_render
+    env = BatchedEnv(n_envs=n, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render,
+                     auto_reset=True, env_id_base=rank * n)
+    spl = max(1, args.steps_per_launch)
+
+    def barrier():
+        env.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if dist is not None:   # warm the communicator outside the timed region
+        warm = torch.zeros(n * world, device="cuda")
+        dist.all_gather_into_tensor(warm, torch.zeros(n, device="cuda"))
+    env.step_synthetic(max(args.warmup, 1), spl)
+
+    barrier()
+    t0 = time.perf_counter()
+    env.event_record(0)
+    env.step_synthetic(args.steps, spl)
+    env.event_record(1)
+    gathered = None
+    if dist is not None:
+        env.sync()                                                     # returns are final before the exchange
+        local = torch.as_tensor(env.device_array("ep_return"), device="cuda")
+        gathered = torch.empty(n * world, device="cuda", dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered, local)                   # the single RCCL all-gather over xGMI
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = env.event_elapsed_ms(0, 1)
+
+    if dist is not None:
+        tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    if rank == 0:
+        total_env_steps = n * world * args.steps
+        value = total_env_steps / wall
+        B = algorithmic_bytes(args.img_h, args.img_w, render)
+        launches = (args.steps + spl - 1) // spl
+        avg_launch_s = kernel_ms * 1e-3 / launches
+        achieved = B * n * spl / avg_launch_s / 1e9                   # GB/s of algorithmic bytes, dominant (only) kernel
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get(f"{n}x{args.img_h}x{args.img_w}x{spl}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/s (whole node) at N envs x 120x160 RGB",
+            "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 state / f64 nearest-point / u8 image", "data": "synthetic",
+            "config": {
+                "workload": f"{n} envs/GPU x {world} GPU, bicycle physics + L1 nearest point"
+                            + (f" + {args.img_h}x{args.img_w} RGB pinhole rasteriser" if render else " (no camera)")
+                            + " (BASELINE configs[2] per GPU), generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
+                "envs_total": n * world, "steps_per_launch": spl, "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "trs_step_kernel", "avg_launch_us": round(avg_launch_s * 1e6, 3), "bytes_per_env_step": B,
+                "env_steps_per_launch": n * spl,
+            },
+        }
+        if gathered is not None:
+            line["config"]["allgather_returns_mean"] = round(float(gathered.mean().item()), 4)
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(min(n, 1024), args.img_h, args.img_w) if render else None
+            if cb:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+// trsim_tables.hpp — host-side (one-time, at trs_load_track) construction of the read-only tables the
+// step kernel stages into LDS: per-point tangents / start headings, the packed 2-bit surface-class map,
+// the per-image-row camera table and the per-row fogged palette.  Follows include/trsim_spec.h; all of
+// it is binary64 arithmetic with IEEE +,-,*,/,sqrt,floor plus libm tan/sin/cos/atan2/fmod evaluated on
+// the host, built with -ffp-contract=off.
+//
+// Track input: the raw [x,y,z] samples the reference's LocationTracker loads
+// (TritonRacerSim/components/track_data_process.py:72-73), duplicates kept.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/trsim.h"
+
+namespace trsim {
+
+struct TrackTables {
+    int n_points = 0;
+    std::vector<double> px, py, pz;        // raw points (SoA, binary64)
+    std::vector<float> tangent;            // [n][2] unit (tx, tz)
+    std::vector<float> start_yaw;          // [n]
+    trs_map_info info{};
+    std::vector<uint32_t> map;             // [map_h][map_words], 16 cells per word, cell ix at bits 2*(ix&15)
+    std::vector<float> rowtab;             // [H][2]
+    std::vector<uint32_t> palette;         // [H][4] 0x00BBGGRR
+    float map_x0f = 0, map_z0f = 0, inv_cellf = 0;
+};
+
+// returns TRS_OK or a negative trs_status, message in `err`
+int build_tables(const trs_config& cfg, const double* xyz, int n_points, TrackTables& out, std::string& err);
+
+}  // namespace trsim
