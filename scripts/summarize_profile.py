@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise a scripts/profile.sh output directory: per-kernel stats + mean PMC values per dispatch."""
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("== kernel stats:", os.path.relpath(f, out))
+    with open(f) as fh:
+        for i, row in enumerate(csv.reader(fh)):
+            if i < 8: print("  ", ",".join(row[:8]))
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    by = collections.defaultdict(list)
+    for r in rows:
+        by[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, v in by.items():
+        v.sort()
+        print(f"== trace {k[:60]}: n={len(v)} mean={sum(v)/len(v)/1e3:.3f}us median={v[len(v)//2]/1e3:.3f}us min={v[0]/1e3:.3f}us")
+    step = [r for r in rows if "trs_step" in r["Kernel_Name"]]
+    if step:
+        r = step[-1]
+        print("   regs:", {k: r[k] for k in r if k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size", "Accum_VGPR_Count")})
+        ts = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in step)
+        gaps = [ts[i + 1][0] - ts[i][1] for i in range(len(ts) - 1)]
+        gaps.sort()
+        print(f"   inter-kernel gap: median={gaps[len(gaps)//2]/1e3:.3f}us mean={sum(gaps)/len(gaps)/1e3:.3f}us")
+for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in acc.items():
+        if "trs_step" not in k: continue
+        print("== pmc", os.path.basename(os.path.dirname(os.path.dirname(f))), k[:50])
+        for c, v in d.items():
+            print(f"   {c}: mean/dispatch={sum(v)/len(v):.1f} n={len(v)}")

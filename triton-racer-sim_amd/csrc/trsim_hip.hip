@@ -41,7 +41,7 @@ namespace {
 
 constexpr int kBlock = 960;            // 15 waves: 4800 four-pixel groups of a 120x160 image = 5 x 960
 constexpr int kWaves = kBlock / 64;
-constexpr int kEMax = 16;              // envs of one workgroup processed per chunk
+constexpr int kEMax = 15;              // envs of one workgroup processed per chunk (<= one wave each in the search)
 constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
 
 struct KParams {
@@ -59,12 +59,12 @@ struct KParams {
     int n_envs, env_id_base, envs_per_wg;
     int np, H, W, gpr, gpe;            // groups (4 px) per row / per env
     unsigned row_magic;                // q / gpr == umulhi(q, row_magic) for q < gpe (checked on the host)
-    int map_w, map_h, map_words;
+    int map_w, map_h, map_words, map_pitch_b;   // map_pitch_b: bytes per map row in the LDS image (odd number of words)
     int off_py, off_pz, off_map, off_rowtab, off_pal, blob_bytes, off_scratch;
     float map_x0f, map_z0f, inv_cellf;
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
     float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
-    int auto_reset, render, synth, n_steps, img_parity;
+    int auto_reset, render, synth, n_steps, img_parity, stage_bytes, rows_per_pass;
     uint32_t step0;
     unsigned long long seed;
 };
@@ -89,18 +89,40 @@ __device__ __forceinline__ void spec_sincos(float a, float& so, float& co)
 
 __device__ __forceinline__ float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
-// wave64 butterfly argmin over (distance, index): smaller distance wins, equal distance -> lower index.
-// Every lane ends with the wave's result.
+// wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.
+// DPP reduction (row_shr 1,2,4,8 then row_bcast15 / row_bcast31): data moves through the VALU's DPP path
+// instead of the LDS crossbar that __shfl (ds_bpermute) uses.  The wave's result ends in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_dpp_step(double& d, int& i)
+{
+    const int lo = __double2loint(d), hi = __double2hiint(d);
+    // lanes without a valid source (row edge / masked rows) read their own value: combining with self is a no-op
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    const double od = __hiloint2double(ohi, olo);
+    const bool take = (od < d) || (od == d && oi < i);
+    d = take ? od : d;
+    i = take ? oi : i;
+}
+
 __device__ __forceinline__ void wave_argmin(double& d, int& i)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double od = __shfl_xor(d, off, 64);
-        const int oi = __shfl_xor(i, off, 64);
-        const bool take = (od < d) || (od == d && oi < i);
-        d = take ? od : d;
-        i = take ? oi : i;
-    }
+    argmin_dpp_step<0x111, 0xf>(d, i);   // row_shr:1
+    argmin_dpp_step<0x112, 0xf>(d, i);   // row_shr:2
+    argmin_dpp_step<0x114, 0xf>(d, i);   // row_shr:4
+    argmin_dpp_step<0x118, 0xf>(d, i);   // row_shr:8   -> lane 15 of each row holds the row's result
+    argmin_dpp_step<0x142, 0xa>(d, i);   // row_bcast:15 into rows 1 and 3
+    argmin_dpp_step<0x143, 0xc>(d, i);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+}
+
+__device__ __forceinline__ unsigned cvt_u32_sat(float x)
+{
+    // v_cvt_u32_f32: truncate toward zero, saturate (negative / NaN -> 0).  For the rasteriser's
+    // clamp(floor(g), 0, G-1) this equals min(cvt_u32_sat(g), G-1): g < 0 -> 0, g >= 0 -> trunc == floor.
+    unsigned r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 __device__ __forceinline__ void synth_controls(unsigned long long seed, uint32_t gid, uint32_t step, float& sf, float& steer, float& thr)
@@ -130,20 +152,19 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        const int n16 = p.blob_bytes >> 4;
+        const int n16 = p.stage_bytes >> 4;     // physics-only launches stage just the track points
         for (int i = tid; i < n16; i += kBlock) dst[i] = src[i];
     }
     const double* lpx = reinterpret_cast<const double*>(smem);
     const double* lpy = reinterpret_cast<const double*>(smem + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(smem + p.off_pz);
-    const uint32_t* lmap = reinterpret_cast<const uint32_t*>(smem + p.off_map);
     const float2* lrow = reinterpret_cast<const float2*>(smem + p.off_rowtab);
     const uint32_t* lpal = reinterpret_cast<const uint32_t*>(smem + p.off_pal);
-    // scratch
-    double* sq = reinterpret_cast<double*>(smem + p.off_scratch);                 // [3][kEMax] query points
+    // scratch (16-B aligned base): camera params first (float4), then binary64 arrays, then ints
+    float4* scam = reinterpret_cast<float4*>(smem + p.off_scratch);               // [kEMax] camx, camz, s, c
+    double* sq = reinterpret_cast<double*>(scam + kEMax);                         // [3][kEMax] query points
     double* spd = sq + 3 * kEMax;                                                 // [kEMax][kWaves] partial distance
     int* spi = reinterpret_cast<int*>(spd + kEMax * kWaves);                      // [kEMax][kWaves] partial index
-    float4* scam = reinterpret_cast<float4*>(spi + kEMax * kWaves);               // [kEMax] camx, camz, s, c
     __syncthreads();
 
     const int e_begin = blockIdx.x * p.envs_per_wg;
@@ -203,17 +224,23 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
             }
             __syncthreads();
 
-            // ---- phase A: nearest raw track point, L1 in binary64, all waves ----
-            for (int j = 0; j < nE; ++j) {
-                const double qx = sq[j], qy = sq[kEMax + j], qz = sq[2 * kEMax + j];
-                double best = TRS_LOST_L1;
-                int bi = 0;
-                for (int i = tid; i < p.np; i += kBlock) {
-                    const double d = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-                    if (d < best) { best = d; bi = i; }
+            // ---- phase A: nearest raw track point, L1 in binary64 ----
+            // the 15 waves are dealt to the chunk's envs: env j is scanned by waves [j*wpe, (j+1)*wpe), each taking
+            // an interleaved slice of the points; one DPP argmin per wave, one partial per (env, slice)
+            const int wpe = kWaves / nE;
+            {
+                const int j = wave / wpe, slice = wave - j * wpe;
+                if (j < nE) {
+                    const double qx = sq[j], qy = sq[kEMax + j], qz = sq[2 * kEMax + j];
+                    double best = TRS_LOST_L1;
+                    int bi = 0;
+                    for (int i = slice * 64 + lane; i < p.np; i += wpe * 64) {
+                        const double d = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
+                        if (d < best) { best = d; bi = i; }
+                    }
+                    wave_argmin(best, bi);
+                    if (lane == 63) { spd[j * kWaves + slice] = best; spi[j * kWaves + slice] = bi; }
                 }
-                wave_argmin(best, bi);
-                if (lane == 0) { spd[j * kWaves + wave] = best; spi[j * kWaves + wave] = bi; }
             }
             __syncthreads();
 
@@ -222,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
             if (tid < nE) {
                 double best = spd[tid * kWaves];
                 int idx = spi[tid * kWaves];
-                for (int w = 1; w < kWaves; ++w) {
+                for (int w = 1; w < wpe; ++w) {
                     const double od = spd[tid * kWaves + w];
                     const int oi = spi[tid * kWaves + w];
                     const bool take = (od < best) || (od == best && oi < idx);
@@ -267,37 +294,38 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
             __syncthreads();
 
             // ---- phase B: rasterise the chunk ----
+            // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre
+            // offsets uf are loop constants; per pixel: 2 fma, 2 saturating converts + 2 min (floor + clamp),
+            // 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette address, 1 LDS palette read.
             if (p.render) {
                 const float half_w = (float)(p.W / 2);
-                const int gwm1 = p.map_w - 1, ghm1 = p.map_h - 1;
+                const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
+                const int cg = tid % p.gpr, r0 = tid / p.gpr;       // rows_per_pass * gpr == kBlock (host-checked)
+                const float uf0 = (float)(cg << 2) + 0.5f - half_w;
+                const float uf1 = uf0 + 1.0f, uf2 = uf0 + 2.0f, uf3 = uf0 + 3.0f;
+                const unsigned char* const mapb = smem + p.off_map;
                 for (int j = 0; j < nE; ++j) {
                     const float4 cam = scam[j];
-                    uint32_t* const out = reinterpret_cast<uint32_t*>(img + (size_t)(c0 + j) * ((size_t)p.gpe * 12));
-                    for (int q = tid; q < p.gpe; q += kBlock) {
-                        const int v = (int)__umulhi((unsigned)q, p.row_magic);
-                        const int u0 = (q - v * p.gpr) << 2;
+                    unsigned char* const out = img + (size_t)(c0 + j) * ((size_t)p.gpe * 12) + (size_t)cg * 12;
+                    for (int v = (r0 < p.rows_per_pass ? r0 : p.H); v < p.H; v += p.rows_per_pass) {
                         const float2 rt = lrow[v];
-                        const uint32_t* pal = lpal + 4 * v;
+                        const unsigned char* const palb = reinterpret_cast<const unsigned char*>(lpal + 4 * v);
                         const float ax = fmaf(rt.x, cam.z, cam.x), az = fmaf(rt.x, cam.w, cam.y);
                         const float dx = rt.y * cam.w, dz = -(rt.y * cam.z);
-                        const float uf0 = (float)u0 + 0.5f - half_w;
-                        uint32_t c[4];
-#pragma unroll
-                        for (int jx = 0; jx < 4; ++jx) {
-                            const float uf = uf0 + (float)jx;
-                            const float gx = fmaf(uf, dx, ax), gz = fmaf(uf, dz, az);
-                            int ix = (int)floorf(gx), iz = (int)floorf(gz);
-                            ix = min(max(ix, 0), gwm1);
-                            iz = min(max(iz, 0), ghm1);
-                            const uint32_t w = lmap[iz * p.map_words + (ix >> 4)];
-                            const uint32_t cls = (w >> ((ix & 15) * 2)) & 3u;
-                            c[jx] = pal[cls];
-                        }
-                        // 4 x RGB (0x00BBGGRR) -> 3 little-endian dwords of the R,G,B byte stream
-                        const uint32_t w0 = c[0] | (c[1] << 24);
-                        const uint32_t w1 = (c[1] >> 8) | (c[2] << 16);
-                        const uint32_t w2 = (c[2] >> 16) | (c[3] << 8);
-                        uint32_t* o = out + (size_t)q * 3;
+                        auto shade = [&](float uf) -> uint32_t {
+                            const unsigned ix = min(cvt_u32_sat(fmaf(uf, dx, ax)), gwm1);
+                            const unsigned iz = min(cvt_u32_sat(fmaf(uf, dz, az)), ghm1);
+                            const unsigned waddr = __umul24(iz, (unsigned)p.map_pitch_b) + ((ix >> 4) << 2);
+                            const uint32_t w = *reinterpret_cast<const uint32_t*>(mapb + waddr);
+                            const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);   // offset uses bits [4:0] = 2*(ix&15)
+                            return *reinterpret_cast<const uint32_t*>(palb + (cls << 2));
+                        };
+                        const uint32_t c0p = shade(uf0), c1p = shade(uf1), c2p = shade(uf2), c3p = shade(uf3);
+                        // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
+                        const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
+                        const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
+                        const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
+                        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * ((size_t)p.gpr * 12));
                         o[0] = w0; o[1] = w1; o[2] = w2;
                     }
                 }
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned ch
             if (d < best) { best = d; bi = i; }
         }
         wave_argmin(best, bi);
-        if (lane == 0) out[qi] = bi;
+        if (lane == 63) out[qi] = bi;      // wave_argmin leaves the result in lane 63
     }
 }
 
@@ -470,14 +498,9 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     k.drag_lin = cfg->drag_lin; k.roll_res = cfg->roll_res; k.brake_max = cfg->brake_max; k.v_max = cfg->v_max;
     k.v_rev_max = cfg->v_rev_max; k.offtrack_cte = cfg->offtrack_cte; k.offtrack_penalty = cfg->offtrack_penalty;
     k.cam_fwd = cfg->cam_fwd; k.auto_reset = cfg->auto_reset; k.render = cfg->render; k.seed = cfg->seed;
-    // q / gpr by multiply-high; verify exhaustively for the group range of one env
-    {
-        const unsigned d = (unsigned)k.gpr;
-        const unsigned magic = (unsigned)((0x100000000ull + d - 1) / d);
-        for (unsigned q = 0; q < (unsigned)k.gpe; ++q)
-            if ((unsigned)(((unsigned long long)q * magic) >> 32) != q / d) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "image too large for the row divider"); }
-        k.row_magic = magic;
-    }
+    if (k.gpr > kBlock) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup"); }
+    k.rows_per_pass = kBlock / k.gpr;      // threads beyond rows_per_pass * gpr idle in the raster phase (none at W = 160: 24 x 40 = 960)
+    k.row_magic = 0;
     HIPCHK(hipStreamSynchronize(e->stream));
     *out = e;
     return TRS_OK;
@@ -507,7 +530,9 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     KParams& k = e->kp;
     // LDS image layout
     const size_t pts = align_up((size_t)n_points * 8, 16);
-    const size_t map_bytes = (size_t)T.info.map_words * T.info.map_h * 4;
+    const int pitch_words = T.info.map_words | 1;          // odd pitch: rows of the map start on different LDS banks
+    k.map_pitch_b = pitch_words * 4;
+    const size_t map_bytes = (size_t)k.map_pitch_b * T.info.map_h;
     size_t off = 0;
     k.off_py = (int)(off += pts); k.off_pz = (int)(off += pts); off += pts;
     e->pts_bytes = (int)off;
@@ -516,14 +541,16 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     k.off_pal = (int)off; off += (size_t)e->H * 16;
     k.blob_bytes = (int)off;
     k.off_scratch = (int)off;
-    const size_t scratch = 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4 + kEMax * 16;
+    k.stage_bytes = e->cfg.render ? k.blob_bytes : e->pts_bytes;
+    const size_t scratch = (size_t)kEMax * 16 + 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4;
     e->lds_bytes = (int)align_up(off + scratch, 16);
     if (e->lds_bytes > 160 * 1024) return fail(TRS_ERR_LIMIT, "tables exceed the 160 KiB LDS of a CU");
     std::vector<unsigned char> h(off, 0);
     std::memcpy(h.data(), T.px.data(), (size_t)n_points * 8);
     std::memcpy(h.data() + k.off_py, T.py.data(), (size_t)n_points * 8);
     std::memcpy(h.data() + k.off_pz, T.pz.data(), (size_t)n_points * 8);
-    std::memcpy(h.data() + k.off_map, T.map.data(), map_bytes);
+    for (int r = 0; r < T.info.map_h; ++r)
+        std::memcpy(h.data() + k.off_map + (size_t)r * k.map_pitch_b, T.map.data() + (size_t)r * T.info.map_words, (size_t)T.info.map_words * 4);
     std::memcpy(h.data() + k.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
     std::memcpy(h.data() + k.off_pal, T.palette.data(), (size_t)e->H * 16);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -648,15 +675,15 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_EP_LEN: src = k.ep_len; need = n * 4; break;
     case TRS_F_DONE: src = k.done; need = n; break;
     case TRS_F_STEER_FILT: src = k.steer_filt; need = n * 4; break;
-    case TRS_F_MAP: if (e->track_loaded) { src = e->blob + k.off_map; need = (size_t)k.map_words * k.map_h * 4; } break;
+    case TRS_F_MAP: if (e->track_loaded) { src = e->tab.map.data(); need = (size_t)k.map_words * k.map_h * 4; host_src = true; } break;
     case TRS_F_ROWTAB: if (e->track_loaded) { src = e->blob + k.off_rowtab; need = (size_t)e->H * 8; } break;
     case TRS_F_PALETTE: if (e->track_loaded) { src = e->blob + k.off_pal; need = (size_t)e->H * 16; } break;
     case TRS_F_TANGENT: if (e->track_loaded) { src = e->tangent; need = (size_t)k.np * 8; } break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
-    (void)host_src;
     if (!src) return fail(TRS_ERR_STATE, "field not available");
     if (bytes != need) return fail(TRS_ERR_ARG, "byte count mismatch");
+    if (host_src) { std::memcpy(dst, src, need); return TRS_OK; }   // the unpitched map lives on the host; its LDS image is pitched
     HIPCHK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return TRS_OK;
