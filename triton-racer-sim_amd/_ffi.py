@@ -102,7 +102,7 @@ class Api:
 
 def load_hip_library(path=None):
     """Open ``csrc/libtrsim.so`` (built by ``__graft_entry__.build()``); no fallback of any kind."""
-    path = path or HIP_LIB_PATH
+    path = path or os.environ.get("TRS_HIP_LIB") or HIP_LIB_PATH      # TRS_HIP_LIB: A/B another HIP build of the same ABI
     if not os.path.exists(path):
         raise RuntimeError(
             f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "

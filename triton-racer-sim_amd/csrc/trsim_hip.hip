@@ -35,6 +35,10 @@
 #include "../../include/trsim_spec.h"
 #include "trsim_tables.hpp"
 
+#ifndef TRS_ABLATE
+#define TRS_ABLATE 0   /* 0 = product; 1/2 = timing-only diagnostic builds (scripts/ablate.sh), never shipped */
+#endif
+
 #define TRS_EXPORT extern "C" __attribute__((visibility("default")))
 
 namespace {
@@ -53,18 +57,18 @@ struct KParams {
     const uint8_t* ctl_reset;
     uint8_t* img[2];
     const unsigned char* blob;
-    const float* tangent;              // [np][2]
     const float* start_yaw;            // [np]
-    unsigned long long* stats;         // [0] off-track events, [1] resets
+    const float* tangent_g;            // [np][2] global copy, used when the table does not fit in LDS (tan_in_lds == 0)
+    unsigned long long* stats;         // [0] off-track events, [1] resets, [2] layout-assumption failures
     int n_envs, env_id_base, envs_per_wg;
     int np, H, W, gpr, gpe;            // groups (4 px) per row / per env
     unsigned row_magic;                // q / gpr == umulhi(q, row_magic) for q < gpe (checked on the host)
     int map_w, map_h, map_words, map_pitch_b;   // map_pitch_b: bytes per map row in the LDS image (odd number of words)
-    int off_py, off_pz, off_map, off_rowtab, off_pal, blob_bytes, off_scratch;
+    int off_map, off_px, off_py, off_pz, off_tan, off_rowtab, off_pal, blob_bytes, off_scratch;   // LDS image: map at 0
     float map_x0f, map_z0f, inv_cellf;
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
     float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
-    int auto_reset, render, synth, n_steps, img_parity, stage_bytes, rows_per_pass;
+    int auto_reset, render, synth, n_steps, img_parity, stage_bytes, rows_per_pass, tan_in_lds;
     uint32_t step0;
     unsigned long long seed;
 };
@@ -141,31 +145,66 @@ __device__ __forceinline__ void synth_controls(unsigned long long seed, uint32_t
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));   // 16-B register tuple (HIP's uint4 struct defeats SROA here)
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
+
+constexpr int kStagers = kBlock - 64;  // waves 1..14 stage tables while wave 0 integrates
+constexpr int kHotRegs = 7;            // 7 x 896 x 16 B = 100 KB >= points + tangents + camera tables
+constexpr int kMapRegs = 7;            // >= TRS_MAP_LDS_BUDGET (96 KB) of packed map
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-
-    // ---- stage the read-only tables into LDS: one linear copy, 16 B per lane ----
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.blob);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        const int n16 = p.stage_bytes >> 4;     // physics-only launches stage just the track points
-        for (int i = tid; i < n16; i += kBlock) dst[i] = src[i];
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;        // LDS byte address of the dynamic segment
+    if (lds0 + (unsigned)p.off_map != 0u) {                 // the rasteriser's map addressing assumes LDS offset 0
+        if (tid == 0 && blockIdx.x == 0) atomicAdd(&p.stats[2], 1ull);
+        return;
     }
-    const double* lpx = reinterpret_cast<const double*>(smem);
+
+    const double* lpx = reinterpret_cast<const double*>(smem + p.off_px);
     const double* lpy = reinterpret_cast<const double*>(smem + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(smem + p.off_pz);
-    const float2* lrow = reinterpret_cast<const float2*>(smem + p.off_rowtab);
-    const uint32_t* lpal = reinterpret_cast<const uint32_t*>(smem + p.off_pal);
+    const float2* ltan = reinterpret_cast<const float2*>(smem + p.off_tan);
+    const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
     // scratch (16-B aligned base): camera params first (float4), then binary64 arrays, then ints
     float4* scam = reinterpret_cast<float4*>(smem + p.off_scratch);               // [kEMax] camx, camz, s, c
     double* sq = reinterpret_cast<double*>(scam + kEMax);                         // [3][kEMax] query points
     double* spd = sq + 3 * kEMax;                                                 // [kEMax][kWaves] partial distance
     int* spi = reinterpret_cast<int*>(spd + kEMax * kWaves);                      // [kEMax][kWaves] partial index
-    __syncthreads();
+    const double* gpx = reinterpret_cast<const double*>(p.blob + p.off_px);       // global copies (reset path only)
+    const double* gpy = reinterpret_cast<const double*>(p.blob + p.off_py);
+    const double* gpz = reinterpret_cast<const double*>(p.blob + p.off_pz);
+
+    // ---- prologue: waves 1..14 stage the read-only tables (register-staged, asynchronous) ----
+    //   hot region  [off_px, off_scratch): points, tangents, camera rows, palette -> written to LDS right away
+    //   map region  [0, off_px): held in registers and written to LDS just before the first raster phase, so the
+    //   88 KB of L2->LDS traffic overlaps phase 0 / A / A2 of the first step (plain loads survive s_barrier)
+    u4v mreg[kMapRegs];
+#pragma unroll
+    for (int r = 0; r < kMapRegs; ++r) mreg[r] = (u4v)(0u);
+    bool map_pending = false;
+    if (wave != 0) {
+        const int st = tid - 64;
+        const u4v* hsrc = reinterpret_cast<const u4v*>(p.blob + p.off_px);
+        u4v* hdst = reinterpret_cast<u4v*>(smem + p.off_px);
+        const int hot16 = (p.off_scratch - p.off_px) >> 4;
+        u4v hreg[kHotRegs];
+#pragma unroll
+        for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; hreg[r] = (i < hot16) ? hsrc[i] : (u4v)(0u); }
+        if (p.render) {
+            const u4v* msrc = reinterpret_cast<const u4v*>(p.blob);
+            const int map16 = p.off_px >> 4;
+#pragma unroll
+            for (int r = 0; r < kMapRegs; ++r) { const int i = st + r * kStagers; if (i < map16) mreg[r] = msrc[i]; }
+            map_pending = true;
+        }
+#pragma unroll
+        for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; if (i < hot16) hdst[i] = hreg[r]; }
+    }
 
     const int e_begin = blockIdx.x * p.envs_per_wg;
     const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
@@ -178,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
             const int nE = min(kEMax, e_end - c0);
             const int e = c0 + tid;          // env of this lane in phases 0 / A2 (tid < nE)
 
-            // ---- phase 0: integrate ----
+            // ---- phase 0: integrate (lane j of wave 0 <-> env j of the chunk: coalesced SoA accesses) ----
             float x1 = 0.f, y0 = 0.f, z1 = 0.f, yaw1 = 0.f, v2 = 0.f, hs = 0.f, hc = 1.f, sf = 0.f;
             int do_reset = 0, prev_idx = 0;
             if (tid < nE) {
@@ -191,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                 prev_idx = p.seg_idx[e];
                 if (do_reset) {
                     const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
-                    x1 = (float)lpx[si]; y0 = (float)lpy[si]; z1 = (float)lpz[si];
+                    x1 = (float)gpx[si]; y0 = (float)gpy[si]; z1 = (float)gpz[si];
                     yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
                     spec_sincos(yaw1, hs, hc);
                 } else {
@@ -257,8 +296,8 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                     idx = take ? oi : idx;
                 }
                 const float y1 = (float)lpy[idx];
-                const float tx = p.tangent[2 * idx], tz = p.tangent[2 * idx + 1];
-                const float cte = (x1 - (float)lpx[idx]) * tz - (z1 - (float)lpz[idx]) * tx;
+                const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
+                const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
                 const bool lost = best >= TRS_LOST_L1;
                 is_done = (fabsf(cte) > p.offtrack_cte) || lost;
                 float epr = p.ep_return[e];
@@ -291,42 +330,69 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                     if (mreset) atomicAdd(&p.stats[1], (unsigned long long)__popcll(mreset));
                 }
             }
+            if (map_pending) {   // first raster of this launch: land the map slice held in registers
+                u4v* mdst = reinterpret_cast<u4v*>(smem);
+                const int map16 = p.off_px >> 4;
+                const int st = tid - 64;
+#pragma unroll
+                for (int r = 0; r < kMapRegs; ++r) { const int i = st + r * kStagers; if (i < map16) mdst[i] = mreg[r]; }
+                map_pending = false;
+            }
             __syncthreads();
 
             // ---- phase B: rasterise the chunk ----
-            // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre
-            // offsets uf are loop constants; per pixel: 2 fma, 2 saturating converts + 2 min (floor + clamp),
-            // 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette address, 1 LDS palette read.
+            // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre offsets
+            // uf are loop constants.  Per pixel: 1 packed fma (gx,gz), 2 saturating converts + 2 min (= floor + clamp),
+            // 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette address op, 1 LDS palette read.
             if (p.render) {
                 const float half_w = (float)(p.W / 2);
                 const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
-                const int cg = tid % p.gpr, r0 = tid / p.gpr;       // rows_per_pass * gpr == kBlock (host-checked)
+                const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (none at W = 160)
                 const float uf0 = (float)(cg << 2) + 0.5f - half_w;
-                const float uf1 = uf0 + 1.0f, uf2 = uf0 + 2.0f, uf3 = uf0 + 3.0f;
-                const unsigned char* const mapb = smem + p.off_map;
+                const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
+                const unsigned pitch = (unsigned)p.map_pitch_b;
+                const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
+                const size_t row_bytes = (size_t)p.gpr * 12;
                 for (int j = 0; j < nE; ++j) {
                     const float4 cam = scam[j];
+                    const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
                     unsigned char* const out = img + (size_t)(c0 + j) * ((size_t)p.gpe * 12) + (size_t)cg * 12;
-                    for (int v = (r0 < p.rows_per_pass ? r0 : p.H); v < p.H; v += p.rows_per_pass) {
-                        const float2 rt = lrow[v];
-                        const unsigned char* const palb = reinterpret_cast<const unsigned char*>(lpal + 4 * v);
-                        const float ax = fmaf(rt.x, cam.z, cam.x), az = fmaf(rt.x, cam.w, cam.y);
-                        const float dx = rt.y * cam.w, dz = -(rt.y * cam.z);
-                        auto shade = [&](float uf) -> uint32_t {
-                            const unsigned ix = min(cvt_u32_sat(fmaf(uf, dx, ax)), gwm1);
-                            const unsigned iz = min(cvt_u32_sat(fmaf(uf, dz, az)), ghm1);
-                            const unsigned waddr = __umul24(iz, (unsigned)p.map_pitch_b) + ((ix >> 4) << 2);
-                            const uint32_t w = *reinterpret_cast<const uint32_t*>(mapb + waddr);
-                            const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);   // offset uses bits [4:0] = 2*(ix&15)
-                            return *reinterpret_cast<const uint32_t*>(palb + (cls << 2));
+                    f2v rt = lrow[vstart < p.H ? vstart : 0];
+                    for (int v = vstart; v < p.H; v += p.rows_per_pass) {
+                        const int vn = v + p.rows_per_pass;
+                        const f2v rtn = lrow[vn < p.H ? vn : v];                            // prefetch the next row's table entry
+                        const unsigned pal_a = lds0 + (unsigned)p.off_pal + ((unsigned)v << 4);
+                        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+                        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
+                        const f2v d = kk2 * cns;                                           // (dx, dz) = (k*c, -(k*s))
+                        auto shade = [&](f2v uf) -> uint32_t {
+                            const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
+                            const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
+                            const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
+                            const unsigned xoff = (ix >> 2) & ~3u;                          // byte offset of the map word in its row
+                            unsigned waddr, paddr;
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(pitch), "v"(xoff));
+                            const uint32_t w = *(lds_u32p)(uintptr_t)waddr;                 // map lives at LDS offset 0 (checked above)
+                            const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);      // offset uses bits [4:0] = 2*(ix&15)
+                            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(paddr) : "v"(cls), "v"(pal_a));
+                            return *(lds_u32p)(uintptr_t)paddr;
                         };
-                        const uint32_t c0p = shade(uf0), c1p = shade(uf1), c2p = shade(uf2), c3p = shade(uf3);
+#if TRS_ABLATE == 2   /* diagnostic build: stores only */
+                        const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
+#else
+                        const uint32_t c0p = shade(ufa), c1p = shade(ufb), c2p = shade(ufc), c3p = shade(ufd);
+#endif
                         // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
                         const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
                         const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
                         const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
-                        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * ((size_t)p.gpr * 12));
+                        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * row_bytes);
+#if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
+                        asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)o;
+#else
                         o[0] = w0; o[1] = w1; o[2] = w2;
+#endif
+                        rt = rtn;
                     }
                 }
             }
@@ -480,8 +546,8 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     k.ep_len = reinterpret_cast<int32_t*>(c); c += fa;
     takef(e->ctl_steer); takef(e->ctl_thr); takef(e->ctl_brk);
     k.done = c; c += ba; k.pending = c; c += ba; e->ctl_reset = c; c += ba;
-    HIPCHK(hipMalloc((void**)&e->stats, 2 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(e->stats, 0, 2 * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipMalloc((void**)&e->stats, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(e->stats, 0, 4 * sizeof(unsigned long long), e->stream));
     k.stats = e->stats;
     if (cfg->render) {
         e->img_bytes = n * (size_t)e->H * e->W * 3;
@@ -528,29 +594,42 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     if (rc) return fail(rc, err);
     const trsim::TrackTables& T = e->tab;
     KParams& k = e->kp;
-    // LDS image layout
+    // LDS image layout: [map (pitched rows) @0][px][py][pz][tangent][rowtab][palette] + scratch
     const size_t pts = align_up((size_t)n_points * 8, 16);
     const int pitch_words = T.info.map_words | 1;          // odd pitch: rows of the map start on different LDS banks
     k.map_pitch_b = pitch_words * 4;
+    if (k.map_pitch_b >= (1 << 24) || T.info.map_h >= (1 << 24)) return fail(TRS_ERR_LIMIT, "map exceeds the 24-bit multiply of the rasteriser");
     const size_t map_bytes = (size_t)k.map_pitch_b * T.info.map_h;
     size_t off = 0;
-    k.off_py = (int)(off += pts); k.off_pz = (int)(off += pts); off += pts;
-    e->pts_bytes = (int)off;
-    k.off_map = (int)off; off += align_up(map_bytes, 16);
+    k.off_map = 0; off += align_up(map_bytes, 16);
+    k.off_px = (int)off; off += pts;
+    k.off_py = (int)off; off += pts;
+    k.off_pz = (int)off; off += pts;
+    e->pts_bytes = (int)(3 * pts);
+    k.off_tan = (int)off;
+    {   // tangents ride in LDS when everything still fits in the CU's 160 KiB (generated track: yes; mountain track: no)
+        const size_t scratch_est = (size_t)kEMax * 16 + 3 * kEMax * 8 + (size_t)kEMax * kWaves * 12 + 64;
+        const size_t with_tan = off + align_up((size_t)n_points * 8, 16) + align_up((size_t)e->H * 8, 16) + (size_t)e->H * 16 + scratch_est;
+        k.tan_in_lds = with_tan <= 160 * 1024 ? 1 : 0;
+        if (k.tan_in_lds) off += align_up((size_t)n_points * 8, 16);
+    }
     k.off_rowtab = (int)off; off += align_up((size_t)e->H * 8, 16);
     k.off_pal = (int)off; off += (size_t)e->H * 16;
     k.blob_bytes = (int)off;
     k.off_scratch = (int)off;
-    k.stage_bytes = e->cfg.render ? k.blob_bytes : e->pts_bytes;
+    k.stage_bytes = k.blob_bytes;
+    if ((size_t)(k.off_scratch - k.off_px) > (size_t)kHotRegs * kStagers * 16 || (size_t)k.off_px > (size_t)kMapRegs * kStagers * 16)
+        return fail(TRS_ERR_LIMIT, "tables exceed the register-staging capacity of the step kernel");
     const size_t scratch = (size_t)kEMax * 16 + 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4;
     e->lds_bytes = (int)align_up(off + scratch, 16);
     if (e->lds_bytes > 160 * 1024) return fail(TRS_ERR_LIMIT, "tables exceed the 160 KiB LDS of a CU");
     std::vector<unsigned char> h(off, 0);
-    std::memcpy(h.data(), T.px.data(), (size_t)n_points * 8);
+    for (int r = 0; r < T.info.map_h; ++r)
+        std::memcpy(h.data() + (size_t)r * k.map_pitch_b, T.map.data() + (size_t)r * T.info.map_words, (size_t)T.info.map_words * 4);
+    std::memcpy(h.data() + k.off_px, T.px.data(), (size_t)n_points * 8);
     std::memcpy(h.data() + k.off_py, T.py.data(), (size_t)n_points * 8);
     std::memcpy(h.data() + k.off_pz, T.pz.data(), (size_t)n_points * 8);
-    for (int r = 0; r < T.info.map_h; ++r)
-        std::memcpy(h.data() + k.off_map + (size_t)r * k.map_pitch_b, T.map.data() + (size_t)r * T.info.map_words, (size_t)T.info.map_words * 4);
+    if (k.tan_in_lds) std::memcpy(h.data() + k.off_tan, T.tangent.data(), (size_t)n_points * 8);
     std::memcpy(h.data() + k.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
     std::memcpy(h.data() + k.off_pal, T.palette.data(), (size_t)e->H * 16);
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -562,7 +641,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemcpy(e->blob, h.data(), off, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->tangent, T.tangent.data(), (size_t)n_points * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->start_yaw, T.start_yaw.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
-    k.blob = e->blob; k.tangent = e->tangent; k.start_yaw = e->start_yaw;
+    k.blob = e->blob; k.start_yaw = e->start_yaw; k.tangent_g = e->tangent;
     k.np = n_points; k.map_w = T.info.map_w; k.map_h = T.info.map_h; k.map_words = T.info.map_words;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
@@ -585,7 +664,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(k.ep_len, 0, n * 4));
     HIPCHK(hipMemset(k.done, 0, n));
     HIPCHK(hipMemset(k.pending, 1, n));
-    HIPCHK(hipMemset(e->stats, 0, 16));
+    HIPCHK(hipMemset(e->stats, 0, 32));
     e->step_count = 0;
     e->track_loaded = true;
     return TRS_OK;
@@ -724,7 +803,7 @@ TRS_EXPORT int trs_locate(trs_env* e, const double* h_xyz, int nq, int32_t* h_id
     int grid = (nq + kW - 1) / kW;
     grid = std::min(grid, e->cu_count * 2);
     hipLaunchKernelGGL(trs_locate_kernel, dim3(grid), dim3(kLocBlock), e->pts_bytes, e->stream,
-                       (const unsigned char*)e->blob, e->pts_bytes, e->kp.off_py, e->kp.off_pz, e->kp.np,
+                       (const unsigned char*)e->blob + e->kp.off_px, e->pts_bytes, e->kp.off_py - e->kp.off_px, e->kp.off_pz - e->kp.off_px, e->kp.np,
                        (const double*)e->loc_q, nq, e->loc_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_idx, e->loc_out, (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
