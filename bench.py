@@ -176,9 +176,12 @@ def main():
         total_env_steps = n * world * args.steps
         value = total_env_steps / wall
         B = algorithmic_bytes(args.img_h, args.img_w, render)
-        launches = (args.steps + spl - 1) // spl
+        # camera on: the library pipelines a call over steps+1 launches of trs_step_kernel (physics of step i beside
+        # the raster of step i-1); physics only: steps/spl launches of trs_physics_kernel
+        launches = (args.steps + 1) if render else (args.steps + spl - 1) // spl
         avg_launch_s = kernel_ms * 1e-3 / launches
-        achieved = B * n * spl / avg_launch_s / 1e9                   # GB/s of algorithmic bytes, dominant (only) kernel
+        per_launch = n * args.steps / launches                         # env-steps one launch completes
+        achieved = B * per_launch / avg_launch_s / 1e9                 # GB/s of algorithmic bytes, dominant (only) kernel
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -201,8 +204,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "trs_step_kernel", "avg_launch_us": round(avg_launch_s * 1e6, 3), "bytes_per_env_step": B,
-                "env_steps_per_launch": n * spl,
+                "kernel": "trs_step_kernel" if render else "trs_physics_kernel", "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },
         }
         if gathered is not None:

@@ -86,7 +86,8 @@ enum {
     TRS_F_ROWTAB,    /* float[img_h][2]  (row_lz, row_k)  */
     TRS_F_PALETTE,   /* uint32[img_h][4] 0x00BBGGRR       */
     TRS_F_TANGENT,   /* float[n_points][2] (tx, tz)       */
-    TRS_F_STEER_FILT /* float[n_envs] synthetic low-pass state */
+    TRS_F_STEER_FILT,/* float[n_envs] synthetic low-pass state */
+    TRS_F_STATS      /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [8..] diagnostics */
 };
 
 typedef struct trs_map_info {

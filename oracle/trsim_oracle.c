@@ -53,9 +53,10 @@ struct trs_env {
     /* state */
     float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
     int32_t *seg_idx, *ep_len;
-    uint8_t *done, *pending;
+    uint8_t *done, *pending, *was_reset;
     uint8_t* img;
     uint64_t step_count;
+    uint64_t stats[64];        /* [0] off-track events, [1] resets */
 };
 
 /* ------------------------------------------------------------------ spec pieces */
@@ -122,10 +123,12 @@ static void step_env(struct trs_env* e, int i, float steer, float thr, float brk
         e->ep_len[i] = 0;
         e->steer_filt[i] = 0.0f;
         e->pending[i] = 0;
+        e->was_reset[i] = 1;
         x1 = (float)e->px[si]; e->y[i] = (float)e->py[si]; z1 = (float)e->pz[si];
         yaw1 = e->start_yaw[si]; v2 = 0.0f;
         spec_sincos(yaw1, &s, &c);
     } else {
+        e->was_reset[i] = 0;
         steer = clampf(steer, -1.0f, 1.0f);
         thr = clampf(thr, -1.0f, 1.0f);
         brk = clampf(brk, 0.0f, 1.0f);
@@ -367,7 +370,7 @@ EXPORT int trso_create(const trs_config* cfg, int device, trs_env** out)
 #define A(p, T) p = calloc((size_t)n, sizeof(T))
     A(e->x, float); A(e->y, float); A(e->z, float); A(e->yaw, float); A(e->v, float); A(e->speed, float); A(e->cte, float);
     A(e->ep_return, float); A(e->last_return, float); A(e->steer_filt, float); A(e->seg_idx, int32_t); A(e->ep_len, int32_t);
-    A(e->done, uint8_t); A(e->pending, uint8_t);
+    A(e->done, uint8_t); A(e->pending, uint8_t); A(e->was_reset, uint8_t);
 #undef A
     if (cfg->render) e->img = calloc((size_t)n * e->H * e->W * 3, 1);
     e->rowtab = calloc((size_t)e->H * 2, sizeof(float));
@@ -381,7 +384,7 @@ EXPORT int trso_destroy(trs_env* e)
     if (!e) return TRS_OK;
     free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
-    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->img);
+    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img);
     free(e);
     return TRS_OK;
 }
@@ -405,6 +408,7 @@ EXPORT int trso_load_track(trs_env* e, const double* xyz, int np)
         e->steer_filt[i] = 0.0f; e->done[i] = 0; e->pending[i] = 1;
     }
     e->step_count = 0;
+    memset(e->stats, 0, sizeof e->stats);
     return TRS_OK;
 }
 
@@ -437,6 +441,7 @@ static int do_steps(struct trs_env* e, const float* st, const float* th, const f
             step_env(e, i, steer, thr, brk, reset_in, &s, &c);
             if (e->img) render_env(e, i, s, c);
         }
+        for (int i = 0; i < e->n; ++i) { e->stats[0] += e->done[i]; e->stats[1] += e->was_reset[i]; }
         e->step_count++;
     }
     return TRS_OK;
@@ -482,6 +487,7 @@ EXPORT int trso_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_PALETTE: src = e->pal; need = (size_t)e->H * 16; break;
     case TRS_F_TANGENT: src = e->tang; need = (size_t)e->np * 8; break;
     case TRS_F_STEER_FILT: src = e->steer_filt; need = n * 4; break;
+    case TRS_F_STATS: src = e->stats; need = sizeof e->stats; break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
     if (!src) return fail(TRS_ERR_STATE, "field not available");

@@ -52,7 +52,7 @@ class TrsMapInfo(C.Structure):
 FIELDS = {
     "img": 0, "pos_x": 1, "pos_y": 2, "pos_z": 3, "speed": 4, "cte": 5, "yaw": 6, "vel": 7,
     "seg_idx": 8, "ep_return": 9, "last_return": 10, "ep_len": 11, "done": 12,
-    "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17,
+    "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17, "stats": 18,
 }
 
 # every symbol include/trsim.h declares (suffix after the prefix)

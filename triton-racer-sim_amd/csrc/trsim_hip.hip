@@ -1,29 +1,33 @@
 // trsim_hip.hip — libtrsim.so: the gfx950 (MI355X, CDNA4) kernels and the C ABI of include/trsim.h.
 //
-// One fused kernel per env step (trs_step_kernel).  A workgroup (960 threads = 15 wave64) owns a
-// contiguous range of envs and keeps every read-only table in LDS for the whole launch:
+// One env step = two kernels on separate HIP streams (no tracing compiler, explicit streams + hipGraph):
 //
-//   LDS image (copied once per launch from one contiguous device blob, 16 B per lane):
-//     px[np] py[np] pz[np]  binary64 raw track points (SoA)      — nearest-point search operands
-//     map[map_h][map_words] packed 2-bit surface classes          — rasteriser lookup
-//     rowtab[H] (row_lz,row_k) float2, palette[H][4] 0x00BBGGRR  — camera rows
-//     + a small scratch area (query points, per-wave argmin partials, camera params)
+//   trs_physics_kernel  (stream P)    state SoA -> new state + one float4 of camera parameters per env
+//     A workgroup (960 threads = 15 wave64) owns a contiguous range of envs; its LDS holds the raw track
+//     points (binary64 SoA) and tangents for the whole launch.
+//       phase 0  lane j of wave 0 integrates env j (bicycle model, include/trsim_spec.h), coalesced SoA loads
+//       phase A  the 15 waves are dealt to the chunk's envs; each scans an interleaved slice of the LDS track:
+//                binary64 L1 distance, per-lane strict '<', wave64 DPP argmin (lowest index wins ties)
+//                (= reference LocationTracker.__find_closest, components/track_data_process.py:89-101)
+//       phase A2 lane j of wave 0 folds env j's partials, computes y, cte, done, reward, stores the SoA state
+//                (coalesced) and the env's camera parameters; off-track envs are counted by wave ballot
 //
-//   per step, per chunk of <=16 envs of the workgroup:
-//     phase 0  lane j of wave 0 integrates env j (bicycle model, include/trsim_spec.h) — coalesced SoA loads
-//     phase A  all 15 waves scan the LDS track for each env: binary64 L1 distance, per-lane strict '<',
-//              wave64 butterfly argmin (lowest index wins ties) -> one partial per wave
-//              (= reference LocationTracker.__find_closest, components/track_data_process.py:89-101)
-//     phase A2 lane j of wave 0 folds env j's 15 partials, computes y, cte, done, reward, stores the SoA
-//              state (coalesced) and the env's camera parameters; off-track envs are counted with a
-//              wave ballot + one atomic
-//     phase B  all threads rasterise the chunk: a lane produces 4 consecutive pixels (12 B) of the
-//              flattened HxWx3 stream, so one wave-instruction stores 768 contiguous bytes (6 full 128-B lines)
+//   (header text below describes the two halves of the fused kernel)
+//     LDS holds the packed 2-bit surface-class map (at LDS offset 0, odd row pitch), the per-row camera
+//     table and the per-row fogged palette.  A thread owns one 4-pixel column group and walks image rows:
+//     1 packed-fp32 fma per pixel for the ground point, saturating convert + min (= floor + clamp),
+//     mad_u24 addressing, one LDS map read, bit-field extract, one LDS palette read; 4 pixels -> 12 bytes
+//     via v_perm, so one wave-instruction stores 768 contiguous bytes (6 full 128-B lines).
+//     Bound: HBM writes of the image (57,600 B per env-step at 120x160) — see DESIGN.md.
 //
-// Bound: HBM writes of the image (57,600 B per env-step at 120x160) — see DESIGN.md.
+//   The physics chain of step t+1 and the start of raster t+1 overlap the store drain of raster t
+//   (rasters alternate between two streams and two image buffers; a 4-deep ring of camera parameters
+//   decouples the two kernels).  Bulk synthetic stepping replays a captured hipGraph of 16 steps.
+//
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (spec rule R1: no implicit FMA contraction).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -47,30 +51,42 @@ constexpr int kBlock = 960;            // 15 waves: 4800 four-pixel groups of a 
 constexpr int kWaves = kBlock / 64;
 constexpr int kEMax = 15;              // envs of one workgroup processed per chunk (<= one wave each in the search)
 constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
+constexpr int kRing = 4;               // camera-parameter ring between the physics and the raster side (2 would do)
+constexpr int kStagers = kBlock - 64;  // physics: waves 1..14 stage tables while wave 0 integrates
+constexpr int kHotRegs = 7;            // 7 x 896 x 16 B = 100 KB >= points + tangents
+[[maybe_unused]] constexpr int kRasterStampThread = 640;  // diagnostic stamps: wave 0 and the first physics wave
 
-struct KParams {
-    // per-env state, SoA
+struct PParams {                        // physics kernel
     float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
     int32_t *seg_idx, *ep_len;
     uint8_t *done, *pending;
     const float *ctl_steer, *ctl_thr, *ctl_brk;
     const uint8_t* ctl_reset;
-    uint8_t* img[2];
-    const unsigned char* blob;
-    const float* start_yaw;            // [np]
-    const float* tangent_g;            // [np][2] global copy, used when the table does not fit in LDS (tan_in_lds == 0)
-    unsigned long long* stats;         // [0] off-track events, [1] resets, [2] layout-assumption failures
-    int n_envs, env_id_base, envs_per_wg;
-    int np, H, W, gpr, gpe;            // groups (4 px) per row / per env
-    unsigned row_magic;                // q / gpr == umulhi(q, row_magic) for q < gpe (checked on the host)
-    int map_w, map_h, map_words, map_pitch_b;   // map_pitch_b: bytes per map row in the LDS image (odd number of words)
-    int off_map, off_px, off_py, off_pz, off_tan, off_rowtab, off_pal, blob_bytes, off_scratch;   // LDS image: map at 0
+    float4* cam;                        // [kRing][n_envs] camx, camz, sin, cos (cell units) for the raster kernel
+    const unsigned char* blob;          // physics LDS image: px | py | pz | tangent
+    const float* start_yaw;             // [np]
+    const float* tangent_g;             // [np][2] global copy, used when the table does not fit in LDS
+    const uint32_t* dev_step;           // device-resident step counter base (graph replays) or nullptr
+    unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
+    int n_envs, env_id_base, envs_per_wg, np;
+    int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
     float map_x0f, map_z0f, inv_cellf;
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
     float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
-    int auto_reset, render, synth, n_steps, img_parity, stage_bytes, rows_per_pass, tan_in_lds;
-    uint32_t step0;
+    int auto_reset, synth, n_steps, cam_slot, write_cam;
+    uint32_t step_off;
     unsigned long long seed;
+};
+
+struct RParams {                        // raster kernel
+    const float4* cam;                  // this step's slot of the ring: [n_envs]
+    uint8_t* img;                       // this step's image buffer
+    const unsigned char* blob;          // raster LDS image: map (pitched rows) @0 | rowtab | palette
+    unsigned long long* stats;
+    int n_envs, envs_per_wg;
+    int H, W, gpr, gpe, rows_per_pass;  // gpr/gpe: 4-pixel groups per row / per env
+    int map_w, map_h, map_pitch_b;
+    int off_rowtab, off_pal, blob_bytes;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -145,73 +161,68 @@ __device__ __forceinline__ void synth_controls(unsigned long long seed, uint32_t
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+#ifndef TRS_STAMPS
+#define TRS_STAMPS 0   /* 1 = diagnostic build: s_memtime stamps per phase into stats[8..] (scripts/stamps.sh), never shipped */
+#endif
+#if TRS_STAMPS
+#define STAMP(slot)                                                                                         \
+    do {                                                                                                    \
+        if (blockIdx.x == 7 && (threadIdx.x == 0 || threadIdx.x == kRasterStampThread)) {                                                   \
+            unsigned long long _t;                                                                          \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                      \
+            STAMP_STATS[8 + (threadIdx.x ? 24 : 0) + (slot)] = _t;                                                      \
+        }                                                                                                   \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));   // 16-B register tuple (HIP's uint4 struct defeats SROA here)
 typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
 
-constexpr int kStagers = kBlock - 64;  // waves 1..14 stage tables while wave 0 integrates
-constexpr int kHotRegs = 7;            // 7 x 896 x 16 B = 100 KB >= points + tangents + camera tables
-constexpr int kMapRegs = 7;            // >= TRS_MAP_LDS_BUDGET (96 KB) of packed map
-
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
+__global__ __launch_bounds__(kBlock) void trs_physics_kernel(const PParams p)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const unsigned lds0 = (unsigned)(uintptr_t)smem;        // LDS byte address of the dynamic segment
-    if (lds0 + (unsigned)p.off_map != 0u) {                 // the rasteriser's map addressing assumes LDS offset 0
-        if (tid == 0 && blockIdx.x == 0) atomicAdd(&p.stats[2], 1ull);
-        return;
-    }
+#define STAMP_STATS p.stats
+    STAMP(0);
 
-    const double* lpx = reinterpret_cast<const double*>(smem + p.off_px);
+    const double* lpx = reinterpret_cast<const double*>(smem);
     const double* lpy = reinterpret_cast<const double*>(smem + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(smem + p.off_pz);
     const float2* ltan = reinterpret_cast<const float2*>(smem + p.off_tan);
-    const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
-    // scratch (16-B aligned base): camera params first (float4), then binary64 arrays, then ints
-    float4* scam = reinterpret_cast<float4*>(smem + p.off_scratch);               // [kEMax] camx, camz, s, c
-    double* sq = reinterpret_cast<double*>(scam + kEMax);                         // [3][kEMax] query points
+    // scratch (16-B aligned base): binary64 arrays first, then ints
+    double* sq = reinterpret_cast<double*>(smem + p.off_scratch);                 // [3][kEMax] query points
     double* spd = sq + 3 * kEMax;                                                 // [kEMax][kWaves] partial distance
     int* spi = reinterpret_cast<int*>(spd + kEMax * kWaves);                      // [kEMax][kWaves] partial index
-    const double* gpx = reinterpret_cast<const double*>(p.blob + p.off_px);       // global copies (reset path only)
+    const double* gpx = reinterpret_cast<const double*>(p.blob);                  // global copies (reset path only)
     const double* gpy = reinterpret_cast<const double*>(p.blob + p.off_py);
     const double* gpz = reinterpret_cast<const double*>(p.blob + p.off_pz);
 
-    // ---- prologue: waves 1..14 stage the read-only tables (register-staged, asynchronous) ----
-    //   hot region  [off_px, off_scratch): points, tangents, camera rows, palette -> written to LDS right away
-    //   map region  [0, off_px): held in registers and written to LDS just before the first raster phase, so the
-    //   88 KB of L2->LDS traffic overlaps phase 0 / A / A2 of the first step (plain loads survive s_barrier)
-    u4v mreg[kMapRegs];
-#pragma unroll
-    for (int r = 0; r < kMapRegs; ++r) mreg[r] = (u4v)(0u);
-    bool map_pending = false;
+    // ---- prologue: waves 1..14 stage the track tables (register-staged) while wave 0 starts phase 0 ----
     if (wave != 0) {
         const int st = tid - 64;
-        const u4v* hsrc = reinterpret_cast<const u4v*>(p.blob + p.off_px);
-        u4v* hdst = reinterpret_cast<u4v*>(smem + p.off_px);
-        const int hot16 = (p.off_scratch - p.off_px) >> 4;
+        const u4v* hsrc = reinterpret_cast<const u4v*>(p.blob);
+        u4v* hdst = reinterpret_cast<u4v*>(smem);
+        const int hot16 = p.blob_bytes >> 4;
         u4v hreg[kHotRegs];
 #pragma unroll
         for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; hreg[r] = (i < hot16) ? hsrc[i] : (u4v)(0u); }
-        if (p.render) {
-            const u4v* msrc = reinterpret_cast<const u4v*>(p.blob);
-            const int map16 = p.off_px >> 4;
-#pragma unroll
-            for (int r = 0; r < kMapRegs; ++r) { const int i = st + r * kStagers; if (i < map16) mreg[r] = msrc[i]; }
-            map_pending = true;
-        }
 #pragma unroll
         for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; if (i < hot16) hdst[i] = hreg[r]; }
     }
 
     const int e_begin = blockIdx.x * p.envs_per_wg;
     const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
+    const uint32_t t0 = (p.dev_step ? *p.dev_step : 0u) + p.step_off;
+    STAMP(1);
 
     for (int k = 0; k < p.n_steps; ++k) {
-        const uint32_t t = p.step0 + (uint32_t)k;
-        uint8_t* const img = p.img[(p.img_parity + k) & 1];
+        const uint32_t t = t0 + (uint32_t)k;
+        float4* const cam_out = p.cam + (size_t)((p.cam_slot + k) & (kRing - 1)) * p.n_envs;
 
         for (int c0 = e_begin; c0 < e_end; c0 += kEMax) {
             const int nE = min(kEMax, e_end - c0);
@@ -221,51 +232,54 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
             float x1 = 0.f, y0 = 0.f, z1 = 0.f, yaw1 = 0.f, v2 = 0.f, hs = 0.f, hc = 1.f, sf = 0.f;
             int do_reset = 0, prev_idx = 0;
             if (tid < nE) {
+                // every load of the env's state is issued up front: one memory round trip, not one per branch
                 const int gid = p.env_id_base + e;
-                const bool pend = p.pending[e] != 0;
-                const bool was_done = p.done[e] != 0;
-                const bool reset_in = (!p.synth && p.ctl_reset && k == 0) ? (p.ctl_reset[e] != 0) : false;
-                do_reset = pend || reset_in || (p.auto_reset && was_done);
-                sf = p.steer_filt[e];
+                const uint8_t pend = p.pending[e], was_done = p.done[e];
+                const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
+                const float sf_in = p.steer_filt[e];
+                const float vx = p.x[e], vy = p.y[e], vz = p.z[e], vyaw = p.yaw[e], vv = p.v[e];
+                float steer = 0.f, thr = 0.f, brk = 0.f;
+                if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
                 prev_idx = p.seg_idx[e];
+                do_reset = (pend != 0) || (rin != 0) || (p.auto_reset && was_done != 0);
+                sf = sf_in;
                 if (do_reset) {
                     const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
                     x1 = (float)gpx[si]; y0 = (float)gpy[si]; z1 = (float)gpz[si];
                     yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
                     spec_sincos(yaw1, hs, hc);
                 } else {
-                    float steer, thr, brk = 0.0f;
                     if (p.synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
-                    else { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
                     steer = clampf(steer, -1.0f, 1.0f);
                     thr = clampf(thr, -1.0f, 1.0f);
                     brk = clampf(brk, 0.0f, 1.0f);
                     float sd, cd;
                     spec_sincos(steer * p.max_steer, sd, cd);
                     const float tan_d = sd / cd;
-                    const float v = p.v[e];
-                    const float a = thr * p.accel_max - p.drag_lin * v;
-                    const float v1 = v + a * p.dt;
+                    const float a = thr * p.accel_max - p.drag_lin * vv;
+                    const float v1 = vv + a * p.dt;
                     const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
                     if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
                     else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
                     else v2 = 0.0f;
                     v2 = clampf(v2, -p.v_rev_max, p.v_max);
-                    yaw1 = p.yaw[e] + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
+                    yaw1 = vyaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
                     if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
                     if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
                     spec_sincos(yaw1, hs, hc);
-                    x1 = p.x[e] + (v2 * hs) * p.dt;
-                    z1 = p.z[e] + (v2 * hc) * p.dt;
-                    y0 = p.y[e];
+                    x1 = vx + (v2 * hs) * p.dt;
+                    z1 = vz + (v2 * hc) * p.dt;
+                    y0 = vy;
                 }
                 sq[tid] = (double)x1; sq[kEMax + tid] = (double)y0; sq[2 * kEMax + tid] = (double)z1;
             }
+            STAMP(2);
             __syncthreads();
+            STAMP(3);
 
             // ---- phase A: nearest raw track point, L1 in binary64 ----
-            // the 15 waves are dealt to the chunk's envs: env j is scanned by waves [j*wpe, (j+1)*wpe), each taking
-            // an interleaved slice of the points; one DPP argmin per wave, one partial per (env, slice)
+            // env j is scanned by waves [j*wpe, (j+1)*wpe), each taking an interleaved slice of the points (two points
+            // per trip so that the LDS reads of one overlap the arithmetic of the other); one DPP argmin per wave
             const int wpe = kWaves / nE;
             {
                 const int j = wave / wpe, slice = wave - j * wpe;
@@ -273,17 +287,30 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                     const double qx = sq[j], qy = sq[kEMax + j], qz = sq[2 * kEMax + j];
                     double best = TRS_LOST_L1;
                     int bi = 0;
-                    for (int i = slice * 64 + lane; i < p.np; i += wpe * 64) {
-                        const double d = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-                        if (d < best) { best = d; bi = i; }
+                    const int stride = wpe * 64;
+                    int i = slice * 64 + lane;
+                    for (; i + stride < p.np; i += 2 * stride) {
+                        const int i2 = i + stride;
+                        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
+                        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
+                        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
+                        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
+                        if (d1 < best) { best = d1; bi = i; }
+                        if (d2 < best) { best = d2; bi = i2; }
+                    }
+                    if (i < p.np) {
+                        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
+                        if (d1 < best) { best = d1; bi = i; }
                     }
                     wave_argmin(best, bi);
                     if (lane == 63) { spd[j * kWaves + slice] = best; spi[j * kWaves + slice] = bi; }
                 }
             }
+            STAMP(4);
             __syncthreads();
+            STAMP(5);
 
-            // ---- phase A2: fold partials, finish the env, store state ----
+            // ---- phase A2: fold partials, finish the env, store state + camera parameters ----
             int is_done = 0;
             if (tid < nE) {
                 double best = spd[tid * kWaves];
@@ -318,9 +345,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                 p.x[e] = x1; p.y[e] = y1; p.z[e] = z1; p.yaw[e] = yaw1; p.v[e] = v2;
                 p.speed[e] = fabsf(v2); p.cte[e] = cte; p.seg_idx[e] = idx; p.done[e] = (uint8_t)is_done;
                 p.ep_return[e] = epr; p.ep_len[e] = epl; p.steer_filt[e] = sf;
-                const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
-                const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
-                scam[tid] = make_float4(camx, camz, hs, hc);
+                if (p.write_cam) {
+                    const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
+                    const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
+                    cam_out[e] = make_float4(camx, camz, hs, hc);
+                }
             }
             if (wave == 0) {   // off-track / reset census: wave ballot, one atomic per workgroup-chunk
                 const unsigned long long mdone = __ballot(is_done != 0);
@@ -330,77 +359,253 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const KParams p)
                     if (mreset) atomicAdd(&p.stats[1], (unsigned long long)__popcll(mreset));
                 }
             }
-            if (map_pending) {   // first raster of this launch: land the map slice held in registers
-                u4v* mdst = reinterpret_cast<u4v*>(smem);
-                const int map16 = p.off_px >> 4;
-                const int st = tid - 64;
-#pragma unroll
-                for (int r = 0; r < kMapRegs; ++r) { const int i = st + r * kStagers; if (i < map16) mdst[i] = mreg[r]; }
-                map_pending = false;
-            }
-            __syncthreads();
-
-            // ---- phase B: rasterise the chunk ----
-            // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre offsets
-            // uf are loop constants.  Per pixel: 1 packed fma (gx,gz), 2 saturating converts + 2 min (= floor + clamp),
-            // 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette address op, 1 LDS palette read.
-            if (p.render) {
-                const float half_w = (float)(p.W / 2);
-                const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
-                const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (none at W = 160)
-                const float uf0 = (float)(cg << 2) + 0.5f - half_w;
-                const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
-                const unsigned pitch = (unsigned)p.map_pitch_b;
-                const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
-                const size_t row_bytes = (size_t)p.gpr * 12;
-                for (int j = 0; j < nE; ++j) {
-                    const float4 cam = scam[j];
-                    const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-                    unsigned char* const out = img + (size_t)(c0 + j) * ((size_t)p.gpe * 12) + (size_t)cg * 12;
-                    f2v rt = lrow[vstart < p.H ? vstart : 0];
-                    for (int v = vstart; v < p.H; v += p.rows_per_pass) {
-                        const int vn = v + p.rows_per_pass;
-                        const f2v rtn = lrow[vn < p.H ? vn : v];                            // prefetch the next row's table entry
-                        const unsigned pal_a = lds0 + (unsigned)p.off_pal + ((unsigned)v << 4);
-                        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
-                        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
-                        const f2v d = kk2 * cns;                                           // (dx, dz) = (k*c, -(k*s))
-                        auto shade = [&](f2v uf) -> uint32_t {
-                            const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
-                            const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
-                            const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
-                            const unsigned xoff = (ix >> 2) & ~3u;                          // byte offset of the map word in its row
-                            unsigned waddr, paddr;
-                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(pitch), "v"(xoff));
-                            const uint32_t w = *(lds_u32p)(uintptr_t)waddr;                 // map lives at LDS offset 0 (checked above)
-                            const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);      // offset uses bits [4:0] = 2*(ix&15)
-                            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(paddr) : "v"(cls), "v"(pal_a));
-                            return *(lds_u32p)(uintptr_t)paddr;
-                        };
-#if TRS_ABLATE == 2   /* diagnostic build: stores only */
-                        const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
-#else
-                        const uint32_t c0p = shade(ufa), c1p = shade(ufb), c2p = shade(ufc), c3p = shade(ufd);
-#endif
-                        // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
-                        const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
-                        const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
-                        const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
-                        uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * row_bytes);
-#if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
-                        asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)o;
-#else
-                        o[0] = w0; o[1] = w1; o[2] = w2;
-#endif
-                        rt = rtn;
-                    }
-                }
-            }
-            __syncthreads();
+            STAMP(6);
+            __syncthreads();     // scratch is reused by the next chunk / step
+            STAMP(7);
         }
     }
 }
 
+#undef STAMP_STATS
+#define STAMP_STATS sp.ra.stats
+// ---------------------------------------------------------------------------------------------
+// Fused, wave-specialised step kernel (camera on).  One launch per env step, one stream.
+//   raster team  = waves 0..9  (640 threads): rasterises the frame of camera-ring slot `r_slot`
+//   physics team = waves 10..14 (one wave per env, no workgroup barriers): advances the envs one step and
+//                  writes their camera parameters to ring slot `p_slot`
+//   seq = 1  (single-step call): raster waits for this launch's physics and renders the SAME step
+//   seq = 0  (inside a multi-step call): raster renders the PREVIOUS step while physics computes the next one;
+//            the host issues a physics-only first launch and a raster-only last launch, so the lag never
+//            leaves the call.
+constexpr int kRasterThreads = 640;
+constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;   // 5
+constexpr int kStageRegs = 10;                               // 10 x 640 x 16 B = 100 KB per pass of the raster team
+
+struct SParams {
+    PParams ph;                         // physics side (blob = px|py|pz|tan image; cam = ring base)
+    RParams ra;                         // raster side (cam/img filled per launch)
+    int do_phys, do_raster, seq, p_slot;
+    int lds_off_phys;                   // LDS byte offset of the physics image (raster image sits at 0)
+};
+
+// one wave advances one env (all lanes compute the same scalars; the track scan is lane-parallel)
+__device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigned char* lphys, int e, uint32_t t, int k,
+                                                 float4* cam_out, int lane)
+{
+    const double* lpx = reinterpret_cast<const double*>(lphys);
+    const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
+    const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
+    const float2* ltan = reinterpret_cast<const float2*>(lphys + p.off_tan);
+    const int gid = p.env_id_base + e;
+    const uint8_t pend = p.pending[e], was_done = p.done[e];
+    const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
+    float sf = p.steer_filt[e];
+    const float vx = p.x[e], vy = p.y[e], vz = p.z[e], vyaw = p.yaw[e], vv = p.v[e];
+    float steer = 0.f, thr = 0.f, brk = 0.f;
+    if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
+    const int prev_idx = p.seg_idx[e];
+    float epr = p.ep_return[e];
+    int epl = p.ep_len[e];
+    const int do_reset = (pend != 0) || (rin != 0) || (p.auto_reset && was_done != 0);
+    float x1, y0, z1, yaw1, v2, hs, hc;
+    if (do_reset) {
+        const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
+        x1 = (float)lpx[si]; y0 = (float)lpy[si]; z1 = (float)lpz[si];
+        yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
+        spec_sincos(yaw1, hs, hc);
+    } else {
+        if (p.synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
+        steer = clampf(steer, -1.0f, 1.0f);
+        thr = clampf(thr, -1.0f, 1.0f);
+        brk = clampf(brk, 0.0f, 1.0f);
+        float sd, cd;
+        spec_sincos(steer * p.max_steer, sd, cd);
+        const float tan_d = sd / cd;
+        const float a = thr * p.accel_max - p.drag_lin * vv;
+        const float v1 = vv + a * p.dt;
+        const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
+        if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
+        else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
+        else v2 = 0.0f;
+        v2 = clampf(v2, -p.v_rev_max, p.v_max);
+        yaw1 = vyaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
+        if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
+        if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
+        spec_sincos(yaw1, hs, hc);
+        x1 = vx + (v2 * hs) * p.dt;
+        z1 = vz + (v2 * hc) * p.dt;
+        y0 = vy;
+    }
+    // nearest raw track point: binary64 L1, lane-strided scan (two points per trip), DPP argmin, broadcast from lane 63
+    const double qx = (double)x1, qy = (double)y0, qz = (double)z1;
+    double best = TRS_LOST_L1;
+    int bi = 0;
+    int i = lane;
+    for (; i + 64 < p.np; i += 128) {
+        const int i2 = i + 64;
+        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
+        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
+        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
+        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
+        if (d1 < best) { best = d1; bi = i; }
+        if (d2 < best) { best = d2; bi = i2; }
+    }
+    if (i < p.np) {
+        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
+        if (d1 < best) { best = d1; bi = i; }
+    }
+    wave_argmin(best, bi);
+    const int idx = __builtin_amdgcn_readlane(bi, 63);
+    const double bestd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+
+    const float y1 = (float)lpy[idx];
+    const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
+    const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
+    const bool lost = bestd >= TRS_LOST_L1;
+    const int is_done = (fabsf(cte) > p.offtrack_cte) || lost;
+    if (do_reset) {
+        if (lane == 0) { p.last_return[e] = epr; p.pending[e] = 0; }
+        epr = 0.0f; epl = 0;
+    } else {
+        int d = idx - prev_idx;
+        const int half = p.np / 2;
+        if (d >= p.np - half) d -= p.np;
+        if (d < -half) d += p.np;
+        const float reward = (float)d - (is_done ? p.offtrack_penalty : 0.0f);
+        epr = epr + reward;
+        epl += 1;
+    }
+    if (lane == 0) {
+        p.x[e] = x1; p.y[e] = y1; p.z[e] = z1; p.yaw[e] = yaw1; p.v[e] = v2;
+        p.speed[e] = fabsf(v2); p.cte[e] = cte; p.seg_idx[e] = idx; p.done[e] = (uint8_t)is_done;
+        p.ep_return[e] = epr; p.ep_len[e] = epl; p.steer_filt[e] = sf;
+        const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
+        const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
+        cam_out[e] = make_float4(camx, camz, hs, hc);
+        if (is_done) atomicAdd(&p.stats[0], 1ull);
+        if (do_reset) atomicAdd(&p.stats[1], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool raster_team = tid < kRasterThreads;
+    const RParams& p = sp.ra;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;        // LDS byte address of the dynamic segment
+    if (lds0 != 0u) {                                       // the map addressing below assumes LDS offset 0
+        if (tid == 0 && blockIdx.x == 0) atomicAdd(&p.stats[2], 1ull);
+        return;
+    }
+    STAMP(0);
+    // ---- prologue: each team stages the tables it reads (register-staged, all loads before the LDS writes) ----
+    if (raster_team) {
+        if (sp.do_raster) {
+            const u4v* src = reinterpret_cast<const u4v*>(p.blob);
+            u4v* dst = reinterpret_cast<u4v*>(smem);
+            const int n16 = p.blob_bytes >> 4;
+            u4v reg[kStageRegs];
+#pragma unroll
+            for (int r = 0; r < kStageRegs; ++r) { const int i = tid + r * kRasterThreads; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
+#pragma unroll
+            for (int r = 0; r < kStageRegs; ++r) { const int i = tid + r * kRasterThreads; if (i < n16) dst[i] = reg[r]; }
+        }
+    } else if (sp.do_phys) {
+        const int st = tid - kRasterThreads;
+        constexpr int kT = kBlock - kRasterThreads;
+        const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
+        u4v* dst = reinterpret_cast<u4v*>(smem + sp.lds_off_phys);
+        const int n16 = sp.ph.blob_bytes >> 4;
+        for (int base = 0; base < n16; base += 8 * kT) {
+            u4v reg[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; if (i < n16) dst[i] = reg[r]; }
+        }
+    }
+    const int e_begin = blockIdx.x * p.envs_per_wg;
+    const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+
+    // ---- physics team: one wave per env, no further workgroup synchronisation ----
+    if (!raster_team && sp.do_phys) {
+        const uint32_t t = (sp.ph.dev_step ? *sp.ph.dev_step : 0u) + sp.ph.step_off;
+        float4* const cam_out = sp.ph.cam + (size_t)sp.p_slot * sp.ph.n_envs;
+        for (int e = e_begin + (wave - kRasterThreads / 64); e < e_end; e += kPhysWaves)
+            physics_env_wave(sp.ph, smem + sp.lds_off_phys, e, t, 0, cam_out, lane);
+    }
+    STAMP(3);
+    if (sp.seq) {
+        __threadfence_block();
+        __syncthreads();          // single-step call: the raster below renders what the physics team just produced
+    }
+    STAMP(4);
+    if (!raster_team || !sp.do_raster) return;
+
+    // ---- raster team ----
+    // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre offsets uf are
+    // loop constants.  Per pixel: 1 packed fma (gx,gz), 2 saturating converts + 2 min (= floor + clamp), 3 address
+    // ops, 1 LDS map read, shift + bit-field extract, 1 palette address op, 1 LDS palette read.
+    const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
+    const float half_w = (float)(p.W / 2);
+    const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
+    const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (none at W = 160: 16 x 40 = 640)
+    const float uf0 = (float)(cg << 2) + 0.5f - half_w;
+    const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
+    const unsigned pitch = (unsigned)p.map_pitch_b;
+    const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
+    const size_t row_bytes = (size_t)p.gpr * 12;
+    for (int e = e_begin; e < e_end; ++e) {
+        const float4 cam = p.cam[e];      // written by the previous launch (seq = 0) or by this workgroup's physics team (seq = 1)
+        const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
+        unsigned char* const out = p.img + (size_t)e * ((size_t)p.gpe * 12) + (size_t)cg * 12;
+        f2v rt = lrow[vstart < p.H ? vstart : 0];
+        for (int v = vstart; v < p.H; v += p.rows_per_pass) {
+            const int vn = v + p.rows_per_pass;
+            const f2v rtn = lrow[vn < p.H ? vn : v];                            // prefetch the next row's table entry
+            const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+            const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+            const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
+            const f2v d = kk2 * cns;                                           // (dx, dz) = (k*c, -(k*s))
+            auto shade = [&](f2v uf) -> uint32_t {
+                const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
+                const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
+                const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
+                const unsigned xoff = (ix >> 2) & ~3u;                          // byte offset of the map word in its row
+                unsigned waddr, paddr;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(pitch), "v"(xoff));
+                const uint32_t w = *(lds_u32p)(uintptr_t)waddr;                 // map lives at LDS offset 0 (checked above)
+                const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);      // offset uses bits [4:0] = 2*(ix&15)
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(paddr) : "v"(cls), "v"(pal_a));
+                return *(lds_u32p)(uintptr_t)paddr;
+            };
+#if TRS_ABLATE == 2   /* diagnostic build: stores only */
+            const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
+#else
+            const uint32_t c0p = shade(ufa), c1p = shade(ufb), c2p = shade(ufc), c3p = shade(ufd);
+#endif
+            // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
+            const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
+            const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
+            const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
+            uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * row_bytes);
+#if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
+            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)o;
+#else
+            o[0] = w0; o[1] = w1; o[2] = w2;
+#endif
+            rt = rtn;
+        }
+    }
+    STAMP(5);
+}
+
+#undef STAMP_STATS
 // Batched LocationTracker.__find_closest (components/track_data_process.py:89-101): one wave per query,
 // track staged in LDS once per workgroup, queries grid-strided.
 __global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int pts_bytes, int off_py, int off_pz, int np,
@@ -450,39 +655,93 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct trs_env {
     trs_config cfg{};
     int device = 0, n = 0, H = 0, W = 0, cu_count = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t sP = nullptr;            // the handle's stream: every launch, copy and timing event
     hipEvent_t ev[8] = {};
     // device memory
     unsigned char* slab = nullptr;       // state + controls
     uint8_t* img[2] = {nullptr, nullptr};
-    unsigned char* blob = nullptr;
+    unsigned char* blob_p = nullptr;     // physics LDS image
+    unsigned char* blob_r = nullptr;     // raster LDS image
     float* tangent = nullptr;
     float* start_yaw = nullptr;
+    float4* cam = nullptr;               // [kRing][n]
+    uint32_t* d_step = nullptr;
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
-    KParams kp{};
+    PParams pp{};
+    RParams rp{};
     trsim::TrackTables tab;
     bool track_loaded = false;
-    int lds_bytes = 0, pts_bytes = 0;
+    int lds_p = 0, lds_r = 0, pts_bytes = 0;
     uint64_t step_count = 0;
     float *ctl_steer = nullptr, *ctl_thr = nullptr, *ctl_brk = nullptr;
     uint8_t* ctl_reset = nullptr;
     size_t img_bytes = 0;
+    int lds_step = 0, lds_off_phys = 0;
 };
 
 namespace {
 
-int launch_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n_steps, int synth)
+int grid_of(const trs_env* e) { return (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg; }
+
+int sync_all(trs_env* e)
 {
-    KParams p = e->kp;
-    p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = rs;
-    p.synth = synth; p.n_steps = n_steps;
-    p.step0 = (uint32_t)e->step_count;
-    p.img_parity = (int)(e->step_count & 1);
-    const int grid = (e->n + p.envs_per_wg - 1) / p.envs_per_wg;
-    hipLaunchKernelGGL(trs_step_kernel, dim3(grid), dim3(kBlock), e->lds_bytes, e->stream, p);
+    HIPCHK(hipStreamSynchronize(e->sP));
+    return TRS_OK;
+}
+
+// one launch of the fused step kernel: physics of step `phys_step` (if do_phys) and raster of step `raster_step`
+// (if do_raster); seq = 1 makes the raster wait for this launch's physics (both refer to the same step then)
+int launch_step(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth,
+                int do_phys, int do_raster, int seq, uint64_t phys_step, uint64_t raster_step)
+{
+    SParams sp;
+    sp.ph = e->pp;
+    sp.ph.ctl_steer = st; sp.ph.ctl_thr = th; sp.ph.ctl_brk = br; sp.ph.ctl_reset = rs;
+    sp.ph.synth = synth; sp.ph.n_steps = 1; sp.ph.write_cam = 1; sp.ph.dev_step = nullptr; sp.ph.step_off = (uint32_t)phys_step;
+    sp.ra = e->rp;
+    sp.ra.cam = e->cam + (size_t)(raster_step & (kRing - 1)) * e->n;
+    sp.ra.img = e->img[raster_step & 1];
+    sp.do_phys = do_phys; sp.do_raster = do_raster; sp.seq = seq;
+    sp.p_slot = (int)(phys_step & (kRing - 1));
+    sp.lds_off_phys = e->lds_off_phys;
+    hipLaunchKernelGGL(trs_step_kernel, dim3(grid_of(e)), dim3(kBlock), e->lds_step, e->sP, sp);
     HIPCHK(hipGetLastError());
-    e->step_count += (uint64_t)n_steps;
+    return TRS_OK;
+}
+
+// n env steps with a camera.  n == 1: one launch, physics then raster.  n > 1: software pipeline over launches —
+// launch i runs physics of step s0+i beside the raster of step s0+i-1; a physics-only launch opens and a
+// raster-only launch closes the call, so on return state and image both belong to step s0+n-1.
+int run_camera_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n)
+{
+    const uint64_t s0 = e->step_count;
+    int rc = TRS_OK;
+    if (n == 1) {
+        rc = launch_step(e, st, th, br, rs, synth, 1, 1, 1, s0, s0);
+    } else {
+        rc = launch_step(e, st, th, br, rs, synth, 1, 0, 0, s0, s0);
+        for (int i = 1; i < n && !rc; ++i) rc = launch_step(e, st, th, br, nullptr, synth, 1, 1, 0, s0 + i, s0 + i - 1);
+        if (!rc) rc = launch_step(e, st, th, br, nullptr, synth, 0, 1, 0, s0 + n - 1, s0 + n - 1);
+    }
+    if (rc) return rc;
+    e->step_count += (uint64_t)n;
+    return TRS_OK;
+}
+
+// physics-only envs: K steps inside one launch of the physics kernel
+int run_physics_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, int per_launch)
+{
+    for (int done = 0; done < n;) {
+        const int now = std::min(per_launch, n - done);
+        PParams p = e->pp;
+        p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = done == 0 ? rs : nullptr;
+        p.synth = synth; p.n_steps = now; p.cam_slot = 0; p.write_cam = 0; p.dev_step = nullptr; p.step_off = (uint32_t)e->step_count;
+        hipLaunchKernelGGL(trs_physics_kernel, dim3(grid_of(e)), dim3(kBlock), e->lds_p, e->sP, p);
+        HIPCHK(hipGetLastError());
+        e->step_count += (uint64_t)now;
+        done += now;
+    }
     return TRS_OK;
 }
 
@@ -529,45 +788,51 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->sP, hipStreamNonBlocking));
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
 
-    // one slab for all per-env arrays: 12 float + 2 int32 arrays, 3 float + 1 byte control arrays, 2+1 byte arrays
+    // one slab for all per-env arrays: 10 float + 2 int32 state arrays, 3 float + 1 byte control arrays, 2 byte flags
     const size_t n = (size_t)e->n, fa = align_up(n * 4, 256), ba = align_up(n, 256);
     const size_t slab_bytes = fa * (10 + 2 + 3) + ba * 3;
     HIPCHK(hipMalloc((void**)&e->slab, slab_bytes));
-    HIPCHK(hipMemsetAsync(e->slab, 0, slab_bytes, e->stream));
+    HIPCHK(hipMemsetAsync(e->slab, 0, slab_bytes, e->sP));
     unsigned char* c = e->slab;
     auto takef = [&](float*& ptr) { ptr = reinterpret_cast<float*>(c); c += fa; };
-    KParams& k = e->kp;
+    PParams& k = e->pp;
     takef(k.x); takef(k.y); takef(k.z); takef(k.yaw); takef(k.v); takef(k.speed); takef(k.cte);
     takef(k.ep_return); takef(k.last_return); takef(k.steer_filt);
     k.seg_idx = reinterpret_cast<int32_t*>(c); c += fa;
     k.ep_len = reinterpret_cast<int32_t*>(c); c += fa;
     takef(e->ctl_steer); takef(e->ctl_thr); takef(e->ctl_brk);
     k.done = c; c += ba; k.pending = c; c += ba; e->ctl_reset = c; c += ba;
-    HIPCHK(hipMalloc((void**)&e->stats, 4 * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(e->stats, 0, 4 * sizeof(unsigned long long), e->stream));
-    k.stats = e->stats;
+    HIPCHK(hipMalloc((void**)&e->stats, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(e->stats, 0, 64 * sizeof(unsigned long long), e->sP));
+    HIPCHK(hipMalloc((void**)&e->d_step, 64));
+    HIPCHK(hipMemsetAsync(e->d_step, 0, 64, e->sP));
+    HIPCHK(hipMalloc((void**)&e->cam, (size_t)kRing * n * sizeof(float4)));
+    HIPCHK(hipMemsetAsync(e->cam, 0, (size_t)kRing * n * sizeof(float4), e->sP));
+    k.stats = e->stats; k.cam = e->cam;
+    RParams& r = e->rp;
+    r.stats = e->stats;
     if (cfg->render) {
         e->img_bytes = n * (size_t)e->H * e->W * 3;
         for (int b = 0; b < 2; ++b) {
             HIPCHK(hipMalloc((void**)&e->img[b], e->img_bytes));
-            HIPCHK(hipMemsetAsync(e->img[b], 0, e->img_bytes, e->stream));
-            k.img[b] = e->img[b];
+            HIPCHK(hipMemsetAsync(e->img[b], 0, e->img_bytes, e->sP));
         }
     }
     k.n_envs = e->n; k.env_id_base = cfg->env_id_base;
     k.envs_per_wg = (e->n + e->cu_count - 1) / e->cu_count;
-    k.H = e->H; k.W = e->W; k.gpr = e->W / 4; k.gpe = k.gpr * e->H;
+    r.n_envs = e->n; r.envs_per_wg = k.envs_per_wg;
+    r.H = e->H; r.W = e->W; r.gpr = e->W / 4; r.gpe = r.gpr * e->H;
     k.dt = cfg->dt; k.max_steer = cfg->max_steer; k.inv_wheelbase = cfg->inv_wheelbase; k.accel_max = cfg->accel_max;
     k.drag_lin = cfg->drag_lin; k.roll_res = cfg->roll_res; k.brake_max = cfg->brake_max; k.v_max = cfg->v_max;
     k.v_rev_max = cfg->v_rev_max; k.offtrack_cte = cfg->offtrack_cte; k.offtrack_penalty = cfg->offtrack_penalty;
-    k.cam_fwd = cfg->cam_fwd; k.auto_reset = cfg->auto_reset; k.render = cfg->render; k.seed = cfg->seed;
-    if (k.gpr > kBlock) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup"); }
-    k.rows_per_pass = kBlock / k.gpr;      // threads beyond rows_per_pass * gpr idle in the raster phase (none at W = 160: 24 x 40 = 960)
-    k.row_magic = 0;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    k.cam_fwd = cfg->cam_fwd; k.auto_reset = cfg->auto_reset; k.seed = cfg->seed;
+    if (r.gpr > kBlock) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup"); }
+    if (r.gpr > kRasterThreads) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than raster threads"); }
+    r.rows_per_pass = kRasterThreads / r.gpr;   // raster threads beyond rows_per_pass * gpr idle (none at W = 160: 16 x 40 = 640)
+    HIPCHK(hipStreamSynchronize(e->sP));
     *out = e;
     return TRS_OK;
 }
@@ -576,11 +841,12 @@ TRS_EXPORT int trs_destroy(trs_env* e)
 {
     if (!e) return TRS_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->blob); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
+    if (e->sP) (void)hipStreamSynchronize(e->sP);
+    (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
+    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->d_step);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->sP) (void)hipStreamDestroy(e->sP);
     delete e;
     return TRS_OK;
 }
@@ -589,62 +855,73 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(e->device));
+    int rc0 = sync_all(e);
+    if (rc0) return rc0;
     std::string err;
     int rc = trsim::build_tables(e->cfg, h_xyz, n_points, e->tab, err);
     if (rc) return fail(rc, err);
     const trsim::TrackTables& T = e->tab;
-    KParams& k = e->kp;
-    // LDS image layout: [map (pitched rows) @0][px][py][pz][tangent][rowtab][palette] + scratch
+    PParams& k = e->pp;
+    RParams& r = e->rp;
+
+    // ---- physics LDS image: px | py | pz | tangent (when it fits) + scratch ----
     const size_t pts = align_up((size_t)n_points * 8, 16);
-    const int pitch_words = T.info.map_words | 1;          // odd pitch: rows of the map start on different LDS banks
-    k.map_pitch_b = pitch_words * 4;
-    if (k.map_pitch_b >= (1 << 24) || T.info.map_h >= (1 << 24)) return fail(TRS_ERR_LIMIT, "map exceeds the 24-bit multiply of the rasteriser");
-    const size_t map_bytes = (size_t)k.map_pitch_b * T.info.map_h;
+    const size_t scratch = 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4;
     size_t off = 0;
-    k.off_map = 0; off += align_up(map_bytes, 16);
-    k.off_px = (int)off; off += pts;
-    k.off_py = (int)off; off += pts;
-    k.off_pz = (int)off; off += pts;
-    e->pts_bytes = (int)(3 * pts);
+    k.off_py = (int)(off += pts); k.off_pz = (int)(off += pts); off += pts;
+    e->pts_bytes = (int)off;
     k.off_tan = (int)off;
-    {   // tangents ride in LDS when everything still fits in the CU's 160 KiB (generated track: yes; mountain track: no)
-        const size_t scratch_est = (size_t)kEMax * 16 + 3 * kEMax * 8 + (size_t)kEMax * kWaves * 12 + 64;
-        const size_t with_tan = off + align_up((size_t)n_points * 8, 16) + align_up((size_t)e->H * 8, 16) + (size_t)e->H * 16 + scratch_est;
-        k.tan_in_lds = with_tan <= 160 * 1024 ? 1 : 0;
-        if (k.tan_in_lds) off += align_up((size_t)n_points * 8, 16);
-    }
-    k.off_rowtab = (int)off; off += align_up((size_t)e->H * 8, 16);
-    k.off_pal = (int)off; off += (size_t)e->H * 16;
+    const size_t tan_bytes = align_up((size_t)n_points * 8, 16);
+    // ---- raster LDS image: map (rows pitched to an odd number of words) @0 | rowtab | palette ----
+    const int pitch_words = T.info.map_words | 1;          // odd pitch: rows of the map start on different LDS banks
+    r.map_pitch_b = pitch_words * 4;
+    if (r.map_pitch_b >= (1 << 24) || T.info.map_h >= (1 << 24)) return fail(TRS_ERR_LIMIT, "map exceeds the 24-bit multiply of the rasteriser");
+    const size_t map_bytes = (size_t)r.map_pitch_b * T.info.map_h;
+    size_t roff = align_up(map_bytes, 16);
+    r.off_rowtab = (int)roff; roff += align_up((size_t)e->H * 8, 16);
+    r.off_pal = (int)roff; roff += (size_t)e->H * 16;
+    r.blob_bytes = (int)roff;
+    e->lds_r = (int)align_up(roff, 16);
+    if ((size_t)r.blob_bytes > (size_t)kStageRegs * kRasterThreads * 16)
+        return fail(TRS_ERR_LIMIT, "map + camera tables exceed the step kernel's LDS staging capacity");
+    // tangents ride in LDS when the fused kernel's image (raster tables + points + tangents) still fits a CU's 160 KiB
+    e->lds_off_phys = e->lds_r;
+    k.tan_in_lds = ((size_t)e->lds_off_phys + off + tan_bytes <= 160 * 1024) ? 1 : 0;
+    if (k.tan_in_lds) off += tan_bytes;
     k.blob_bytes = (int)off;
     k.off_scratch = (int)off;
-    k.stage_bytes = k.blob_bytes;
-    if ((size_t)(k.off_scratch - k.off_px) > (size_t)kHotRegs * kStagers * 16 || (size_t)k.off_px > (size_t)kMapRegs * kStagers * 16)
-        return fail(TRS_ERR_LIMIT, "tables exceed the register-staging capacity of the step kernel");
-    const size_t scratch = (size_t)kEMax * 16 + 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4;
-    e->lds_bytes = (int)align_up(off + scratch, 16);
-    if (e->lds_bytes > 160 * 1024) return fail(TRS_ERR_LIMIT, "tables exceed the 160 KiB LDS of a CU");
-    std::vector<unsigned char> h(off, 0);
-    for (int r = 0; r < T.info.map_h; ++r)
-        std::memcpy(h.data() + (size_t)r * k.map_pitch_b, T.map.data() + (size_t)r * T.info.map_words, (size_t)T.info.map_words * 4);
-    std::memcpy(h.data() + k.off_px, T.px.data(), (size_t)n_points * 8);
-    std::memcpy(h.data() + k.off_py, T.py.data(), (size_t)n_points * 8);
-    std::memcpy(h.data() + k.off_pz, T.pz.data(), (size_t)n_points * 8);
-    if (k.tan_in_lds) std::memcpy(h.data() + k.off_tan, T.tangent.data(), (size_t)n_points * 8);
-    std::memcpy(h.data() + k.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
-    std::memcpy(h.data() + k.off_pal, T.palette.data(), (size_t)e->H * 16);
-    HIPCHK(hipStreamSynchronize(e->stream));
-    (void)hipFree(e->blob); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
-    e->blob = nullptr; e->tangent = nullptr; e->start_yaw = nullptr;
-    HIPCHK(hipMalloc((void**)&e->blob, off));
+    e->lds_p = (int)align_up(off + scratch, 16);
+    e->lds_step = (int)align_up((size_t)e->lds_off_phys + off, 16);
+    if (e->lds_p > 160 * 1024 || (size_t)k.blob_bytes > (size_t)kHotRegs * kStagers * 16 || (e->cfg.render && e->lds_step > 160 * 1024))
+        return fail(TRS_ERR_LIMIT, "track too long for the LDS-resident nearest-point search");
+    std::vector<unsigned char> hp(off, 0);
+    std::memcpy(hp.data(), T.px.data(), (size_t)n_points * 8);
+    std::memcpy(hp.data() + k.off_py, T.py.data(), (size_t)n_points * 8);
+    std::memcpy(hp.data() + k.off_pz, T.pz.data(), (size_t)n_points * 8);
+    if (k.tan_in_lds) std::memcpy(hp.data() + k.off_tan, T.tangent.data(), (size_t)n_points * 8);
+
+    std::vector<unsigned char> hr(roff, 0);
+    for (int row = 0; row < T.info.map_h; ++row)
+        std::memcpy(hr.data() + (size_t)row * r.map_pitch_b, T.map.data() + (size_t)row * T.info.map_words, (size_t)T.info.map_words * 4);
+    std::memcpy(hr.data() + r.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
+    std::memcpy(hr.data() + r.off_pal, T.palette.data(), (size_t)e->H * 16);
+
+    (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
+    e->blob_p = e->blob_r = nullptr; e->tangent = nullptr; e->start_yaw = nullptr;
+    HIPCHK(hipMalloc((void**)&e->blob_p, off));
+    HIPCHK(hipMalloc((void**)&e->blob_r, roff));
     HIPCHK(hipMalloc((void**)&e->tangent, (size_t)n_points * 8));
     HIPCHK(hipMalloc((void**)&e->start_yaw, (size_t)n_points * 4));
-    HIPCHK(hipMemcpy(e->blob, h.data(), off, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->blob_p, hp.data(), off, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->blob_r, hr.data(), roff, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->tangent, T.tangent.data(), (size_t)n_points * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->start_yaw, T.start_yaw.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
-    k.blob = e->blob; k.start_yaw = e->start_yaw; k.tangent_g = e->tangent;
-    k.np = n_points; k.map_w = T.info.map_w; k.map_h = T.info.map_h; k.map_words = T.info.map_words;
+    k.blob = e->blob_p; k.start_yaw = e->start_yaw; k.tangent_g = e->tangent;
+    r.blob = e->blob_r;
+    k.np = n_points; r.map_w = T.info.map_w; r.map_h = T.info.map_h;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_step));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->pts_bytes));
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
     const size_t n = (size_t)e->n;
@@ -664,7 +941,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(k.ep_len, 0, n * 4));
     HIPCHK(hipMemset(k.done, 0, n));
     HIPCHK(hipMemset(k.pending, 1, n));
-    HIPCHK(hipMemset(e->stats, 0, 32));
+    HIPCHK(hipMemset(e->stats, 0, 64 * sizeof(unsigned long long)));
     e->step_count = 0;
     e->track_loaded = true;
     return TRS_OK;
@@ -674,12 +951,13 @@ TRS_EXPORT int trs_reset(trs_env* e, const uint8_t* h_mask)
 {
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    if (!h_mask) { HIPCHK(hipMemset(e->kp.pending, 1, (size_t)e->n)); return TRS_OK; }
+    int rc = sync_all(e);
+    if (rc) return rc;
+    if (!h_mask) { HIPCHK(hipMemset(e->pp.pending, 1, (size_t)e->n)); return TRS_OK; }
     std::vector<uint8_t> cur((size_t)e->n);
-    HIPCHK(hipMemcpy(cur.data(), e->kp.pending, cur.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cur.data(), e->pp.pending, cur.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < e->n; ++i) if (h_mask[i]) cur[i] = 1;
-    HIPCHK(hipMemcpy(e->kp.pending, cur.data(), cur.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->pp.pending, cur.data(), cur.size(), hipMemcpyHostToDevice));
     return TRS_OK;
 }
 
@@ -689,7 +967,9 @@ TRS_EXPORT int trs_step(trs_env* e, const float* d_st, const float* d_th, const 
     if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
-    return launch_steps(e, d_st, d_th, d_br, d_rs, n_steps, 0);
+    // held controls; the reset request applies to the first step only
+    return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps)
+                         : run_physics_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, 1);
 }
 
 TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps)
@@ -699,11 +979,11 @@ TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, c
     if (!h_st || !h_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
     const size_t n = (size_t)e->n;
-    HIPCHK(hipMemcpyAsync(e->ctl_steer, h_st, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(e->ctl_thr, h_th, n * 4, hipMemcpyHostToDevice, e->stream));
-    if (h_br) HIPCHK(hipMemcpyAsync(e->ctl_brk, h_br, n * 4, hipMemcpyHostToDevice, e->stream));
-    if (h_rs) HIPCHK(hipMemcpyAsync(e->ctl_reset, h_rs, n, hipMemcpyHostToDevice, e->stream));
-    return launch_steps(e, e->ctl_steer, e->ctl_thr, h_br ? e->ctl_brk : nullptr, h_rs ? e->ctl_reset : nullptr, n_steps, 0);
+    HIPCHK(hipMemcpyAsync(e->ctl_steer, h_st, n * 4, hipMemcpyHostToDevice, e->sP));
+    HIPCHK(hipMemcpyAsync(e->ctl_thr, h_th, n * 4, hipMemcpyHostToDevice, e->sP));
+    if (h_br) HIPCHK(hipMemcpyAsync(e->ctl_brk, h_br, n * 4, hipMemcpyHostToDevice, e->sP));
+    if (h_rs) HIPCHK(hipMemcpyAsync(e->ctl_reset, h_rs, n, hipMemcpyHostToDevice, e->sP));
+    return trs_step(e, e->ctl_steer, e->ctl_thr, h_br ? e->ctl_brk : nullptr, h_rs ? e->ctl_reset : nullptr, n_steps);
 }
 
 TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
@@ -711,19 +991,15 @@ TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     HIPCHK(hipSetDevice(e->device));
-    for (int done = 0; done < n_steps;) {
-        const int now = std::min(steps_per_launch, n_steps - done);
-        int rc = launch_steps(e, nullptr, nullptr, nullptr, nullptr, now, 1);
-        if (rc) return rc;
-        done += now;
-    }
-    return TRS_OK;
+    // camera on: one launch per step, pipelined over the call (steps_per_launch applies to physics-only envs)
+    return e->cfg.render ? run_camera_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps)
+                         : run_physics_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch);
 }
 
 TRS_EXPORT int trs_get_state(trs_env* e, trs_state_view* o)
 {
     if (!e || !o) return fail(TRS_ERR_ARG, "null argument");
-    const KParams& k = e->kp;
+    const PParams& k = e->pp;
     o->n_envs = e->n; o->img_h = e->H; o->img_w = e->W; o->n_points = k.np;
     o->img = e->cfg.render ? e->img[(e->step_count + 1) & 1] : nullptr;   // buffer written by the last step
     o->pos_x = k.x; o->pos_y = k.y; o->pos_z = k.z; o->speed = k.speed; o->cte = k.cte; o->yaw = k.yaw; o->vel = k.v;
@@ -736,7 +1012,7 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
 {
     if (!e || !dst) return fail(TRS_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(e->device));
-    const KParams& k = e->kp;
+    const PParams& k = e->pp;
     const void* src = nullptr; size_t need = 0; const size_t n = (size_t)e->n;
     bool host_src = false;
     switch (which) {
@@ -754,17 +1030,22 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_EP_LEN: src = k.ep_len; need = n * 4; break;
     case TRS_F_DONE: src = k.done; need = n; break;
     case TRS_F_STEER_FILT: src = k.steer_filt; need = n * 4; break;
-    case TRS_F_MAP: if (e->track_loaded) { src = e->tab.map.data(); need = (size_t)k.map_words * k.map_h * 4; host_src = true; } break;
-    case TRS_F_ROWTAB: if (e->track_loaded) { src = e->blob + k.off_rowtab; need = (size_t)e->H * 8; } break;
-    case TRS_F_PALETTE: if (e->track_loaded) { src = e->blob + k.off_pal; need = (size_t)e->H * 16; } break;
+    case TRS_F_STATS: src = e->stats; need = 64 * sizeof(unsigned long long); break;
+    // the tables live on the host exactly as built; their LDS images on the device are re-laid-out (pitched map)
+    case TRS_F_MAP: if (e->track_loaded) { src = e->tab.map.data(); need = e->tab.map.size() * 4; host_src = true; } break;
+    case TRS_F_ROWTAB: if (e->track_loaded) { src = e->blob_r + e->rp.off_rowtab; need = (size_t)e->H * 8; } break;
+    case TRS_F_PALETTE: if (e->track_loaded) { src = e->blob_r + e->rp.off_pal; need = (size_t)e->H * 16; } break;
     case TRS_F_TANGENT: if (e->track_loaded) { src = e->tangent; need = (size_t)k.np * 8; } break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
     if (!src) return fail(TRS_ERR_STATE, "field not available");
     if (bytes != need) return fail(TRS_ERR_ARG, "byte count mismatch");
-    if (host_src) { std::memcpy(dst, src, need); return TRS_OK; }   // the unpitched map lives on the host; its LDS image is pitched
-    HIPCHK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (host_src) { std::memcpy(dst, src, need); return TRS_OK; }
+    int rc = sync_all(e);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    if (which == TRS_F_STATS && static_cast<unsigned long long*>(dst)[2] != 0)
+        return fail(TRS_ERR_DEVICE, "raster kernel found its dynamic LDS segment at a non-zero offset");
     return TRS_OK;
 }
 
@@ -772,9 +1053,10 @@ TRS_EXPORT int trs_set_pose(trs_env* e, const float* x, const float* y, const fl
 {
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = sync_all(e);
+    if (rc) return rc;
     const size_t n = (size_t)e->n;
-    const KParams& k = e->kp;
+    const PParams& k = e->pp;
     if (x) HIPCHK(hipMemcpy(k.x, x, n * 4, hipMemcpyHostToDevice));
     if (y) HIPCHK(hipMemcpy(k.y, y, n * 4, hipMemcpyHostToDevice));
     if (z) HIPCHK(hipMemcpy(k.z, z, n * 4, hipMemcpyHostToDevice));
@@ -792,22 +1074,22 @@ TRS_EXPORT int trs_locate(trs_env* e, const double* h_xyz, int nq, int32_t* h_id
     if (nq == 0) return TRS_OK;
     HIPCHK(hipSetDevice(e->device));
     if (nq > e->loc_cap) {
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipStreamSynchronize(e->sP));
         (void)hipFree(e->loc_q); (void)hipFree(e->loc_out); e->loc_q = nullptr; e->loc_out = nullptr; e->loc_cap = 0;
         HIPCHK(hipMalloc((void**)&e->loc_q, (size_t)nq * 24));
         HIPCHK(hipMalloc((void**)&e->loc_out, (size_t)nq * 4));
         e->loc_cap = nq;
     }
-    HIPCHK(hipMemcpyAsync(e->loc_q, h_xyz, (size_t)nq * 24, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->loc_q, h_xyz, (size_t)nq * 24, hipMemcpyHostToDevice, e->sP));
     constexpr int kW = kLocBlock / 64;
     int grid = (nq + kW - 1) / kW;
     grid = std::min(grid, e->cu_count * 2);
-    hipLaunchKernelGGL(trs_locate_kernel, dim3(grid), dim3(kLocBlock), e->pts_bytes, e->stream,
-                       (const unsigned char*)e->blob + e->kp.off_px, e->pts_bytes, e->kp.off_py - e->kp.off_px, e->kp.off_pz - e->kp.off_px, e->kp.np,
+    hipLaunchKernelGGL(trs_locate_kernel, dim3(grid), dim3(kLocBlock), e->pts_bytes, e->sP,
+                       (const unsigned char*)e->blob_p, e->pts_bytes, e->pp.off_py, e->pp.off_pz, e->pp.np,
                        (const double*)e->loc_q, nq, e->loc_out);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_idx, e->loc_out, (size_t)nq * 4, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpyAsync(h_idx, e->loc_out, (size_t)nq * 4, hipMemcpyDeviceToHost, e->sP));
+    HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
 }
 
@@ -815,7 +1097,7 @@ TRS_EXPORT int trs_map_info_get(trs_env* e, trs_map_info* o)
 {
     if (!e || !o || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     *o = e->tab.info;
-    o->lds_bytes = e->lds_bytes;
+    o->lds_bytes = e->cfg.render ? e->lds_step : e->lds_p;
     return TRS_OK;
 }
 
@@ -823,15 +1105,14 @@ TRS_EXPORT int trs_sync(trs_env* e)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    return TRS_OK;
+    return sync_all(e);
 }
 
 TRS_EXPORT int trs_event_record(trs_env* e, int slot)
 {
     if (!e || slot < 0 || slot >= 8) return fail(TRS_ERR_ARG, "bad event slot");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipEventRecord(e->ev[slot], e->stream));
+    HIPCHK(hipEventRecord(e->ev[slot], e->sP));
     return TRS_OK;
 }
 

@@ -20,7 +20,7 @@ _FIELD_DTYPES = {
     "img": np.uint8, "pos_x": np.float32, "pos_y": np.float32, "pos_z": np.float32, "speed": np.float32,
     "cte": np.float32, "yaw": np.float32, "vel": np.float32, "seg_idx": np.int32, "ep_return": np.float32,
     "last_return": np.float32, "ep_len": np.int32, "done": np.uint8, "map": np.uint32, "rowtab": np.float32,
-    "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32,
+    "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32, "stats": np.uint64,
 }
 
 
@@ -143,7 +143,7 @@ class BatchedEnv:
         mi = self.map_info
         return {
             "img": (self.n, self.H, self.W, 3), "map": (mi.map_h, mi.map_words) if mi else None,
-            "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2),
+            "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2), "stats": (64,),
         }.get(name, (self.n,))
 
     def fetch(self, name):
