@@ -1,0 +1,100 @@
+"""Drop-in parts in the Car loop.  The CPU variants inject the oracle backend to exercise the HOST logic (port
+names, Python types, None handling, record writing); the gpu variant runs the same loop on the HIP path and
+compares the two frame by frame."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from triton_racer_sim_amd.components import GYM_INPUTS, GYM_OUTPUTS, BatchedGymInterface, HipGymInterface, LocationTracker
+from triton_racer_sim_amd.core import Car, Component
+from triton_racer_sim_amd.recorder import DataStorage
+
+
+class Driver(Component):
+    """Stands in for joystick + multiplexer: emits mux/* and the recorder's usr/* flags."""
+
+    def __init__(self, n_ticks):
+        super().__init__(outputs=["mux/steering", "mux/throttle", "mux/breaking", "usr/reset", "usr/del_record", "usr/toggle_record"])
+        self.k, self.n = 0, n_ticks
+
+    def step(self, *args):
+        self.k += 1
+        if self.k > self.n:
+            raise KeyboardInterrupt
+        return 0.3 * np.sin(self.k / 5.0), 0.6, None if self.k % 2 else 0.0, self.k == 10, False, True
+
+
+class Probe(Component):
+    def __init__(self):
+        super().__init__(inputs=GYM_OUTPUTS + ["loc/segment"])
+        self.rows = []
+
+    def step(self, *args):
+        self.rows.append(args)
+
+
+def drive(api, tmp_path, n_ticks=25):
+    cfg = dict(load_golden("config_keys.json")["values"])             # the reference's full default config dict (G6)
+    cfg.update(scene_name="generated_track", use_location_tracker=True)
+    gym = HipGymInterface(poll_socket_sleep_time=0.01, gym_config=cfg, _api=api)
+    tracker = LocationTracker(track_data_path=cfg["track_data_file"], _api=api)
+    store, probe = DataStorage(storage_path=str(tmp_path / "records_1")), Probe()
+    car = Car(loop_hz=1e9, verbose=False)
+    for part in (Driver(n_ticks), gym, tracker, probe, store):         # manage.py:54-108 order: controls, sim, tracker, storage
+        car.addComponent(part)
+    car.start()
+    return gym, probe, tmp_path / "records_1"
+
+
+def check_run(gym, probe, rec_dir, n_ticks=25):
+    assert gym.step_inputs == GYM_INPUTS and gym.step_outputs == GYM_OUTPUTS and gym.threaded is False
+    assert gym.getName() == "Gym Interface"
+    assert len(probe.rows) == n_ticks
+    img, x, y, z, speed, cte, seg = probe.rows[-1]
+    assert isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.shape == (120, 160, 3) and img.flags["C_CONTIGUOUS"]
+    assert all(type(v) is float for v in (x, y, z, speed, cte, seg))   # Python floats: json.dump needs them
+    assert 0.0 <= seg < 10.0 and 0.5 < y < 0.6 and speed > 1.0
+    assert probe.rows[3][0] is not probe.rows[4][0]                    # a fresh array per frame, never overwritten
+    assert not np.array_equal(probe.rows[3][0], probe.rows[-1][0])
+    assert probe.rows[9][4] == 0.0 and probe.rows[8][4] > 0.0          # the 10th tick carried usr/reset: back at the start, v = 0
+    rec = json.load(open(rec_dir / "record_5.json"))
+    g3 = load_golden("datastorage_record.json")
+    assert list(rec) == g3["records"]["record_0.json"]["keys"]
+    assert rec["cam/img"] == "img_5.jpg" and rec["mux/break"] is None and os.path.exists(rec_dir / "img_5.jpg")
+    assert rec["gym/x"] == probe.rows[5][1] and rec["loc/segment"] == probe.rows[5][6]
+
+
+def test_car_loop_with_oracle_backend(oracle_api, tmp_path):
+    gym, probe, rec_dir = drive(oracle_api, tmp_path)
+    check_run(gym, probe, rec_dir)
+
+
+def test_location_tracker_contract(oracle_api):
+    lt = LocationTracker("track_data/generated_track.json", _api=oracle_api)
+    g1 = load_golden("locate_generated.json")
+    for k in range(0, 400, 13):
+        assert lt.step(*g1["queries"][k]) == (g1["segment"][k],)
+    with pytest.raises(TypeError):
+        lt.step(None, 0.0, 0.0)                                        # the reference raises TypeError on None too
+    assert lt.step_inputs == ["gym/x", "gym/y", "gym/z"] and lt.step_outputs == ["loc/segment"]
+
+
+def test_batched_interface_ports(oracle_api):
+    part = BatchedGymInterface(6, to_host=True, _api=oracle_api)
+    out = part.step(None, None, None, None)                            # first tick: nothing on the bus yet
+    assert len(out) == len(part.step_outputs) == 8 and out[0].shape == (6, 120, 160, 3) and out[6].dtype == np.int32
+    out = part.step(np.linspace(-1, 1, 6), 0.5, None, None)
+    assert out[4].shape == (6,) and (out[4] > 0).all()
+
+
+@pytest.mark.gpu
+def test_car_loop_on_gpu_equals_oracle(oracle_api, tmp_path):
+    gym, probe, rec_dir = drive(None, tmp_path / "gpu")
+    check_run(gym, probe, rec_dir)
+    _, ref, _ = drive(oracle_api, tmp_path / "cpu")
+    for a, b in zip(probe.rows, ref.rows):
+        assert np.array_equal(a[0], b[0])                              # frame, byte for byte
+        assert a[6] == b[6] and max(abs(p - q) for p, q in zip(a[1:6], b[1:6])) <= 1e-5

@@ -1,0 +1,68 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/trsim.h declares, agrees with the
+ctypes struct layouts, and fails LOUDLY when there is no device (no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from triton_racer_sim_amd import _ffi
+
+
+def header_functions():
+    with open(os.path.join(ROOT, "include", "trsim.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(trs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds():
+    assert header_functions() == sorted("trs_" + s for s in _ffi.SYMBOLS)
+
+
+def test_hip_library_exports_every_symbol():
+    lib = ctypes.CDLL(_ffi.HIP_LIB_PATH)          # built by __graft_entry__.build(); loading needs no GPU
+    for name in header_functions():
+        assert hasattr(lib, name), name
+
+
+def test_oracle_exports_the_same_abi(oracle_api):
+    for s in _ffi.SYMBOLS:
+        assert hasattr(oracle_api.cdll, "trso_" + s), s
+
+
+def test_struct_layouts_match_c(oracle_api, hip_api):
+    for api in (oracle_api, hip_api):
+        cfg = _ffi.TrsConfig()
+        api.default_config(ctypes.byref(cfg))
+        assert cfg.struct_size == ctypes.sizeof(_ffi.TrsConfig)      # C sizeof(trs_config) == ctypes layout
+        assert (cfg.img_h, cfg.img_w, cfg.render, cfg.seed) == (120, 160, 1, 0x5EED)
+        assert abs(cfg.dt - 0.05) < 1e-9 and cfg.z_far == 40.0      # last field reads back -> no padding drift
+
+
+def test_bad_arguments_return_errors_not_crashes(oracle_api):
+    h = ctypes.c_void_p()
+    cfg = _ffi.TrsConfig()
+    oracle_api.default_config(ctypes.byref(cfg))
+    cfg.struct_size = 8
+    assert oracle_api.create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
+    assert b"struct_size" in oracle_api.last_error()
+    oracle_api.default_config(ctypes.byref(cfg))
+    cfg.img_w = 158
+    assert oracle_api.create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
+    oracle_api.default_config(ctypes.byref(cfg))
+    assert oracle_api.create(ctypes.byref(cfg), 0, ctypes.byref(h)) == 0
+    assert oracle_api.step_synthetic(h, 1, 1) == -2                  # no track loaded
+    assert oracle_api.destroy(h) == 0
+
+
+def test_product_fails_loudly_without_gpu(hip_api):
+    n = ctypes.c_int(-1)
+    assert hip_api.device_count(ctypes.byref(n)) == 0
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    from triton_racer_sim_amd.env import BatchedEnv
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        BatchedEnv(n_envs=2)
+    with pytest.raises(RuntimeError, match="HIP extension not built"):
+        _ffi.load_hip_library("/nonexistent/libtrsim.so")

@@ -1,0 +1,71 @@
+"""Rows either side of the hot path, on CPU: the record writer against fixture G3 and the
+vectorised control glue against fixtures G4 / G5 (all captured from the reference)."""
+import json
+import os
+
+import numpy as np
+
+from conftest import load_golden
+from triton_racer_sim_amd import control
+from triton_racer_sim_amd.recorder import DataStorage
+
+
+def test_record_layout_equals_reference(tmp_path):
+    g3 = load_golden("datastorage_record.json")
+    ds = DataStorage(storage_path=str(tmp_path / "records_1"))
+    assert ds.step_inputs == g3["step_inputs"]
+    img = (np.arange(120 * 160 * 3, dtype=np.uint32) % 251).astype(np.uint8).reshape(120, 160, 3)
+    ds.step(img, 0.5, -0.25, None, 3.5, 1.25, 47.5, 0.56, 46.7, 0.125, False, True)
+    ds.step(img, np.float32(0.6), 0.25, None, 3.6, 1.5, 47.6, 0.56, 46.8, -0.125, False, True)   # numpy scalar is accepted
+    ds.step(img, 0.0, 0.0, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, False, False)                      # not recording
+    ds.onShutdown()
+    files = sorted(os.listdir(tmp_path / "records_1"))
+    assert files == g3["files"]                                        # img_0.jpg, img_1.jpg, record_0.json, record_1.json
+    raw0 = open(tmp_path / "records_1" / "record_0.json").read()
+    assert raw0 == g3["records"]["record_0.json"]["raw"]               # byte-identical JSON (key order, null, floats)
+    rec1 = json.load(open(tmp_path / "records_1" / "record_1.json"))
+    assert list(rec1) == g3["records"]["record_1.json"]["keys"] and abs(rec1["mux/throttle"] - 0.6) < 1e-6
+    from PIL import Image
+    im = Image.open(tmp_path / "records_1" / "img_0.jpg")
+    assert list(im.size) == g3["jpeg_size"] and im.mode == g3["jpeg_mode"]
+
+
+def test_recorder_delete_and_empty_folder(tmp_path):
+    ds = DataStorage(to_store=["gym/speed"], storage_path=str(tmp_path / "r"))
+    for k in range(3):
+        ds.step(float(k), False, True)
+    ds.step(9.0, True, False)                                          # del_record: count -> max(count - 100, 0)
+    ds.step(7.0, False, True)
+    ds.onShutdown()
+    assert json.load(open(tmp_path / "r" / "record_0.json"))["gym/speed"] == 7.0      # overwritten from index 0
+    empty = DataStorage(to_store=["gym/speed"], storage_path=str(tmp_path / "e"))
+    empty.onShutdown()
+    assert not os.path.exists(tmp_path / "e")
+
+
+def test_speed_controller_tables():
+    g4 = load_golden("mapping.json")
+    for name, fn in (("calcThrottle", control.calc_throttle), ("calcBreak", control.calc_break)):
+        rows = np.asarray(g4[name])
+        out = fn(rows[:, 0], rows[:, 1], rows[:, 2])
+        assert np.allclose(out, rows[:, 3], rtol=0, atol=1e-15), name
+        assert ((rows[:, 3] == 0) == (out == 0)).all()                 # dead bands hit exactly
+    rows = np.asarray(g4["three_segment_map"])
+    assert np.allclose(control.three_segment_map(rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3]), rows[:, 4], atol=1e-12)
+
+
+def test_driver_assistance_tables():
+    g5 = load_golden("driver_assistance.json")
+    for mode, rows in g5.items():
+        for args, want in rows:
+            got = control.driver_assistance(*args, mode=mode, k=5)
+            if None in args:
+                assert list(got) == want                               # pass-through, untouched
+                continue
+            got = [float(np.asarray(g).reshape(-1)[0]) for g in got]
+            assert np.allclose(got, want, atol=1e-12), (mode, args, got, want)
+    # batched call == row by row
+    rows = [r for r in g5["steering"] if None not in r[0]]
+    a = np.asarray([r[0] for r in rows], dtype=np.float64)
+    st, th, br = control.driver_assistance(a[:, 0], a[:, 1], a[:, 2], a[:, 3], mode="steering", k=5)
+    assert np.allclose(np.stack([st, th, br], 1), np.asarray([r[1] for r in rows]), atol=1e-12)

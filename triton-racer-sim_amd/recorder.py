@@ -1,0 +1,94 @@
+"""Record writer with the reference's tub layout (``components/datastorage.py:13-33,67-79``).
+
+One record per recorded tick: ``record_{k}.json`` + ``img_{k}.jpg`` with ``k`` starting at 0
+(``datastorage.py:100,111-112``; the reference's loaders start reading at 1 — ``keras_train.py:36`` — a
+quirk of the reference that is preserved, not fixed).  The JSON holds the stored port values in declared
+order followed by ``usr/del_record`` and ``usr/toggle_record``; the image value is replaced by its file
+name (``:76-79``).  Key quirk kept: the default list stores ``mux/break`` although the multiplexer writes
+``mux/breaking`` (``datastorage.py:13`` vs ``controlmultiplexer.py:9``), so it records ``null`` unless a
+DriverAssistance part runs.
+
+Differences that do not change the files: values are passed through ``float()`` / ``int()`` when they are
+numpy scalars (``json.dump`` of ``np.float32`` raises in the reference, ``gyminterface.py:100-104`` avoids
+it the same way), and ``onShutdown`` drains the queue instead of abandoning it.
+"""
+import json
+import os
+import queue
+import threading
+
+import numpy as np
+
+from .core import Component
+
+DEFAULT_TO_STORE = ["cam/img", "mux/throttle", "mux/steering", "mux/break", "gym/speed", "loc/segment",
+                    "gym/x", "gym/y", "gym/z", "gym/cte"]
+
+
+def _plain(v):
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
+
+
+class DataStorage(Component):
+    def __init__(self, to_store=None, storage_path=None):
+        Component.__init__(self, inputs=list(DEFAULT_TO_STORE if to_store is None else to_store), threaded=False)
+        self.step_inputs += ["usr/del_record", "usr/toggle_record"]
+        if storage_path is None:
+            raise ValueError("storage_path is required (the reference derives it from sys.path[0]/data/records_N)")
+        self.storage_path = storage_path
+        os.mkdir(self.storage_path)
+        self.count = 0
+        self._written = 0
+        self._q = queue.Queue()
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._io_loop, daemon=True)
+        self._thread.start()
+
+    def step(self, *args):
+        if args[-2]:                                   # usr/del_record: forget the last 100 (datastorage.py:27-28,82-87)
+            self.count = max(self.count - 100, 0)
+            self._q.put(("rewind", self.count))
+        elif args[-1]:                                 # usr/toggle_record
+            record = {name: args[i] for i, name in enumerate(self.step_inputs)}
+            self._q.put(("store", record))
+            self.count += 1
+
+    def _store(self, k, record):
+        key = "cam/img" if "cam/img" in record else "cam/processed_img"
+        img = record.get(key)
+        if img is not None:
+            from PIL import Image
+            Image.fromarray(np.asarray(img)).save(os.path.join(self.storage_path, f"img_{k}.jpg"))
+            record[key] = f"img_{k}.jpg"
+        with open(os.path.join(self.storage_path, f"record_{k}.json"), "w") as f:
+            json.dump({name: _plain(v) for name, v in record.items()}, f)
+
+    def _io_loop(self):
+        while True:
+            try:
+                kind, payload = self._q.get(timeout=0.05)
+            except queue.Empty:
+                if self._stop.is_set():
+                    return
+                continue
+            if kind == "rewind":
+                self._written = payload
+            else:
+                self._store(self._written, payload)
+                self._written += 1
+
+    def flush(self):
+        while not self._q.empty():
+            threading.Event().wait(0.005)
+
+    def onShutdown(self):
+        self.flush()
+        self._stop.set()
+        self._thread.join(timeout=5)
+        if not os.listdir(self.storage_path):          # datastorage.py:45-47
+            os.rmdir(self.storage_path)
+
+    def getName(self):
+        return "Data Storage"

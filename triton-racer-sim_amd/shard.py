@@ -1,0 +1,47 @@
+"""Env shards over the GPUs of one node: one process per GPU, rank r owns the contiguous global env ids
+``[r * n_local, (r + 1) * n_local)``.  Shards never exchange state (the track is replicated, RNG streams and
+start poses are keyed by GLOBAL env id), so the data path has no collective; the only exchange is ONE
+all-gather of the per-env episode returns (RCCL over xGMI with the ``nccl`` backend, 4 B per env — latency
+bound, issued per reporting interval, never per step).  The reference has no distributed layer at all
+(SURVEY.md §5); this is the MI355X-native fan-out named by BASELINE.json's north_star.
+"""
+import numpy as np
+
+from .env import BatchedEnv
+
+
+def shard_range(n_total, rank, world):
+    if n_total % world:
+        raise ValueError(f"n_total={n_total} is not divisible by world_size={world}")
+    n_local = n_total // world
+    return rank * n_local, n_local
+
+
+class ShardedEnvs:
+    def __init__(self, n_total, rank=0, world=1, device=None, _api=None, **env_kw):
+        self.n_total, self.rank, self.world = int(n_total), int(rank), int(world)
+        self.base, self.n_local = shard_range(self.n_total, self.rank, self.world)
+        self.env = BatchedEnv(n_envs=self.n_local, env_id_base=self.base, device=self.rank if device is None else device,
+                              _api=_api, **env_kw)
+
+    def step_synthetic(self, n_steps=1, steps_per_launch=1):
+        self.env.step_synthetic(n_steps, steps_per_launch)
+
+    def allgather(self, name="ep_return"):
+        """All ranks receive the full ``[n_total]`` vector of a per-env float32 field, ordered by global env id."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1 or not dist.is_initialized():
+            return torch.from_numpy(self.env.fetch(name))
+        if dist.get_backend() == "nccl":                       # device-resident, zero copy: RCCL all-gather over xGMI
+            self.env.sync()
+            local = torch.as_tensor(self.env.device_array(name), device="cuda")
+            out = torch.empty(self.n_total, dtype=local.dtype, device="cuda")
+        else:                                                  # gloo (CPU tests)
+            local = torch.from_numpy(np.ascontiguousarray(self.env.fetch(name)))
+            out = torch.empty(self.n_total, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local)
+        return out
+
+    def close(self):
+        self.env.close()
