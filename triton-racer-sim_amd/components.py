@@ -121,6 +121,8 @@ class LocationTracker(Component):
         return self.env.locate(points)
 
     def localize(self, point):
+        if any(c is None for c in point):                 # the reference fails in abs(None - float) (track_data_process.py:104)
+            raise TypeError("unsupported operand type(s) for -: 'NoneType' and 'float'")
         idx = int(self.env.locate(np.asarray(point, dtype=np.float64).reshape(1, 3))[0])
         return idx / float(len(self.data)) * (self.max - self.min) + self.min, 0.0
 
