@@ -123,7 +123,7 @@ def main():
         args.gpus = world
 
     import torch
-    from triton_racer_sim_amd.env import BatchedEnv
+    from triton_racer_sim_amd.shard import ShardedEnvs
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
@@ -136,8 +136,8 @@ def main():
 
     n = args.envs_per_gpu
     render = not args.no_render
-    env = BatchedEnv(n_envs=n, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render,
-                     auto_reset=True, env_id_base=rank * n)
+    shard = ShardedEnvs(n * world, rank, world, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render, auto_reset=True)
+    env = shard.env
     spl = max(1, args.steps_per_launch)
 
     def barrier():
@@ -159,10 +159,7 @@ def main():
     env.event_record(1)
     gathered = None
     if dist is not None:
-        env.sync()                                                     # returns are final before the exchange
-        local = torch.as_tensor(env.device_array("ep_return"), device="cuda")
-        gathered = torch.empty(n * world, device="cuda", dtype=torch.float32)
-        dist.all_gather_into_tensor(gathered, local)                   # the single RCCL all-gather over xGMI
+        gathered = shard.allgather("ep_return")                        # the single RCCL all-gather over xGMI (4 B per env)
     barrier()
     wall = time.perf_counter() - t0
     kernel_ms = env.event_elapsed_ms(0, 1)

@@ -32,3 +32,16 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
         print("== pmc", os.path.basename(os.path.dirname(os.path.dirname(f))), k[:50])
         for c, v in d.items():
             print(f"   {c}: mean/dispatch={sum(v)/len(v):.1f} n={len(v)}")
+
+# HBM traffic per launch for bench.py's roofline.traffic: WRITE_SIZE + 2 x FETCH_SIZE (KiB; gfx950 FETCH_SIZE reads 1/2
+# of a wide coalesced stream, /opt/skills/guides/MI355X_MICROARCH.md section HBM), mean over the step-kernel dispatches
+import json
+vals = {}
+for name in ("WRITE_SIZE", "FETCH_SIZE"):
+    for f in glob.glob(os.path.join(out, f"pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "trs_step" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if v: vals[name] = sum(v) / len(v)
+if len(vals) == 2:
+    traffic = (vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"]) * 1024
+    print(f"== traffic per launch: {traffic:.0f} B (WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB, FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB x2)")
+    json.dump({"traffic_bytes_per_launch": traffic, **vals}, open(os.path.join(out, "traffic.json"), "w"))

@@ -37,6 +37,7 @@ class Probe(Component):
 
 
 def drive(api, tmp_path, n_ticks=25):
+    os.makedirs(tmp_path, exist_ok=True)
     cfg = dict(load_golden("config_keys.json")["values"])             # the reference's full default config dict (G6)
     cfg.update(scene_name="generated_track", use_location_tracker=True)
     gym = HipGymInterface(poll_socket_sleep_time=0.01, gym_config=cfg, _api=api)
