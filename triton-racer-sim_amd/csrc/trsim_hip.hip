@@ -1,29 +1,24 @@
 // trsim_hip.hip — libtrsim.so: the gfx950 (MI355X, CDNA4) kernels and the C ABI of include/trsim.h.
 //
-// One env step = two kernels on separate HIP streams (no tracing compiler, explicit streams + hipGraph):
+//   trs_step_kernel     camera on: ONE launch per env step on ONE stream.  960-thread workgroups (15 wave64) own a
+//     contiguous range of envs and are wave-specialised:
+//       physics team (waves 10..14, one wave per env, no workgroup barrier): SoA state load, bicycle-model step
+//         (include/trsim_spec.h), binary64 L1 scan of the LDS-resident track with a wave64 DPP argmin
+//         (= reference LocationTracker.__find_closest, components/track_data_process.py:89-101), y / cte / done /
+//         reward, state store, one float4 of camera parameters per env into a small ring;
+//       raster team (waves 0..9): LDS holds the packed 2-bit surface-class map (LDS offset 0, odd row pitch), the
+//         per-row camera table and the per-row fogged palette; a thread owns a 4-pixel column group and walks rows:
+//         1 packed-fp32 fma per pixel, saturating convert + min (= floor + clamp), mad_u24 addressing, one LDS map
+//         read, bit-field extract, one LDS palette read; 4 pixels -> 12 bytes via v_perm, so one wave-instruction
+//         stores 768 contiguous bytes (6 full 128-B lines).  Bound: HBM writes (57,600 B per env-step at 120x160).
+//     Inside a multi-step call the raster team renders step t-1 while the physics team computes step t; the host
+//     opens the call with a physics-only launch and closes it with a raster-only launch (the lag never leaves the
+//     call).  A single-step call runs physics -> barrier -> raster in one launch.
+//   trs_physics_kernel  camera off (BASELINE config 2): lane-per-env integration (coalesced SoA), wave-sliced
+//     search, wave-ballot census of off-track envs, K steps per launch.
+//   trs_locate_kernel   batched LocationTracker for arbitrary binary64 query points.
 //
-//   trs_physics_kernel  (stream P)    state SoA -> new state + one float4 of camera parameters per env
-//     A workgroup (960 threads = 15 wave64) owns a contiguous range of envs; its LDS holds the raw track
-//     points (binary64 SoA) and tangents for the whole launch.
-//       phase 0  lane j of wave 0 integrates env j (bicycle model, include/trsim_spec.h), coalesced SoA loads
-//       phase A  the 15 waves are dealt to the chunk's envs; each scans an interleaved slice of the LDS track:
-//                binary64 L1 distance, per-lane strict '<', wave64 DPP argmin (lowest index wins ties)
-//                (= reference LocationTracker.__find_closest, components/track_data_process.py:89-101)
-//       phase A2 lane j of wave 0 folds env j's partials, computes y, cte, done, reward, stores the SoA state
-//                (coalesced) and the env's camera parameters; off-track envs are counted by wave ballot
-//
-//   (header text below describes the two halves of the fused kernel)
-//     LDS holds the packed 2-bit surface-class map (at LDS offset 0, odd row pitch), the per-row camera
-//     table and the per-row fogged palette.  A thread owns one 4-pixel column group and walks image rows:
-//     1 packed-fp32 fma per pixel for the ground point, saturating convert + min (= floor + clamp),
-//     mad_u24 addressing, one LDS map read, bit-field extract, one LDS palette read; 4 pixels -> 12 bytes
-//     via v_perm, so one wave-instruction stores 768 contiguous bytes (6 full 128-B lines).
-//     Bound: HBM writes of the image (57,600 B per env-step at 120x160) — see DESIGN.md.
-//
-//   The physics chain of step t+1 and the start of raster t+1 overlap the store drain of raster t
-//   (rasters alternate between two streams and two image buffers; a 4-deep ring of camera parameters
-//   decouples the two kernels).  Bulk synthetic stepping replays a captured hipGraph of 16 steps.
-//
+// Rejected on measurements: all-wave fused phases; two kernels on three streams + hipGraph.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (spec rule R1: no implicit FMA contraction).
 #include <hip/hip_runtime.h>
 
