@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic: per-phase s_memtime stamps of workgroup 7 (wave 0 and wave 1) for single-step launches.
+# Diagnostic: s_memtime stamps of workgroup 7 (wave 0 = raster team, wave 10 = first physics wave) in pipelined launches.
 set -e
 cd "$(dirname "$0")/.."
 C=triton-racer-sim_amd/csrc
@@ -9,18 +9,17 @@ import sys, numpy as np
 sys.path.insert(0, '.')
 from triton_racer_sim_amd.env import BatchedEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-render = (sys.argv[2] != '0') if len(sys.argv) > 2 else True
-env = BatchedEnv(n_envs=n, auto_reset=True, render=render)
+env = BatchedEnv(n_envs=n, auto_reset=True)
 env.step_synthetic(50, 1)
-names = ["entry", "prologue issued", "phase0 done", "barrier1 passed", "phaseA done", "barrier2 passed", "phaseA2(+map write) done", "barrier3 passed", "raster done", "barrier4 passed"]
+names = ["entry", "staging issued+written", "barrier passed", "physics done (phys wave)", "seq barrier (n/a)", "raster done"]
 acc = []
-for _ in range(20):
-    env.step_synthetic(1, 1)
+for _ in range(10):
+    env.step_synthetic(6, 1)          # pipelined: last full launch before the raster-only flush is what remains in the slots
     st = env.fetch("stats").astype(np.int64)
-    acc.append(np.stack([st[8:18], st[24:34]]))
+    acc.append(np.stack([st[8:14], st[32:38]]))
 a = np.median(np.array(acc), axis=0)
 base = a[0, 0]
-print(f"n_envs={n} render={render}  (cycles from wave 0 entry; ~2.4 cycles/ns)")
+print(f"n_envs={n} (ticks from wave 0 entry; NOTE the final launch of a call is raster-only, so physics slots are from the launch before)")
 for i, nm in enumerate(names):
-    print(f"  {nm:28s} wave0 {a[0,i]-base:9.0f}   wave1 {a[1,i]-base:9.0f}")
+    print(f"  {nm:28s} raster wave0 {a[0,i]-base:9.0f}   physics wave10 {a[1,i]-base:9.0f}")
 PY

@@ -175,6 +175,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));   // 16-B register tuple (HIP's uint4 struct defeats SROA here)
 typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+
+#ifndef TRS_STORE_AUX
+#define TRS_STORE_AUX 17   /* cache policy of the image stores: 0 plain, 2 nt, 16 sc1, 17 sc0 sc1 (write-through: the frame streams to HBM while the kernel computes instead of being flushed from L2 at kernel end; +13% at 1024 envs, profiles/r01_store_policy_ab.txt) */
+#endif
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void trs_physics_kernel(const PParams p)
@@ -558,7 +563,10 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     for (int e = e_begin; e < e_end; ++e) {
         const float4 cam = p.cam[e];      // written by the previous launch (seq = 0) or by this workgroup's physics team (seq = 1)
         const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-        unsigned char* const out = p.img + (size_t)e * ((size_t)p.gpe * 12) + (size_t)cg * 12;
+        // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+        const int col_off = cg * 12;
         f2v rt = lrow[vstart < p.H ? vstart : 0];
         for (int v = vstart; v < p.H; v += p.rows_per_pass) {
             const int vn = v + p.rows_per_pass;
@@ -588,11 +596,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
             const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
             const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
-            uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)v * row_bytes);
 #if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
-            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)o;
+            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)rsrc; (void)col_off;
 #else
-            o[0] = w0; o[1] = w1; o[2] = w2;
+            const u3v px3 = {w0, w1, w2};
+            __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
 #endif
             rt = rtn;
         }
