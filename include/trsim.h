@@ -146,6 +146,41 @@ int trs_locate(trs_env* env, const double* h_xyz, int n_queries, int32_t* h_idx_
 
 int trs_map_info_get(trs_env* env, trs_map_info* out);
 
+/* ---- image path: ImgPreprocessing (components/img_preprocessing.py:37-102) + pilot normalisation ---- */
+
+/* The `preprocessing_*` keys of core/config.py:15-28. */
+typedef struct trs_pre_config {
+    uint32_t struct_size;
+    int32_t  dynamic_brightness;     /* preprocessing_dynamic_brightness_enabled (config.py:20) */
+    double   brightness_baseline;    /* preprocessing_brightness_baseline, 550 (config.py:21) */
+    float    contrast_ratio;         /* preprocessing_contrast_enhancement_ratio, 1.0 (config.py:18) */
+    float    contrast_offset;        /* preprocessing_contrast_enhancement_offset, 125 (config.py:19) */
+    int32_t  color_filter_enabled;   /* preprocessing_color_filter_enabled (config.py:22) */
+    int32_t  n_filters;              /* <= 4 */
+    uint8_t  hsv_lo[4][3], hsv_hi[4][3];   /* preprocessing_color_filter_hsvs (config.py:23), OpenCV 8-bit HSV, H in [0,180) */
+    int32_t  dst_channel[4];         /* preprocessing_color_filter_destination_channels (config.py:24) */
+    int32_t  edge_detection_enabled; /* Canny (img_preprocessing.py:76-79): NOT implemented yet -> TRS_ERR_ARG when set */
+    int32_t  reserved;
+} trs_pre_config;
+
+void trs_default_pre_config(trs_pre_config* cfg);
+
+/* ImgPreprocessing.__process without the Canny layer (img_preprocessing.py:37-54,57-74,81-102) for n_images frames
+ * of the env's image size: brightness/contrast trim in binary32 exactly as numpy evaluates it (mean over rows
+ * 40..118, :88-99), then the HSV in-range masks written over their destination channels.
+ * d_src NULL = the env's latest frame (n_images must then be n_envs); d_dst NULL = the env's own processed-image
+ * buffer (returned through *d_out).  Device pointers; asynchronous on the handle's stream. */
+int trs_preprocess(trs_env* env, const trs_pre_config* cfg, const uint8_t* d_src, uint8_t* d_dst, int n_images,
+                   const uint8_t** d_out);
+
+/* Same for host frames (the N = 1 Component path): upload, process, download, synchronous. */
+int trs_preprocess_host(trs_env* env, const trs_pre_config* cfg, const uint8_t* h_src, uint8_t* h_dst, int n_images);
+
+/* Pilot-side normalisation (components/keras_pilot.py:49-55, keras_train.py:41-42): float32(img) / 255.
+ * d_src NULL = latest frame; d_dst = float[n_images][H][W][3] device buffer. */
+int trs_normalize(trs_env* env, const uint8_t* d_src, float* d_dst, int n_images);
+int trs_normalize_host(trs_env* env, const uint8_t* h_src, float* h_dst, int n_images);
+
 /* stream control + device-side timing (HIP events on the handle's stream) */
 int trs_sync(trs_env* env);
 int trs_event_record(trs_env* env, int slot);                 /* slot 0..7 */

@@ -55,6 +55,7 @@ struct trs_env {
     int32_t *seg_idx, *ep_len;
     uint8_t *done, *pending, *was_reset;
     uint8_t* img;
+    uint8_t* pre;              /* processed-image buffer (trso_preprocess with dst == NULL) */
     uint64_t step_count;
     uint64_t stats[64];        /* [0] off-track events, [1] resets */
 };
@@ -384,7 +385,7 @@ EXPORT int trso_destroy(trs_env* e)
     if (!e) return TRS_OK;
     free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
-    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img);
+    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre);
     free(e);
     return TRS_OK;
 }
@@ -531,6 +532,135 @@ EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return
 EXPORT int trso_event_elapsed_ms(trs_env* e, int a, int b, float* ms) { (void)e; (void)a; (void)b; if (ms) *ms = 0.0f; return TRS_OK; }
 EXPORT int trso_device_count(int* out) { if (out) *out = 0; return TRS_OK; }
 EXPORT const char* trso_last_error(void) { return g_err; }
+
+
+/* ------------------------------------------------------------------ image path (rows a10, a11 colour masks, a13)
+ * Restates ImgPreprocessing.__trim_brightness_contrast / __color_filter / __merge
+ * (/root/reference/TritonRacerSim/components/img_preprocessing.py:57-74,81-102).  The numpy part (:92-99) is
+ * restated operation by operation in binary32 and is PINNED by tests/test_image_path.py against numpy itself;
+ * cv2.mean (:88) is restated as exact integer sums divided in binary64; cv2.cvtColor(RGB2HSV) + cv2.inRange
+ * (:66,:71) follow OpenCV's published 8-bit algorithm (fixed-point tables, H in [0,180)) — cv2 is not
+ * installed here, so that part is PARITY UNPINNED. */
+
+static int g_sdiv[256], g_hdiv[256], g_tables_ready;
+
+static void hsv_tables(void)
+{
+    if (g_tables_ready) return;
+    g_sdiv[0] = g_hdiv[0] = 0;
+    for (int i = 1; i < 256; ++i) {
+        g_sdiv[i] = (int)lrint((255 << 12) / (1.0 * i));
+        g_hdiv[i] = (int)lrint((180 << 12) / (6.0 * i));
+    }
+    g_tables_ready = 1;
+}
+
+static void rgb2hsv_u8(int r, int g, int b, int* ho, int* so, int* vo)
+{
+    int v = r > g ? r : g; if (b > v) v = b;
+    int vmin = r < g ? r : g; if (b < vmin) vmin = b;
+    int diff = v - vmin;
+    int vr = (v == r) ? -1 : 0, vg = (v == g) ? -1 : 0;
+    int sat = (diff * g_sdiv[v] + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * g_hdiv[diff] + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    *ho = h > 255 ? 255 : h; *so = sat > 255 ? 255 : sat; *vo = v;
+}
+
+static void preprocess_image(const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int H, int W)
+{
+    int r0 = 40 < H ? 40 : H, r1 = 119 < H ? 119 : H;
+    uint64_t sum[3] = {0, 0, 0};
+    for (int y = r0; y < r1; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int ch = 0; ch < 3; ++ch) sum[ch] += src[((size_t)y * W + x) * 3 + ch];
+    double cnt = (double)(r1 - r0) * (double)W;
+    double cur = 0.0;
+    for (int ch = 0; ch < 3; ++ch) cur = cur + (cnt > 0 ? (double)sum[ch] / cnt : 0.0);
+    cur = cur + 0.0;                                        /* cv2.mean returns a 4-tuple; the 4th entry is 0 */
+    double delta = (c->brightness_baseline - cur) / 3;
+    float deltaf = (float)delta, off = c->contrast_offset, con = c->contrast_ratio;
+    for (size_t i = 0; i < (size_t)H * W; ++i) {
+        int t[3];
+        for (int ch = 0; ch < 3; ++ch) {
+            float x = (float)src[3 * i + ch];
+            if (c->dynamic_brightness) x = x + deltaf;
+            x = x - off;
+            x = x * con;
+            x = x + off;
+            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+            t[ch] = (int)x;                                 /* astype(uint8): truncation */
+        }
+        int o[3] = {t[0], t[1], t[2]};
+        if (c->color_filter_enabled) {
+            int h, sa, v;
+            rgb2hsv_u8(t[0], t[1], t[2], &h, &sa, &v);
+            for (int f = 0; f < c->n_filters; ++f) {
+                int in = h >= c->hsv_lo[f][0] && h <= c->hsv_hi[f][0] && sa >= c->hsv_lo[f][1] && sa <= c->hsv_hi[f][1] &&
+                         v >= c->hsv_lo[f][2] && v <= c->hsv_hi[f][2];
+                o[c->dst_channel[f]] = in ? 255 : 0;
+            }
+        }
+        dst[3 * i] = (uint8_t)o[0]; dst[3 * i + 1] = (uint8_t)o[1]; dst[3 * i + 2] = (uint8_t)o[2];
+    }
+}
+
+static int check_pre(const trs_pre_config* c)
+{
+    if (!c || c->struct_size != sizeof(trs_pre_config)) return fail(TRS_ERR_ARG, "trs_pre_config.struct_size mismatch");
+    if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "Canny edge detection is not implemented");
+    if (c->n_filters < 0 || c->n_filters > 4) return fail(TRS_ERR_ARG, "n_filters out of range");
+    for (int f = 0; f < c->n_filters; ++f) if (c->dst_channel[f] < 0 || c->dst_channel[f] > 2) return fail(TRS_ERR_ARG, "dst_channel out of range");
+    return TRS_OK;
+}
+
+EXPORT void trso_default_pre_config(trs_pre_config* c)
+{
+    memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->brightness_baseline = 550.0; c->contrast_ratio = 1.0f; c->contrast_offset = 125.0f;
+    c->n_filters = 2;                                       /* core/config.py:23-24: white and yellow */
+    const uint8_t lo[2][3] = {{0, 0, 130}, {25, 180, 155}}, hi[2][3] = {{180, 64, 255}, {43, 255, 255}};
+    memcpy(c->hsv_lo, lo, sizeof lo); memcpy(c->hsv_hi, hi, sizeof hi);
+    c->dst_channel[0] = 0; c->dst_channel[1] = 1;
+}
+
+EXPORT int trso_preprocess_host(trs_env* e, const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int n)
+{
+    if (!e || !src || !dst || n < 0) return fail(TRS_ERR_ARG, "bad argument");
+    int rc = check_pre(c);
+    if (rc) return rc;
+    hsv_tables();
+    size_t stride = (size_t)e->H * e->W * 3;
+#pragma omp parallel for schedule(static) num_threads(e->threads)
+    for (int i = 0; i < n; ++i) preprocess_image(c, src + i * stride, dst + i * stride, e->H, e->W);
+    return TRS_OK;
+}
+
+EXPORT int trso_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int n, const uint8_t** out)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    if (!src) { if (!e->img || n != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera"); src = e->img; }
+    if (!dst) { if (!e->pre) e->pre = malloc((size_t)e->n * e->H * e->W * 3); if (n > e->n) return fail(TRS_ERR_ARG, "own buffer holds n_envs frames"); dst = e->pre; }
+    if (out) *out = dst;
+    return trso_preprocess_host(e, c, src, dst, n);
+}
+
+EXPORT int trso_normalize_host(trs_env* e, const uint8_t* src, float* dst, int n)
+{
+    if (!e || !src || !dst || n < 0) return fail(TRS_ERR_ARG, "bad argument");
+    size_t total = (size_t)n * e->H * e->W * 3;
+    for (size_t i = 0; i < total; ++i) dst[i] = (float)src[i] / 255.0f;     /* keras_pilot.py:49-50 */
+    return TRS_OK;
+}
+
+EXPORT int trso_normalize(trs_env* e, const uint8_t* src, float* dst, int n)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    if (!src) { if (!e->img || n != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera"); src = e->img; }
+    return trso_normalize_host(e, src, dst, n);
+}
 
 /* oracle-only: number of OpenMP threads used by step / locate (cpu_baseline "cores") */
 EXPORT int trso_set_threads(trs_env* e, int n)

@@ -1,0 +1,149 @@
+"""Image path.  The numpy lines of the reference's filter are restated here WITH NUMPY
+ITSELF (img_preprocessing.py:88-99 and keras_pilot.py:49-50 are numpy one-liners), which pins the oracle's
+binary32 arithmetic; the OpenCV parts (cv2.mean as exact integer mean, 8-bit RGB->HSV, inRange) are
+cross-checked against an independent float HSV.  GPU tests compare the HIP kernels with the oracle, bit for bit."""
+import colorsys
+
+import numpy as np
+import pytest
+
+from triton_racer_sim_amd.components import HipImgPreprocessing
+
+CFGS = [
+    {},                                                                                     # reference defaults: identity trim
+    {"preprocessing_dynamic_brightness_enabled": True, "preprocessing_brightness_baseline": 550},
+    {"preprocessing_contrast_enhancement_ratio": 1.37, "preprocessing_contrast_enhancement_offset": 125},
+    {"preprocessing_dynamic_brightness_enabled": True, "preprocessing_brightness_baseline": 300,
+     "preprocessing_contrast_enhancement_ratio": 0.6, "preprocessing_contrast_enhancement_offset": 90},
+]
+
+
+def frames(n=5, seed=0, h=120, w=160):
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    if n < 3:
+        return out
+    out[0] = 0
+    out[1] = 255
+    yy, xx = np.mgrid[0:h, 0:w]
+    out[2] = np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx + yy) % 256)], -1).astype(np.uint8)
+    return out
+
+
+def numpy_trim(img, cfg):
+    """img_preprocessing.py:84-99 with numpy; cv2.mean(img[40:119]) = per-channel mean in binary64 (+ a 0.0 4th entry)."""
+    contrast = cfg.get("preprocessing_contrast_enhancement_ratio", 1.0)
+    offset = cfg.get("preprocessing_contrast_enhancement_offset", 125)
+    baseline = cfg.get("preprocessing_brightness_baseline", 550)
+    roi = img[40:119, :, :]
+    mean = [float(roi[:, :, c].astype(np.uint64).sum()) / float(roi.shape[0] * roi.shape[1]) for c in range(3)] + [0.0]
+    current_brightness = sum(list(mean))
+    delta = (baseline - current_brightness) / 3
+    img_arr = img.astype(np.float32)
+    if cfg.get("preprocessing_dynamic_brightness_enabled", False):
+        img_arr += delta
+    img_arr -= offset
+    img_arr *= contrast
+    img_arr += offset
+    img_arr = np.clip(img_arr, 0, 255)
+    return img_arr.astype(np.uint8)
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_oracle_trim_equals_numpy(make_env, cfg):
+    env = make_env("oracle", n_envs=1, track=None, render=False)
+    src = frames()
+    got = env.preprocess_host(src, cfg)
+    for i in range(len(src)):
+        assert np.array_equal(got[i], numpy_trim(src[i], cfg)), (cfg, i)
+
+
+def test_oracle_normalize_equals_numpy(make_env):
+    env = make_env("oracle", n_envs=1, track=None, render=False)
+    src = frames(3, seed=2)
+    want = np.asarray(src, dtype=np.float32)
+    want /= 255                                                           # keras_pilot.py:49-50
+    assert np.array_equal(env.normalize_host(src), want)
+
+
+def test_oracle_colour_masks_against_float_hsv(make_env):
+    """OpenCV's 8-bit HSV is a fixed-point approximation of (H/2, S*255, V*255); away from the range bounds the
+    in-range decision must agree with a float HSV (colorsys).  Default filters: white -> R, yellow -> G."""
+    env = make_env("oracle", n_envs=1, track=None, render=False)
+    cfg = {"preprocessing_color_filter_enabled": True}
+    src = frames(4, seed=5)
+    got = env.preprocess_host(src, cfg)
+    bounds = [((0, 0, 130), (180, 64, 255)), ((25, 180, 155), (43, 255, 255))]
+    rng = np.random.default_rng(1)
+    checked = 0
+    for _ in range(6000):
+        i, y, x = rng.integers(0, 4), rng.integers(0, 120), rng.integers(0, 160)
+        r, g, b = (int(c) for c in src[i, y, x])
+        h, s, v = colorsys.rgb_to_hsv(r / 255, g / 255, b / 255)
+        hsv = (h * 180, s * 255, v * 255)
+        for f, (lo, hi) in enumerate(bounds):
+            margin = min(min(abs(hsv[k] - lo[k]), abs(hsv[k] - hi[k])) for k in range(3))
+            if margin < 1.5:
+                continue                                                  # too close to a bound for a float check
+            inside = all(lo[k] <= hsv[k] <= hi[k] for k in range(3))
+            assert got[i, y, x, f] == (255 if inside else 0), (r, g, b, hsv, f)
+            checked += 1
+        assert got[i, y, x, 2] == src[i, y, x, 2]                         # blue channel untouched (identity trim)
+    assert checked > 5000
+    assert set(np.unique(got[..., :2])) <= {0, 255}
+
+
+def test_oracle_rejects_canny_and_bad_channels(make_env):
+    env = make_env("oracle", n_envs=1, track=None, render=False)
+    with pytest.raises(RuntimeError, match="Canny"):
+        env.preprocess_host(frames(1), {"preprocessing_edge_detection_enabled": True})
+    with pytest.raises(RuntimeError, match="dst_channel"):
+        env.preprocess_host(frames(1), {"preprocessing_color_filter_enabled": True, "preprocessing_color_filter_hsvs": [((0, 0, 0), (180, 255, 255))],
+                                        "preprocessing_color_filter_destination_channels": [3]})
+
+
+def test_component_handoff_semantics(oracle_api):
+    """step() returns the frame processed from the PREVIOUS deposit; None first (img_preprocessing.py:18-21)."""
+    part = HipImgPreprocessing({"preprocessing_contrast_enhancement_ratio": 1.2}, _api=oracle_api)
+    assert part.step_inputs == ["cam/img"] and part.step_outputs == ["cam/processed_img"] and part.getName() == "Image Preprocessing"
+    a, b = frames(2, seed=9)
+    assert part.step(None) == (None,)
+    assert part.step(a) == (None,)
+    out = part.step(b)[0]
+    assert np.array_equal(out, numpy_trim(a, part.cfg))
+    assert np.array_equal(part.step(None)[0], numpy_trim(b, part.cfg))   # no new frame: the last result stays
+    part.onShutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(120, 160), (240, 320), (64, 64)])
+def test_gpu_preprocess_and_normalize_equal_oracle(make_env, size):
+    h, w = size
+    g = make_env("hip", n_envs=1, track=None, render=False, img_h=h, img_w=w)
+    o = make_env("oracle", n_envs=1, track=None, render=False, img_h=h, img_w=w)
+    src = frames(7, seed=3, h=h, w=w)
+    for cfg in CFGS + [{"preprocessing_color_filter_enabled": True},
+                       {"preprocessing_color_filter_enabled": True, "preprocessing_dynamic_brightness_enabled": True,
+                        "preprocessing_color_filter_hsvs": [((0, 0, 100), (90, 255, 255)), ((90, 30, 0), (180, 255, 200)), ((10, 10, 10), (170, 200, 240))],
+                        "preprocessing_color_filter_destination_channels": [2, 0, 2]}]:
+        assert np.array_equal(g.preprocess_host(src, cfg), o.preprocess_host(src, cfg)), (size, cfg)
+    assert np.array_equal(g.normalize_host(src), o.normalize_host(src))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_latest_frames_on_device(make_env):
+    """Batched path: the env's own frames are filtered without leaving the device."""
+    import ctypes
+    g = make_env("hip", n_envs=48, auto_reset=True)
+    o = make_env("oracle", n_envs=48, auto_reset=True)
+    for env in (g, o):
+        env.step_synthetic(20, 1)
+    cfg = {"preprocessing_color_filter_enabled": True, "preprocessing_dynamic_brightness_enabled": True}
+    want = o.preprocess_host(o.fetch("img"), cfg)
+    handle = g.preprocess_latest(cfg)
+    got = g.preprocess_host(g.fetch("img"), cfg)                          # same frames through the host path
+    assert np.array_equal(got, want)
+    torch = pytest.importorskip("torch")
+    g.sync()
+    dev = torch.as_tensor(handle, device="cuda").cpu().numpy()
+    assert np.array_equal(dev, want)

@@ -48,6 +48,16 @@ class TrsMapInfo(C.Structure):
     ]
 
 
+class TrsPreConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dynamic_brightness", C.c_int32), ("brightness_baseline", C.c_double),
+        ("contrast_ratio", C.c_float), ("contrast_offset", C.c_float),
+        ("color_filter_enabled", C.c_int32), ("n_filters", C.c_int32),
+        ("hsv_lo", (C.c_uint8 * 3) * 4), ("hsv_hi", (C.c_uint8 * 3) * 4), ("dst_channel", C.c_int32 * 4),
+        ("edge_detection_enabled", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 # selectors of trs_copy_to_host: name -> (enum value, numpy dtype string, per-env? shape tag)
 FIELDS = {
     "img": 0, "pos_x": 1, "pos_y": 2, "pos_z": 3, "speed": 4, "cte": 5, "yaw": 6, "vel": 7,
@@ -60,6 +70,7 @@ SYMBOLS = [
     "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic",
     "get_state", "copy_to_host", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
+    "default_pre_config", "preprocess", "preprocess_host", "normalize", "normalize_host",
 ]
 
 
@@ -88,6 +99,11 @@ class Api:
             "event_elapsed_ms": (i32, [vp, i32, i32, C.POINTER(C.c_float)]),
             "device_count": (i32, [C.POINTER(i32)]),
             "last_error": (C.c_char_p, []),
+            "default_pre_config": (None, [C.POINTER(TrsPreConfig)]),
+            "preprocess": (i32, [vp, C.POINTER(TrsPreConfig), vp, vp, i32, C.POINTER(vp)]),
+            "preprocess_host": (i32, [vp, C.POINTER(TrsPreConfig), vp, vp, i32]),
+            "normalize": (i32, [vp, vp, vp, i32]),
+            "normalize_host": (i32, [vp, vp, vp, i32]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(cdll, prefix + name)
@@ -100,8 +116,32 @@ class Api:
             raise RuntimeError(f"{self.prefix}{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own ``libamdhip64``; two HIP runtimes in one process do not both see the GPU
+    (``RuntimeError: No HIP GPUs are available`` in whichever loads second).  When torch is installed but not
+    imported yet, bind ITS runtime first so that ``libtrsim.so`` and a later ``import torch`` share it; with torch
+    already imported (or absent) the loader does the right thing by itself."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    lib = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(lib):
+        try:
+            C.CDLL(lib, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_hip_library(path=None):
     """Open ``csrc/libtrsim.so`` (built by ``__graft_entry__.build()``); no fallback of any kind."""
+    _share_torch_hip_runtime()
     path = path or os.environ.get("TRS_HIP_LIB") or HIP_LIB_PATH      # TRS_HIP_LIB: A/B another HIP build of the same ABI
     if not os.path.exists(path):
         raise RuntimeError(

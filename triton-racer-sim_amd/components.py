@@ -135,3 +135,34 @@ class LocationTracker(Component):
 
     def getName(self):
         return "Location Tracker"
+
+
+class HipImgPreprocessing(Component):
+    """``cam/img -> cam/processed_img`` with the reference's hand-off semantics
+    (``components/img_preprocessing.py:18-35``): ``step`` deposits the new frame and returns the frame processed
+    from the PREVIOUS deposit (the reference's filter thread is one tick behind the loop; ``None`` until the
+    first result exists).  The filter itself (trim, HSV masks, merge; ``:37-74,81-102``) runs on the GPU.
+    Canny (``:76-79``) is not implemented: enabling it raises."""
+
+    def __init__(self, cfg=None, device=0, _api=None):
+        Component.__init__(self, inputs=["cam/img"], outputs=["cam/processed_img"], threaded=False)
+        self.cfg = dict(cfg or {})
+        self.env = BatchedEnv(n_envs=1, track=None, device=device, render=False, img_h=int(self.cfg.get("img_h", 120)),
+                              img_w=int(self.cfg.get("img_w", 160)), _api=_api)
+        self.pre = self.env.pre_config(self.cfg)
+        self.processed_img = None
+        self.running = True
+
+    def step(self, *args):
+        img_arr = args[0]
+        previous = self.processed_img
+        if img_arr is not None:
+            self.processed_img = self.env.preprocess_host(np.asarray(img_arr)[None], self.pre)[0]
+        return previous,
+
+    def onShutdown(self):
+        self.running = False
+        self.env.close()
+
+    def getName(self):
+        return "Image Preprocessing"

@@ -609,6 +609,120 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 }
 
 #undef STAMP_STATS
+// ---------------------------------------------------------------------------------------------
+// Image path (SURVEY rows a10, a11 colour masks, a13): ImgPreprocessing.__process without the Canny layer
+// (components/img_preprocessing.py:37-74,81-102) and the pilot's float32/255 normalisation
+// (components/keras_pilot.py:49-55).  One 256-thread workgroup per frame; a lane handles 4 pixels (12 B).
+//   pass 1: exact integer channel sums over rows 40..118 (cv2.mean, :88), wave reduce -> LDS -> delta (binary64)
+//   pass 2: binary32 trim in numpy's operation order (:92-99), OpenCV 8-bit RGB->HSV + inRange masks (:65-74),
+//           masks written over their destination channels (:57-63); the second read of the frame hits L2
+// Bound: HBM, 2 x H*W*3 bytes per frame (one read, one write).
+struct PreParams {
+    const uint8_t* src; uint8_t* dst;
+    const int* hsv_tab;                 // [512]: sdiv[256] | hdiv[256] (OpenCV fixed-point reciprocal tables)
+    int n_img, H, W, gpr, gpe, r0, r1;  // 4-pixel groups per row / per frame; brightness rows [r0, r1)
+    int dynamic, color, n_filters;
+    float contrast, offset;
+    double baseline;
+    unsigned lo[4], hi[4];              // packed h | s<<8 | v<<16
+    int dst_ch[4];
+};
+
+__device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
+
+__global__ __launch_bounds__(256) void trs_preprocess_kernel(const PreParams p)
+{
+    __shared__ int s_tab[512];
+    __shared__ unsigned s_part[4][3];
+    __shared__ float s_delta;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t frame_bytes = (size_t)p.gpe * 12;
+    for (int i = tid; i < 512; i += 256) s_tab[i] = p.hsv_tab[i];
+    for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        // ---- pass 1: channel sums over the brightness rows ----
+        unsigned sr = 0, sg = 0, sb = 0;
+        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += 256) {
+            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+            // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3
+            sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
+            sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
+            sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+        if (lane == 0) { s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            const double cnt = (double)(p.r1 - p.r0) * (double)p.W;
+            double cur = 0.0;
+            for (int ch = 0; ch < 3; ++ch) {
+                const unsigned long long tot = (unsigned long long)s_part[0][ch] + s_part[1][ch] + s_part[2][ch] + s_part[3][ch];
+                cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
+            }
+            cur = cur + 0.0;
+            s_delta = (float)((p.baseline - cur) / 3);
+        }
+        __syncthreads();
+        const float deltaf = s_delta, off = p.offset, con = p.contrast;
+        // ---- pass 2: trim, masks, merge ----
+        for (int g = tid; g < p.gpe; g += 256) {
+            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+            unsigned by[12];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { by[k] = (w.x >> (8 * k)) & 255u; by[4 + k] = (w.y >> (8 * k)) & 255u; by[8 + k] = (w.z >> (8 * k)) & 255u; }
+            unsigned ob[12];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                int t[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float x = (float)by[3 * px + ch];
+                    if (p.dynamic) x = x + deltaf;
+                    x = x - off;
+                    x = x * con;
+                    x = x + off;
+                    x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+                    t[ch] = (int)x;
+                }
+                int o0 = t[0], o1 = t[1], o2 = t[2];
+                if (p.color) {
+                    const int r = t[0], gg = t[1], b = t[2];
+                    const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
+                    const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
+                    const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
+                    int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
+                    h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
+                    if (h < 0) h += 180;
+                    const int hh = min(h, 255), ss = min(sat, 255);
+                    for (int f = 0; f < p.n_filters; ++f) {
+                        const int lh = p.lo[f] & 255, ls = (p.lo[f] >> 8) & 255, lv = (p.lo[f] >> 16) & 255;
+                        const int uh = p.hi[f] & 255, us = (p.hi[f] >> 8) & 255, uv = (p.hi[f] >> 16) & 255;
+                        const int m = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
+                        const int dc = p.dst_ch[f];
+                        o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
+                    }
+                }
+                ob[3 * px] = (unsigned)o0; ob[3 * px + 1] = (unsigned)o1; ob[3 * px + 2] = (unsigned)o2;
+            }
+            const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
+                             ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
+            __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
+        }
+        __syncthreads();   // s_part / s_delta are reused by the next frame of this workgroup
+    }
+}
+
+// float32(img) / 255 (keras_pilot.py:49-50): 4 bytes in, one 16-B store out per lane
+__global__ __launch_bounds__(256) void trs_normalize_kernel(const uint32_t* src, float4* dst, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint32_t w = src[i];
+        dst[i] = make_float4((float)(w & 255u) / 255.0f, (float)((w >> 8) & 255u) / 255.0f, (float)((w >> 16) & 255u) / 255.0f, (float)(w >> 24) / 255.0f);
+    }
+}
+
 // Batched LocationTracker.__find_closest (components/track_data_process.py:89-101): one wave per query,
 // track staged in LDS once per workgroup, queries grid-strided.
 __global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int pts_bytes, int off_py, int off_pz, int np,
@@ -671,6 +785,9 @@ struct trs_env {
     uint32_t* d_step = nullptr;
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
+    uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
+    uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
+    int* hsv_tab = nullptr;
     PParams pp{};
     RParams rp{};
     trsim::TrackTables tab;
@@ -848,6 +965,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->d_step);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
+    (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->sP) (void)hipStreamDestroy(e->sP);
     delete e;
@@ -1092,6 +1210,150 @@ TRS_EXPORT int trs_locate(trs_env* e, const double* h_xyz, int nq, int32_t* h_id
                        (const double*)e->loc_q, nq, e->loc_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_idx, e->loc_out, (size_t)nq * 4, hipMemcpyDeviceToHost, e->sP));
+    HIPCHK(hipStreamSynchronize(e->sP));
+    return TRS_OK;
+}
+
+
+// ---- image path -----------------------------------------------------------------------------------------
+
+namespace {
+
+int check_pre(const trs_pre_config* c)
+{
+    if (!c || c->struct_size != sizeof(trs_pre_config)) return fail(TRS_ERR_ARG, "trs_pre_config.struct_size mismatch");
+    if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "Canny edge detection is not implemented");
+    if (c->n_filters < 0 || c->n_filters > 4) return fail(TRS_ERR_ARG, "n_filters out of range");
+    for (int f = 0; f < c->n_filters; ++f)
+        if (c->dst_channel[f] < 0 || c->dst_channel[f] > 2) return fail(TRS_ERR_ARG, "dst_channel out of range");
+    return TRS_OK;
+}
+
+int ensure_hsv_table(trs_env* e)
+{
+    if (e->hsv_tab) return TRS_OK;
+    int tab[512];
+    tab[0] = tab[256] = 0;
+    for (int i = 1; i < 256; ++i) {          // OpenCV's sdiv_table / hdiv_table180, hsv_shift = 12
+        tab[i] = (int)std::lrint((255 << 12) / (1.0 * i));
+        tab[256 + i] = (int)std::lrint((180 << 12) / (6.0 * i));
+    }
+    HIPCHK(hipMalloc((void**)&e->hsv_tab, sizeof tab));
+    HIPCHK(hipMemcpy(e->hsv_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+    return TRS_OK;
+}
+
+int ensure_tmp(trs_env* e, size_t frames)
+{
+    if (frames <= e->tmp_cap) return TRS_OK;
+    HIPCHK(hipStreamSynchronize(e->sP));
+    (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f);
+    e->tmp_in = e->tmp_out = nullptr; e->tmp_f = nullptr; e->tmp_cap = 0;
+    const size_t fb = (size_t)e->H * e->W * 3;
+    HIPCHK(hipMalloc((void**)&e->tmp_in, frames * fb));
+    HIPCHK(hipMalloc((void**)&e->tmp_out, frames * fb));
+    HIPCHK(hipMalloc((void**)&e->tmp_f, frames * fb * sizeof(float)));
+    e->tmp_cap = frames;
+    return TRS_OK;
+}
+
+const uint8_t* latest_frame(const trs_env* e) { return e->cfg.render ? e->img[(e->step_count + 1) & 1] : nullptr; }
+
+}  // namespace
+
+TRS_EXPORT void trs_default_pre_config(trs_pre_config* c)
+{
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->brightness_baseline = 550.0; c->contrast_ratio = 1.0f; c->contrast_offset = 125.0f;
+    c->n_filters = 2;                                       // core/config.py:23-24: white and yellow
+    const uint8_t lo[2][3] = {{0, 0, 130}, {25, 180, 155}}, hi[2][3] = {{180, 64, 255}, {43, 255, 255}};
+    std::memcpy(c->hsv_lo, lo, sizeof lo); std::memcpy(c->hsv_hi, hi, sizeof hi);
+    c->dst_channel[0] = 0; c->dst_channel[1] = 1;
+}
+
+TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t* d_src, uint8_t* d_dst, int n_images, const uint8_t** d_out)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    int rc = check_pre(c);
+    if (rc) return rc;
+    if (n_images < 0) return fail(TRS_ERR_ARG, "n_images < 0");
+    HIPCHK(hipSetDevice(e->device));
+    if (!d_src) {
+        if (!latest_frame(e) || n_images != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera");
+        d_src = latest_frame(e);
+    }
+    if (!d_dst) {
+        if (n_images > e->n) return fail(TRS_ERR_ARG, "own buffer holds n_envs frames");
+        if (!e->pre) HIPCHK(hipMalloc((void**)&e->pre, (size_t)e->n * e->H * e->W * 3));
+        d_dst = e->pre;
+    }
+    if (d_out) *d_out = d_dst;
+    if (n_images == 0) return TRS_OK;
+    rc = ensure_hsv_table(e);
+    if (rc) return rc;
+    PreParams p{};
+    p.src = d_src; p.dst = d_dst; p.hsv_tab = e->hsv_tab;
+    p.n_img = n_images; p.H = e->H; p.W = e->W; p.gpr = e->W / 4; p.gpe = p.gpr * e->H;
+    p.r0 = std::min(40, e->H); p.r1 = std::min(119, e->H);                 // img[40:119] (img_preprocessing.py:88)
+    p.dynamic = c->dynamic_brightness; p.color = c->color_filter_enabled; p.n_filters = c->n_filters;
+    p.contrast = c->contrast_ratio; p.offset = c->contrast_offset; p.baseline = c->brightness_baseline;
+    for (int f = 0; f < 4; ++f) {
+        p.lo[f] = c->hsv_lo[f][0] | (c->hsv_lo[f][1] << 8) | (c->hsv_lo[f][2] << 16);
+        p.hi[f] = c->hsv_hi[f][0] | (c->hsv_hi[f][1] << 8) | (c->hsv_hi[f][2] << 16);
+        p.dst_ch[f] = c->dst_channel[f];
+    }
+    const int grid = std::min(n_images, e->cu_count * 8);
+    hipLaunchKernelGGL(trs_preprocess_kernel, dim3(grid), dim3(256), 0, e->sP, p);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_preprocess_host(trs_env* e, const trs_pre_config* c, const uint8_t* h_src, uint8_t* h_dst, int n_images)
+{
+    if (!e || !h_src || !h_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (n_images == 0) return TRS_OK;
+    int rc = ensure_tmp(e, (size_t)n_images);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n_images * e->H * e->W * 3;
+    HIPCHK(hipMemcpyAsync(e->tmp_in, h_src, bytes, hipMemcpyHostToDevice, e->sP));
+    rc = trs_preprocess(e, c, e->tmp_in, e->tmp_out, n_images, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_dst, e->tmp_out, bytes, hipMemcpyDeviceToHost, e->sP));
+    HIPCHK(hipStreamSynchronize(e->sP));
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_normalize(trs_env* e, const uint8_t* d_src, float* d_dst, int n_images)
+{
+    if (!e || !d_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (!d_src) {
+        if (!latest_frame(e) || n_images != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera");
+        d_src = latest_frame(e);
+    }
+    const size_t n4 = (size_t)n_images * e->H * e->W * 3 / 4;            // W % 4 == 0 -> whole dwords
+    if (n4 == 0) return TRS_OK;
+    const int grid = (int)std::min<size_t>((n4 + 255) / 256, (size_t)e->cu_count * 16);
+    hipLaunchKernelGGL(trs_normalize_kernel, dim3(grid), dim3(256), 0, e->sP, reinterpret_cast<const uint32_t*>(d_src), reinterpret_cast<float4*>(d_dst), n4);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_normalize_host(trs_env* e, const uint8_t* h_src, float* h_dst, int n_images)
+{
+    if (!e || !h_src || !h_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (n_images == 0) return TRS_OK;
+    int rc = ensure_tmp(e, (size_t)n_images);
+    if (rc) return rc;
+    const size_t bytes = (size_t)n_images * e->H * e->W * 3;
+    HIPCHK(hipMemcpyAsync(e->tmp_in, h_src, bytes, hipMemcpyHostToDevice, e->sP));
+    rc = trs_normalize(e, e->tmp_in, e->tmp_f, n_images);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_dst, e->tmp_f, bytes * sizeof(float), hipMemcpyDeviceToHost, e->sP));
     HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
 }

@@ -182,6 +182,52 @@ class BatchedEnv:
         """``LocationTracker.__map`` (``track_data_process.py:106-107``): index → 'loc/segment' float."""
         return np.asarray(idx, dtype=np.float64) / float(self.n_points) * (max_map - min_map) + min_map
 
+    # -- image path (ImgPreprocessing + pilot normalisation) ------------------------------------
+    def pre_config(self, cfg=None):
+        """``trs_pre_config`` from the reference's ``preprocessing_*`` keys (``core/config.py:15-28``)."""
+        pc = _ffi.TrsPreConfig()
+        self.api.default_pre_config(C.byref(pc))
+        cfg = cfg or {}
+        pc.dynamic_brightness = int(bool(cfg.get("preprocessing_dynamic_brightness_enabled", False)))
+        pc.brightness_baseline = float(cfg.get("preprocessing_brightness_baseline", 550))
+        pc.contrast_ratio = float(cfg.get("preprocessing_contrast_enhancement_ratio", 1.0))
+        pc.contrast_offset = float(cfg.get("preprocessing_contrast_enhancement_offset", 125))
+        pc.color_filter_enabled = int(bool(cfg.get("preprocessing_color_filter_enabled", False)))
+        pc.edge_detection_enabled = int(bool(cfg.get("preprocessing_edge_detection_enabled", False)))
+        if "preprocessing_color_filter_hsvs" in cfg:
+            bounds = cfg["preprocessing_color_filter_hsvs"]
+            chans = cfg.get("preprocessing_color_filter_destination_channels", list(range(len(bounds))))
+            if len(bounds) > 4 or len(chans) != len(bounds):
+                raise ValueError("at most 4 colour filters, one destination channel each")
+            pc.n_filters = len(bounds)
+            for f, (lo, hi) in enumerate(bounds):
+                for k in range(3):
+                    pc.hsv_lo[f][k], pc.hsv_hi[f][k] = int(min(lo[k], 255)), int(min(hi[k], 255))
+                pc.dst_channel[f] = int(chans[f])
+        return pc
+
+    def preprocess_host(self, frames, cfg=None):
+        """``ImgPreprocessing.__process`` (no Canny) for host frames ``uint8[n,H,W,3]`` -> fresh ndarray."""
+        src = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.H, self.W, 3)
+        dst = np.empty_like(src)
+        pc = cfg if isinstance(cfg, _ffi.TrsPreConfig) else self.pre_config(cfg)
+        self.api.check(self.api.preprocess_host(self._h, C.byref(pc), src.ctypes.data, dst.ctypes.data, int(src.shape[0])), "preprocess_host")
+        return dst
+
+    def preprocess_latest(self, cfg=None):
+        """Process the env's latest frames on the device; returns a zero-copy handle on ``uint8[N,H,W,3]``."""
+        pc = cfg if isinstance(cfg, _ffi.TrsPreConfig) else self.pre_config(cfg)
+        out = C.c_void_p()
+        self.api.check(self.api.preprocess(self._h, C.byref(pc), None, None, self.n, C.byref(out)), "preprocess")
+        return _DevicePtr(out.value, (self.n, self.H, self.W, 3), np.uint8, self)
+
+    def normalize_host(self, frames):
+        """Pilot-side ``float32(img) / 255`` (``keras_pilot.py:49-55``) -> ``float32[n,H,W,3]``."""
+        src = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.H, self.W, 3)
+        dst = np.empty(src.shape, dtype=np.float32)
+        self.api.check(self.api.normalize_host(self._h, src.ctypes.data, dst.ctypes.data, int(src.shape[0])), "normalize_host")
+        return dst
+
     # -- timing (HIP events on the handle's stream) -------------------------------------------
     def event_record(self, slot):
         self.api.check(self.api.event_record(self._h, int(slot)), "event_record")
