@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,9 +130,10 @@ def main():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = args.envs_per_gpu

@@ -31,7 +31,7 @@ class ShardedEnvs:
         """All ranks receive the full ``[n_total]`` vector of a per-env float32 field, ordered by global env id."""
         import torch
         import torch.distributed as dist
-        if self.world == 1 or not dist.is_initialized():
+        if not dist.is_initialized():
             return torch.from_numpy(self.env.fetch(name))
         if dist.get_backend() == "nccl":                       # device-resident, zero copy: RCCL all-gather over xGMI
             self.env.sync()
