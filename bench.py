@@ -175,9 +175,9 @@ def main():
         total_env_steps = n * world * args.steps
         value = total_env_steps / wall
         B = algorithmic_bytes(args.img_h, args.img_w, render)
-        # camera on: the library pipelines a call over steps+1 launches of trs_step_kernel (physics of step i beside
-        # the raster of step i-1); physics only: steps/spl launches of trs_physics_kernel
-        launches = (args.steps + 1) if render else (args.steps + spl - 1) // spl
+        # camera on: the library pipelines a call over ceil(steps/spl)+1 launches of trs_step_kernel (physics runs ahead of the
+        # raster inside and across launches); physics only: steps/spl launches of trs_physics_kernel
+        launches = ((args.steps + spl - 1) // spl + 1) if render else (args.steps + spl - 1) // spl
         avg_launch_s = kernel_ms * 1e-3 / launches
         per_launch = n * args.steps / launches                         # env-steps one launch completes
         achieved = B * per_launch / avg_launch_s / 1e9                 # GB/s of algorithmic bytes, dominant (only) kernel

@@ -383,29 +383,41 @@ constexpr int kStageRegs = 10;                               // 10 x 640 x 16 B 
 
 struct SParams {
     PParams ph;                         // physics side (blob = px|py|pz|tan image; cam = ring base)
-    RParams ra;                         // raster side (cam/img filled per launch)
-    int do_phys, do_raster, seq, p_slot;
-    int lds_off_phys;                   // LDS byte offset of the physics image (raster image sits at 0)
+    RParams ra;                         // raster side
+    uint8_t* img0; uint8_t* img1;       // frame of absolute step s goes to img[s & 1]
+    int n_phys;                         // physics steps this launch advances (0 = raster-only flush)
+    int r_first, r_last;                // raster renders launch-local steps r_first..r_last; -1 = the step before this
+                                        // launch (camera parameters from the global ring, written by the previous launch)
+    unsigned step_base;                 // absolute index of this launch's physics step 0
+    int lds_off_phys, lds_off_cam, lds_off_prog, cam_stride;   // LDS: physics image, float4 lcam[n_phys][cam_stride], int pprog[cam_stride]
 };
 
 // one wave advances one env (all lanes compute the same scalars; the track scan is lane-parallel)
+template <typename T>
+__device__ __forceinline__ T coherent_load(const T* ptr)
+{   // vector load that bypasses the per-CU L1 and the scalar cache: inside a K-step launch the value may have been
+    // stored by lane 0 of this wave one step earlier
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigned char* lphys, int e, uint32_t t, int k,
-                                                 float4* cam_out, int lane)
+                                                 float4* cam_out, float4* lcam_slot, int* pprog_j, bool multi, int lane)
 {
     const double* lpx = reinterpret_cast<const double*>(lphys);
     const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
     const float2* ltan = reinterpret_cast<const float2*>(lphys + p.off_tan);
     const int gid = p.env_id_base + e;
-    const uint8_t pend = p.pending[e], was_done = p.done[e];
+    const uint8_t pend = coherent_load(&p.pending[e]), was_done = coherent_load(&p.done[e]);
     const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
-    float sf = p.steer_filt[e];
-    const float vx = p.x[e], vy = p.y[e], vz = p.z[e], vyaw = p.yaw[e], vv = p.v[e];
+    float sf = coherent_load(&p.steer_filt[e]);
+    const float vx = coherent_load(&p.x[e]), vy = coherent_load(&p.y[e]), vz = coherent_load(&p.z[e]);
+    const float vyaw = coherent_load(&p.yaw[e]), vv = coherent_load(&p.v[e]);
     float steer = 0.f, thr = 0.f, brk = 0.f;
     if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
-    const int prev_idx = p.seg_idx[e];
-    float epr = p.ep_return[e];
-    int epl = p.ep_len[e];
+    const int prev_idx = coherent_load(&p.seg_idx[e]);
+    float epr = coherent_load(&p.ep_return[e]);
+    int epl = coherent_load(&p.ep_len[e]);
     const int do_reset = (pend != 0) || (rin != 0) || (p.auto_reset && was_done != 0);
     float x1, y0, z1, yaw1, v2, hs, hc;
     if (do_reset) {
@@ -481,10 +493,14 @@ __device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigne
         p.ep_return[e] = epr; p.ep_len[e] = epl; p.steer_filt[e] = sf;
         const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
         const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
-        cam_out[e] = make_float4(camx, camz, hs, hc);
+        const float4 cam = make_float4(camx, camz, hs, hc);
+        cam_out[e] = cam;                                   // for the next launch (its first frame)
+        *lcam_slot = cam;                                   // for this launch's raster team
         if (is_done) atomicAdd(&p.stats[0], 1ull);
         if (do_reset) atomicAdd(&p.stats[1], 1ull);
+        __hip_atomic_store(pprog_j, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish: step k of this env is done
     }
+    if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the state stores have reached L2 before the next step reloads them
 }
 
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     STAMP(0);
     // ---- prologue: each team stages the tables it reads (register-staged, all loads before the LDS writes) ----
     if (raster_team) {
-        if (sp.do_raster) {
+        if (sp.r_last >= sp.r_first) {
             const u4v* src = reinterpret_cast<const u4v*>(p.blob);
             u4v* dst = reinterpret_cast<u4v*>(smem);
             const int n16 = p.blob_bytes >> 4;
@@ -512,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 #pragma unroll
             for (int r = 0; r < kStageRegs; ++r) { const int i = tid + r * kRasterThreads; if (i < n16) dst[i] = reg[r]; }
         }
-    } else if (sp.do_phys) {
+    } else if (sp.n_phys > 0) {
         const int st = tid - kRasterThreads;
         constexpr int kT = kBlock - kRasterThreads;
         const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
@@ -528,24 +544,28 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     }
     const int e_begin = blockIdx.x * p.envs_per_wg;
     const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
+    float4* const lcam = reinterpret_cast<float4*>(smem + sp.lds_off_cam);     // [n_phys][cam_stride]
+    int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
+    for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
     STAMP(1);
     __syncthreads();
     STAMP(2);
 
-    // ---- physics team: one wave per env, no further workgroup synchronisation ----
-    if (!raster_team && sp.do_phys) {
-        const uint32_t t = (sp.ph.dev_step ? *sp.ph.dev_step : 0u) + sp.ph.step_off;
-        float4* const cam_out = sp.ph.cam + (size_t)sp.p_slot * sp.ph.n_envs;
-        for (int e = e_begin + (wave - kRasterThreads / 64); e < e_end; e += kPhysWaves)
-            physics_env_wave(sp.ph, smem + sp.lds_off_phys, e, t, 0, cam_out, lane);
+    // ---- physics team: one wave per env, no workgroup synchronisation; runs up to n_phys steps ahead of the raster ----
+    if (!raster_team) {
+        float4* const ring = sp.ph.cam;
+        for (int k = 0; k < sp.n_phys; ++k) {
+            const uint32_t t = sp.step_base + (uint32_t)k;
+            float4* const cam_out = ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs;
+            for (int e = e_begin + (wave - kRasterThreads / 64); e < e_end; e += kPhysWaves) {
+                const int j = e - e_begin;
+                physics_env_wave(sp.ph, smem + sp.lds_off_phys, e, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], sp.n_phys > 1, lane);
+            }
+        }
+        STAMP(3);
+        return;
     }
-    STAMP(3);
-    if (sp.seq) {
-        __threadfence_block();
-        __syncthreads();          // single-step call: the raster below renders what the physics team just produced
-    }
-    STAMP(4);
-    if (!raster_team || !sp.do_raster) return;
+    if (sp.r_last < sp.r_first) return;
 
     // ---- raster team ----
     // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre offsets uf are
@@ -560,12 +580,23 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const unsigned pitch = (unsigned)p.map_pitch_b;
     const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
     const size_t row_bytes = (size_t)p.gpr * 12;
+    for (int sidx = sp.r_first; sidx <= sp.r_last; ++sidx) {
+    const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
+    uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
+    const float4* const cam_prev = sp.ph.cam + (size_t)(abs_step & (kRing - 1)) * sp.ph.n_envs;
     for (int e = e_begin; e < e_end; ++e) {
-        const float4 cam = p.cam[e];      // written by the previous launch (seq = 0) or by this workgroup's physics team (seq = 1)
+        float4 cam;
+        if (sidx < 0) {
+            cam = cam_prev[e];                                                // written by the previous launch
+        } else {
+            const int j = e - e_begin;                                        // wait until the physics team has finished this step of env j
+            while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
+            cam = lcam[sidx * sp.cam_stride + j];
+        }
         const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
         // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            p.img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
         const int col_off = cg * 12;
         f2v rt = lrow[vstart < p.H ? vstart : 0];
         for (int v = vstart; v < p.H; v += p.rows_per_pass) {
@@ -604,6 +635,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 #endif
             rt = rtn;
         }
+    }
     }
     STAMP(5);
 }
@@ -797,7 +829,7 @@ struct trs_env {
     float *ctl_steer = nullptr, *ctl_thr = nullptr, *ctl_brk = nullptr;
     uint8_t* ctl_reset = nullptr;
     size_t img_bytes = 0;
-    int lds_step = 0, lds_off_phys = 0;
+    int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
 };
 
 namespace {
@@ -810,39 +842,47 @@ int sync_all(trs_env* e)
     return TRS_OK;
 }
 
-// one launch of the fused step kernel: physics of step `phys_step` (if do_phys) and raster of step `raster_step`
-// (if do_raster); seq = 1 makes the raster wait for this launch's physics (both refer to the same step then)
+// one launch of the fused step kernel: physics steps [step_base, step_base + n_phys) and the frames of launch-local
+// steps r_first..r_last (-1 = step_base - 1, whose camera parameters the previous launch left in the global ring)
 int launch_step(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth,
-                int do_phys, int do_raster, int seq, uint64_t phys_step, uint64_t raster_step)
+                int n_phys, int r_first, int r_last, uint64_t step_base)
 {
     SParams sp;
     sp.ph = e->pp;
     sp.ph.ctl_steer = st; sp.ph.ctl_thr = th; sp.ph.ctl_brk = br; sp.ph.ctl_reset = rs;
-    sp.ph.synth = synth; sp.ph.n_steps = 1; sp.ph.write_cam = 1; sp.ph.dev_step = nullptr; sp.ph.step_off = (uint32_t)phys_step;
+    sp.ph.synth = synth; sp.ph.n_steps = n_phys; sp.ph.write_cam = 1; sp.ph.dev_step = nullptr; sp.ph.step_off = (uint32_t)step_base;
     sp.ra = e->rp;
-    sp.ra.cam = e->cam + (size_t)(raster_step & (kRing - 1)) * e->n;
-    sp.ra.img = e->img[raster_step & 1];
-    sp.do_phys = do_phys; sp.do_raster = do_raster; sp.seq = seq;
-    sp.p_slot = (int)(phys_step & (kRing - 1));
+    sp.img0 = e->img[0]; sp.img1 = e->img[1];
+    sp.n_phys = n_phys; sp.r_first = r_first; sp.r_last = r_last;
+    sp.step_base = (unsigned)step_base;
     sp.lds_off_phys = e->lds_off_phys;
-    hipLaunchKernelGGL(trs_step_kernel, dim3(grid_of(e)), dim3(kBlock), e->lds_step, e->sP, sp);
+    sp.cam_stride = e->pp.envs_per_wg;
+    sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
+    sp.lds_off_prog = sp.lds_off_cam + std::max(n_phys, 1) * sp.cam_stride * 16;
+    const int lds = sp.lds_off_prog + sp.cam_stride * 4;
+    hipLaunchKernelGGL(trs_step_kernel, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
 
-// n env steps with a camera.  n == 1: one launch, physics then raster.  n > 1: software pipeline over launches —
-// launch i runs physics of step s0+i beside the raster of step s0+i-1; a physics-only launch opens and a
-// raster-only launch closes the call, so on return state and image both belong to step s0+n-1.
-int run_camera_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n)
+// n env steps with a camera, K = steps per launch.  n == 1: one launch, the raster team waits for the physics team
+// through the LDS progress counters.  Otherwise a software pipeline over launches: a launch advances K physics steps
+// and renders the previous launch's last step plus its own steps 0..K-2; a raster-only launch closes the call, so on
+// return state and image both belong to step s0+n-1.
+int run_camera_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, int per_launch)
 {
     const uint64_t s0 = e->step_count;
+    const int kmax = std::max(1, std::min(per_launch, e->max_steps_per_launch));
     int rc = TRS_OK;
     if (n == 1) {
-        rc = launch_step(e, st, th, br, rs, synth, 1, 1, 1, s0, s0);
+        rc = launch_step(e, st, th, br, rs, synth, 1, 0, 0, s0);
     } else {
-        rc = launch_step(e, st, th, br, rs, synth, 1, 0, 0, s0, s0);
-        for (int i = 1; i < n && !rc; ++i) rc = launch_step(e, st, th, br, nullptr, synth, 1, 1, 0, s0 + i, s0 + i - 1);
-        if (!rc) rc = launch_step(e, st, th, br, nullptr, synth, 0, 1, 0, s0 + n - 1, s0 + n - 1);
+        for (int done = 0; done < n && !rc;) {
+            const int k = std::min(kmax, n - done);
+            rc = launch_step(e, st, th, br, done == 0 ? rs : nullptr, synth, k, done == 0 ? 0 : -1, k - 2, s0 + done);
+            done += k;
+        }
+        if (!rc) rc = launch_step(e, st, th, br, nullptr, synth, 0, -1, -1, s0 + n);
     }
     if (rc) return rc;
     e->step_count += (uint64_t)n;
@@ -1042,7 +1082,13 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     k.np = n_points; r.map_w = T.info.map_w; r.map_h = T.info.map_h;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_step));
+    {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
+        const int epw = k.envs_per_wg;
+        const int free_b = 160 * 1024 - e->lds_step - epw * 4;
+        e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
+        if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
+    }
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->pts_bytes));
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
     const size_t n = (size_t)e->n;
@@ -1089,7 +1135,7 @@ TRS_EXPORT int trs_step(trs_env* e, const float* d_st, const float* d_th, const 
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
     // held controls; the reset request applies to the first step only
-    return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps)
+    return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, n_steps)
                          : run_physics_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, 1);
 }
 
@@ -1112,8 +1158,7 @@ TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     HIPCHK(hipSetDevice(e->device));
-    // camera on: one launch per step, pipelined over the call (steps_per_launch applies to physics-only envs)
-    return e->cfg.render ? run_camera_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps)
+    return e->cfg.render ? run_camera_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch)
                          : run_physics_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch);
 }
 
