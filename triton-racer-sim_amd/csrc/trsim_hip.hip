@@ -14,8 +14,8 @@
 //     Inside a multi-step call the raster team renders step t-1 while the physics team computes step t; the host
 //     opens the call with a physics-only launch and closes it with a raster-only launch (the lag never leaves the
 //     call).  A single-step call runs physics -> barrier -> raster in one launch.
-//   trs_physics_kernel  camera off (BASELINE config 2): lane-per-env integration (coalesced SoA), wave-sliced
-//     search, wave-ballot census of off-track envs, K steps per launch.
+//   trs_physics_kernel  camera off (BASELINE config 2): the same wave-per-env routine, 4 envs per 256-thread
+//     workgroup, K steps per launch, no synchronisation after the one-time staging of the track into LDS.
 //   trs_locate_kernel   batched LocationTracker for arbitrary binary64 query points.
 //
 // Rejected on measurements: all-wave fused phases; two kernels on three streams + hipGraph.
@@ -43,12 +43,8 @@
 namespace {
 
 constexpr int kBlock = 960;            // 15 waves: 4800 four-pixel groups of a 120x160 image = 5 x 960
-constexpr int kWaves = kBlock / 64;
-constexpr int kEMax = 15;              // envs of one workgroup processed per chunk (<= one wave each in the search)
 constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
 constexpr int kRing = 4;               // camera-parameter ring between the physics and the raster side (2 would do)
-constexpr int kStagers = kBlock - 64;  // physics: waves 1..14 stage tables while wave 0 integrates
-constexpr int kHotRegs = 7;            // 7 x 896 x 16 B = 100 KB >= points + tangents
 [[maybe_unused]] constexpr int kRasterStampThread = 640;  // diagnostic stamps: wave 0 and the first physics wave
 
 struct PParams {                        // physics kernel
@@ -181,191 +177,6 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 #define TRS_STORE_AUX 17   /* cache policy of the image stores: 0 plain, 2 nt, 16 sc1, 17 sc0 sc1 (write-through: the frame streams to HBM while the kernel computes instead of being flushed from L2 at kernel end; +13% at 1024 envs, profiles/r01_store_policy_ab.txt) */
 #endif
 
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void trs_physics_kernel(const PParams p)
-{
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-#define STAMP_STATS p.stats
-    STAMP(0);
-
-    const double* lpx = reinterpret_cast<const double*>(smem);
-    const double* lpy = reinterpret_cast<const double*>(smem + p.off_py);
-    const double* lpz = reinterpret_cast<const double*>(smem + p.off_pz);
-    const float2* ltan = reinterpret_cast<const float2*>(smem + p.off_tan);
-    // scratch (16-B aligned base): binary64 arrays first, then ints
-    double* sq = reinterpret_cast<double*>(smem + p.off_scratch);                 // [3][kEMax] query points
-    double* spd = sq + 3 * kEMax;                                                 // [kEMax][kWaves] partial distance
-    int* spi = reinterpret_cast<int*>(spd + kEMax * kWaves);                      // [kEMax][kWaves] partial index
-    const double* gpx = reinterpret_cast<const double*>(p.blob);                  // global copies (reset path only)
-    const double* gpy = reinterpret_cast<const double*>(p.blob + p.off_py);
-    const double* gpz = reinterpret_cast<const double*>(p.blob + p.off_pz);
-
-    // ---- prologue: waves 1..14 stage the track tables (register-staged) while wave 0 starts phase 0 ----
-    if (wave != 0) {
-        const int st = tid - 64;
-        const u4v* hsrc = reinterpret_cast<const u4v*>(p.blob);
-        u4v* hdst = reinterpret_cast<u4v*>(smem);
-        const int hot16 = p.blob_bytes >> 4;
-        u4v hreg[kHotRegs];
-#pragma unroll
-        for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; hreg[r] = (i < hot16) ? hsrc[i] : (u4v)(0u); }
-#pragma unroll
-        for (int r = 0; r < kHotRegs; ++r) { const int i = st + r * kStagers; if (i < hot16) hdst[i] = hreg[r]; }
-    }
-
-    const int e_begin = blockIdx.x * p.envs_per_wg;
-    const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
-    const uint32_t t0 = (p.dev_step ? *p.dev_step : 0u) + p.step_off;
-    STAMP(1);
-
-    for (int k = 0; k < p.n_steps; ++k) {
-        const uint32_t t = t0 + (uint32_t)k;
-        float4* const cam_out = p.cam + (size_t)((p.cam_slot + k) & (kRing - 1)) * p.n_envs;
-
-        for (int c0 = e_begin; c0 < e_end; c0 += kEMax) {
-            const int nE = min(kEMax, e_end - c0);
-            const int e = c0 + tid;          // env of this lane in phases 0 / A2 (tid < nE)
-
-            // ---- phase 0: integrate (lane j of wave 0 <-> env j of the chunk: coalesced SoA accesses) ----
-            float x1 = 0.f, y0 = 0.f, z1 = 0.f, yaw1 = 0.f, v2 = 0.f, hs = 0.f, hc = 1.f, sf = 0.f;
-            int do_reset = 0, prev_idx = 0;
-            if (tid < nE) {
-                // every load of the env's state is issued up front: one memory round trip, not one per branch
-                const int gid = p.env_id_base + e;
-                const uint8_t pend = p.pending[e], was_done = p.done[e];
-                const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
-                const float sf_in = p.steer_filt[e];
-                const float vx = p.x[e], vy = p.y[e], vz = p.z[e], vyaw = p.yaw[e], vv = p.v[e];
-                float steer = 0.f, thr = 0.f, brk = 0.f;
-                if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
-                prev_idx = p.seg_idx[e];
-                do_reset = (pend != 0) || (rin != 0) || (p.auto_reset && was_done != 0);
-                sf = sf_in;
-                if (do_reset) {
-                    const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
-                    x1 = (float)gpx[si]; y0 = (float)gpy[si]; z1 = (float)gpz[si];
-                    yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
-                    spec_sincos(yaw1, hs, hc);
-                } else {
-                    if (p.synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
-                    steer = clampf(steer, -1.0f, 1.0f);
-                    thr = clampf(thr, -1.0f, 1.0f);
-                    brk = clampf(brk, 0.0f, 1.0f);
-                    float sd, cd;
-                    spec_sincos(steer * p.max_steer, sd, cd);
-                    const float tan_d = sd / cd;
-                    const float a = thr * p.accel_max - p.drag_lin * vv;
-                    const float v1 = vv + a * p.dt;
-                    const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
-                    if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
-                    else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
-                    else v2 = 0.0f;
-                    v2 = clampf(v2, -p.v_rev_max, p.v_max);
-                    yaw1 = vyaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
-                    if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
-                    if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
-                    spec_sincos(yaw1, hs, hc);
-                    x1 = vx + (v2 * hs) * p.dt;
-                    z1 = vz + (v2 * hc) * p.dt;
-                    y0 = vy;
-                }
-                sq[tid] = (double)x1; sq[kEMax + tid] = (double)y0; sq[2 * kEMax + tid] = (double)z1;
-            }
-            STAMP(2);
-            __syncthreads();
-            STAMP(3);
-
-            // ---- phase A: nearest raw track point, L1 in binary64 ----
-            // env j is scanned by waves [j*wpe, (j+1)*wpe), each taking an interleaved slice of the points (two points
-            // per trip so that the LDS reads of one overlap the arithmetic of the other); one DPP argmin per wave
-            const int wpe = kWaves / nE;
-            {
-                const int j = wave / wpe, slice = wave - j * wpe;
-                if (j < nE) {
-                    const double qx = sq[j], qy = sq[kEMax + j], qz = sq[2 * kEMax + j];
-                    double best = TRS_LOST_L1;
-                    int bi = 0;
-                    const int stride = wpe * 64;
-                    int i = slice * 64 + lane;
-                    for (; i + stride < p.np; i += 2 * stride) {
-                        const int i2 = i + stride;
-                        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
-                        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
-                        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
-                        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
-                        if (d1 < best) { best = d1; bi = i; }
-                        if (d2 < best) { best = d2; bi = i2; }
-                    }
-                    if (i < p.np) {
-                        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-                        if (d1 < best) { best = d1; bi = i; }
-                    }
-                    wave_argmin(best, bi);
-                    if (lane == 63) { spd[j * kWaves + slice] = best; spi[j * kWaves + slice] = bi; }
-                }
-            }
-            STAMP(4);
-            __syncthreads();
-            STAMP(5);
-
-            // ---- phase A2: fold partials, finish the env, store state + camera parameters ----
-            int is_done = 0;
-            if (tid < nE) {
-                double best = spd[tid * kWaves];
-                int idx = spi[tid * kWaves];
-                for (int w = 1; w < wpe; ++w) {
-                    const double od = spd[tid * kWaves + w];
-                    const int oi = spi[tid * kWaves + w];
-                    const bool take = (od < best) || (od == best && oi < idx);
-                    best = take ? od : best;
-                    idx = take ? oi : idx;
-                }
-                const float y1 = (float)lpy[idx];
-                const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
-                const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
-                const bool lost = best >= TRS_LOST_L1;
-                is_done = (fabsf(cte) > p.offtrack_cte) || lost;
-                float epr = p.ep_return[e];
-                int epl = p.ep_len[e];
-                if (do_reset) {
-                    p.last_return[e] = epr;
-                    epr = 0.0f; epl = 0;
-                    p.pending[e] = 0;
-                } else {
-                    int d = idx - prev_idx;
-                    const int half = p.np / 2;
-                    if (d >= p.np - half) d -= p.np;
-                    if (d < -half) d += p.np;
-                    const float reward = (float)d - (is_done ? p.offtrack_penalty : 0.0f);
-                    epr = epr + reward;
-                    epl += 1;
-                }
-                p.x[e] = x1; p.y[e] = y1; p.z[e] = z1; p.yaw[e] = yaw1; p.v[e] = v2;
-                p.speed[e] = fabsf(v2); p.cte[e] = cte; p.seg_idx[e] = idx; p.done[e] = (uint8_t)is_done;
-                p.ep_return[e] = epr; p.ep_len[e] = epl; p.steer_filt[e] = sf;
-                if (p.write_cam) {
-                    const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
-                    const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
-                    cam_out[e] = make_float4(camx, camz, hs, hc);
-                }
-            }
-            if (wave == 0) {   // off-track / reset census: wave ballot, one atomic per workgroup-chunk
-                const unsigned long long mdone = __ballot(is_done != 0);
-                const unsigned long long mreset = __ballot(do_reset != 0);
-                if (lane == 0) {
-                    if (mdone) atomicAdd(&p.stats[0], (unsigned long long)__popcll(mdone));
-                    if (mreset) atomicAdd(&p.stats[1], (unsigned long long)__popcll(mreset));
-                }
-            }
-            STAMP(6);
-            __syncthreads();     // scratch is reused by the next chunk / step
-            STAMP(7);
-        }
-    }
-}
-
 #undef STAMP_STATS
 #define STAMP_STATS sp.ra.stats
 // ---------------------------------------------------------------------------------------------
@@ -400,25 +211,50 @@ __device__ __forceinline__ T coherent_load(const T* ptr)
     return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigned char* lphys, int e, uint32_t t, int k,
-                                                 float4* cam_out, float4* lcam_slot, int* pprog_j, bool multi, int lane)
+// Per-env state held in registers by the wave that owns the env (every lane holds the same values).
+struct EnvRegs {
+    float x, y, z, yaw, v, sf, epr, speed, cte;
+    int seg, epl, done, pend;
+};
+
+__device__ __forceinline__ void env_load(const PParams& p, int e, EnvRegs& s)
+{
+    s.pend = coherent_load(&p.pending[e]); s.done = coherent_load(&p.done[e]);
+    s.sf = coherent_load(&p.steer_filt[e]);
+    s.x = coherent_load(&p.x[e]); s.y = coherent_load(&p.y[e]); s.z = coherent_load(&p.z[e]);
+    s.yaw = coherent_load(&p.yaw[e]); s.v = coherent_load(&p.v[e]);
+    s.seg = coherent_load(&p.seg_idx[e]);
+    s.epr = coherent_load(&p.ep_return[e]);
+    s.epl = coherent_load(&p.ep_len[e]);
+    s.speed = 0.f; s.cte = 0.f;
+}
+
+__device__ __forceinline__ void env_store(const PParams& p, int e, const EnvRegs& s, int lane)
+{
+    if (lane == 0) {
+        p.x[e] = s.x; p.y[e] = s.y; p.z[e] = s.z; p.yaw[e] = s.yaw; p.v[e] = s.v;
+        p.speed[e] = s.speed; p.cte[e] = s.cte; p.seg_idx[e] = s.seg; p.done[e] = (uint8_t)s.done;
+        p.ep_return[e] = s.epr; p.ep_len[e] = s.epl; p.steer_filt[e] = s.sf; p.pending[e] = (uint8_t)s.pend;
+    }
+}
+
+// One wave advances one env by one step, state in registers (include/trsim_spec.h, "one env step").
+__device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
+                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane)
 {
     const double* lpx = reinterpret_cast<const double*>(lphys);
     const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
     const float2* ltan = reinterpret_cast<const float2*>(lphys + p.off_tan);
     const int gid = p.env_id_base + e;
-    const uint8_t pend = coherent_load(&p.pending[e]), was_done = coherent_load(&p.done[e]);
     const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
-    float sf = coherent_load(&p.steer_filt[e]);
-    const float vx = coherent_load(&p.x[e]), vy = coherent_load(&p.y[e]), vz = coherent_load(&p.z[e]);
-    const float vyaw = coherent_load(&p.yaw[e]), vv = coherent_load(&p.v[e]);
+    float sf = s.sf;
     float steer = 0.f, thr = 0.f, brk = 0.f;
     if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
-    const int prev_idx = coherent_load(&p.seg_idx[e]);
-    float epr = coherent_load(&p.ep_return[e]);
-    int epl = coherent_load(&p.ep_len[e]);
-    const int do_reset = (pend != 0) || (rin != 0) || (p.auto_reset && was_done != 0);
+    const int prev_idx = s.seg;
+    float epr = s.epr;
+    int epl = s.epl;
+    const int do_reset = (s.pend != 0) || (rin != 0) || (p.auto_reset && s.done != 0);
     float x1, y0, z1, yaw1, v2, hs, hc;
     if (do_reset) {
         const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
@@ -433,20 +269,20 @@ __device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigne
         float sd, cd;
         spec_sincos(steer * p.max_steer, sd, cd);
         const float tan_d = sd / cd;
-        const float a = thr * p.accel_max - p.drag_lin * vv;
-        const float v1 = vv + a * p.dt;
+        const float a = thr * p.accel_max - p.drag_lin * s.v;
+        const float v1 = s.v + a * p.dt;
         const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
         if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
         else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
         else v2 = 0.0f;
         v2 = clampf(v2, -p.v_rev_max, p.v_max);
-        yaw1 = vyaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
+        yaw1 = s.yaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
         if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
         if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
         spec_sincos(yaw1, hs, hc);
-        x1 = vx + (v2 * hs) * p.dt;
-        z1 = vz + (v2 * hc) * p.dt;
-        y0 = vy;
+        x1 = s.x + (v2 * hs) * p.dt;
+        z1 = s.z + (v2 * hc) * p.dt;
+        y0 = s.y;
     }
     // nearest raw track point: binary64 L1, lane-strided scan (two points per trip), DPP argmin, broadcast from lane 63
     const double qx = (double)x1, qy = (double)y0, qz = (double)z1;
@@ -476,7 +312,7 @@ __device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigne
     const bool lost = bestd >= TRS_LOST_L1;
     const int is_done = (fabsf(cte) > p.offtrack_cte) || lost;
     if (do_reset) {
-        if (lane == 0) { p.last_return[e] = epr; p.pending[e] = 0; }
+        if (lane == 0) p.last_return[e] = epr;
         epr = 0.0f; epl = 0;
     } else {
         int d = idx - prev_idx;
@@ -487,20 +323,49 @@ __device__ __forceinline__ void physics_env_wave(const PParams& p, const unsigne
         epr = epr + reward;
         epl += 1;
     }
+    s.x = x1; s.y = y1; s.z = z1; s.yaw = yaw1; s.v = v2; s.sf = sf; s.epr = epr; s.epl = epl;
+    s.speed = fabsf(v2); s.cte = cte; s.seg = idx; s.done = is_done; s.pend = 0;
     if (lane == 0) {
-        p.x[e] = x1; p.y[e] = y1; p.z[e] = z1; p.yaw[e] = yaw1; p.v[e] = v2;
-        p.speed[e] = fabsf(v2); p.cte[e] = cte; p.seg_idx[e] = idx; p.done[e] = (uint8_t)is_done;
-        p.ep_return[e] = epr; p.ep_len[e] = epl; p.steer_filt[e] = sf;
         const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
         const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
         const float4 cam = make_float4(camx, camz, hs, hc);
-        cam_out[e] = cam;                                   // for the next launch (its first frame)
+        if (p.write_cam) cam_out[e] = cam;                  // for the next launch (its first frame)
         *lcam_slot = cam;                                   // for this launch's raster team
         if (is_done) atomicAdd(&p.stats[0], 1ull);
         if (do_reset) atomicAdd(&p.stats[1], 1ull);
         __hip_atomic_store(pprog_j, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish: step k of this env is done
     }
-    if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the state stores have reached L2 before the next step reloads them
+}
+
+// Physics-only envs (BASELINE config 2): the same barrier-free wave-per-env routine, 4 envs per 256-thread workgroup,
+// K steps per launch.  The track image is staged once per launch; nothing is synchronised after that.
+constexpr int kPhysBlock = 256;
+
+__global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const u4v* src = reinterpret_cast<const u4v*>(p.blob);
+        u4v* dst = reinterpret_cast<u4v*>(smem);
+        const int n16 = p.blob_bytes >> 4;
+        for (int base = 0; base < n16; base += 8 * kPhysBlock) {
+            u4v reg[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + tid + r * kPhysBlock; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + tid + r * kPhysBlock; if (i < n16) dst[i] = reg[r]; }
+        }
+    }
+    float4* const lsink = reinterpret_cast<float4*>(smem + p.off_scratch);          // per-wave sinks for the camera hand-off slots
+    int* const psink = reinterpret_cast<int*>(smem + p.off_scratch + (kPhysBlock / 64) * 16);
+    __syncthreads();
+    const int e = blockIdx.x * (kPhysBlock / 64) + wave;
+    if (e >= p.n_envs) return;
+    EnvRegs st;
+    env_load(p, e, st);
+    for (int k = 0; k < p.n_steps; ++k)
+        env_step(p, smem, e, st, p.step_off + (uint32_t)k, k, p.cam, &lsink[wave], &psink[wave], lane);
+    env_store(p, e, st, lane);
 }
 
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
@@ -554,12 +419,34 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     // ---- physics team: one wave per env, no workgroup synchronisation; runs up to n_phys steps ahead of the raster ----
     if (!raster_team) {
         float4* const ring = sp.ph.cam;
-        for (int k = 0; k < sp.n_phys; ++k) {
-            const uint32_t t = sp.step_base + (uint32_t)k;
-            float4* const cam_out = ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs;
-            for (int e = e_begin + (wave - kRasterThreads / 64); e < e_end; e += kPhysWaves) {
+        const unsigned char* const lphys = smem + sp.lds_off_phys;
+        const int pw = wave - kRasterThreads / 64;
+        if (p.envs_per_wg <= kPhysWaves) {
+            // at most one env per physics wave: its state lives in registers for all the steps of this launch
+            const int e = e_begin + pw;
+            if (e < e_end && sp.n_phys > 0) {
                 const int j = e - e_begin;
-                physics_env_wave(sp.ph, smem + sp.lds_off_phys, e, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], sp.n_phys > 1, lane);
+                EnvRegs st;
+                env_load(sp.ph, e, st);
+                for (int k = 0; k < sp.n_phys; ++k) {
+                    const uint32_t t = sp.step_base + (uint32_t)k;
+                    env_step(sp.ph, lphys, e, st, t, k, ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs, &lcam[k * sp.cam_stride + j], &pprog[j], lane);
+                }
+                env_store(sp.ph, e, st, lane);
+            }
+        } else {
+            // several envs per wave: step-major order keeps every env's raster fed; state goes through L2 between steps
+            for (int k = 0; k < sp.n_phys; ++k) {
+                const uint32_t t = sp.step_base + (uint32_t)k;
+                float4* const cam_out = ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs;
+                for (int e = e_begin + pw; e < e_end; e += kPhysWaves) {
+                    const int j = e - e_begin;
+                    EnvRegs st;
+                    env_load(sp.ph, e, st);
+                    env_step(sp.ph, lphys, e, st, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], lane);
+                    env_store(sp.ph, e, st, lane);
+                }
+                if (sp.n_phys > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores have reached L2 before the next step reloads them
             }
         }
         STAMP(3);
@@ -897,7 +784,7 @@ int run_physics_steps(trs_env* e, const float* st, const float* th, const float*
         PParams p = e->pp;
         p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = done == 0 ? rs : nullptr;
         p.synth = synth; p.n_steps = now; p.cam_slot = 0; p.write_cam = 0; p.dev_step = nullptr; p.step_off = (uint32_t)e->step_count;
-        hipLaunchKernelGGL(trs_physics_kernel, dim3(grid_of(e)), dim3(kBlock), e->lds_p, e->sP, p);
+        hipLaunchKernelGGL(trs_physics_kernel, dim3((e->n + kPhysBlock / 64 - 1) / (kPhysBlock / 64)), dim3(kPhysBlock), e->lds_p, e->sP, p);
         HIPCHK(hipGetLastError());
         e->step_count += (uint64_t)now;
         done += now;
@@ -1027,7 +914,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
 
     // ---- physics LDS image: px | py | pz | tangent (when it fits) + scratch ----
     const size_t pts = align_up((size_t)n_points * 8, 16);
-    const size_t scratch = 3 * kEMax * 8 + (size_t)kEMax * kWaves * 8 + (size_t)kEMax * kWaves * 4;
+    const size_t scratch = (size_t)(kPhysBlock / 64) * (16 + 4) + 16;     // physics-only kernel: per-wave sinks
     size_t off = 0;
     k.off_py = (int)(off += pts); k.off_pz = (int)(off += pts); off += pts;
     e->pts_bytes = (int)off;
@@ -1053,7 +940,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     k.off_scratch = (int)off;
     e->lds_p = (int)align_up(off + scratch, 16);
     e->lds_step = (int)align_up((size_t)e->lds_off_phys + off, 16);
-    if (e->lds_p > 160 * 1024 || (size_t)k.blob_bytes > (size_t)kHotRegs * kStagers * 16 || (e->cfg.render && e->lds_step > 160 * 1024))
+    if (e->lds_p > 160 * 1024 || (e->cfg.render && e->lds_step > 160 * 1024))
         return fail(TRS_ERR_LIMIT, "track too long for the LDS-resident nearest-point search");
     std::vector<unsigned char> hp(off, 0);
     std::memcpy(hp.data(), T.px.data(), (size_t)n_points * 8);
