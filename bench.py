@@ -25,9 +25,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(h, w, render):
-    # H*W*3 image bytes written once + 88 B of state / control / telemetry per env-step
-    return (h * w * 3 if render else 0) + 88
+def algorithmic_bytes(h, w, render, depth=False):
+    # H*W*3 image bytes written once (+ H*W*4 of fp32 depth) + 88 B of state / control / telemetry per env-step
+    return (h * w * 3 if render else 0) + (h * w * 4 if render and depth else 0) + 88
 
 
 def usable_cores():
@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--img-w", type=int, default=160)
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
+    ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
     args = ap.parse_args()
@@ -138,7 +139,8 @@ def main():
 
     n = args.envs_per_gpu
     render = not args.no_render
-    shard = ShardedEnvs(n * world, rank, world, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render, auto_reset=True)
+    shard = ShardedEnvs(n * world, rank, world, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render, auto_reset=True,
+                        depth=args.depth)
     env = shard.env
     spl = max(1, args.steps_per_launch)
 
@@ -174,7 +176,7 @@ def main():
     if rank == 0:
         total_env_steps = n * world * args.steps
         value = total_env_steps / wall
-        B = algorithmic_bytes(args.img_h, args.img_w, render)
+        B = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         # camera on: the library pipelines a call over ceil(steps/spl)+1 launches of trs_step_kernel (physics runs ahead of the
         # raster inside and across launches); physics only: steps/spl launches of trs_physics_kernel
         launches = ((args.steps + spl - 1) // spl + 1) if render else (args.steps + spl - 1) // spl
@@ -197,6 +199,7 @@ def main():
             "config": {
                 "workload": f"{n} envs/GPU x {world} GPU, bicycle physics + L1 nearest point"
                             + (f" + {args.img_h}x{args.img_w} RGB pinhole rasteriser" if render else " (no camera)")
+                            + (" + fp32 depth" if render and args.depth else "")
                             + " (BASELINE configs[2] per GPU), generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
                 "envs_total": n * world, "steps_per_launch": spl, "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
             },

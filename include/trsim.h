@@ -47,7 +47,7 @@ typedef struct trs_config {
     int32_t  img_h, img_w;     /* config.py:8-9 -> 120, 160; img_w % 4 == 0 */
     int32_t  render;           /* 0 = physics only (BASELINE config 2), 1 = RGB camera */
     int32_t  auto_reset;       /* 1 = an env that finished (off track) restarts on its next step */
-    int32_t  reserved0;
+    int32_t  depth;            /* 1 = also write a binary32 z-depth image [n_envs][img_h][img_w] (BASELINE config 5 frame format) */
     uint64_t seed;             /* synthetic-control RNG seed, default 0x5EED */
     /* physics (trsim_spec.h) */
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
@@ -76,6 +76,7 @@ typedef struct trs_state_view {
     const int32_t* ep_len;
     const uint8_t* done;       /* 1 = this step ended the episode (off track / lost) */
     uint64_t step_count;       /* steps taken since create */
+    const float*   depth;      /* float[n_envs][img_h][img_w] z-depth of the last frame, NULL unless cfg.depth */
 } trs_state_view;
 
 /* selectors for trs_copy_to_host */
@@ -87,7 +88,9 @@ enum {
     TRS_F_PALETTE,   /* uint32[img_h][4] 0x00BBGGRR       */
     TRS_F_TANGENT,   /* float[n_points][2] (tx, tz)       */
     TRS_F_STEER_FILT,/* float[n_envs] synthetic low-pass state */
-    TRS_F_STATS      /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [8..] diagnostics */
+    TRS_F_STATS,     /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [8..] diagnostics */
+    TRS_F_DEPTH,     /* float[n_envs][img_h][img_w] */
+    TRS_F_ROWDEPTH   /* float[img_h] */
 };
 
 typedef struct trs_map_info {

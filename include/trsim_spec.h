@@ -62,6 +62,8 @@
  *     cls = 2-bit class of cell (ix, iz)  (the map border is class 0)
  *     rgb = palette[v][cls]
  *   SKY/FAR rows have row_lz = row_k = 0 and a palette whose 4 entries are equal.
+ *   depth channel (optional, binary32 [H][W]): z-depth of the ground plane, constant along an image row:
+ *     GROUND row: (float)(t*dz) world units;  SKY and FAR rows: (float)z_far.
  */
 #ifndef TRSIM_SPEC_H
 #define TRSIM_SPEC_H

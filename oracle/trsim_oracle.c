@@ -49,6 +49,8 @@ struct trs_env {
     uint32_t* map;
     float* rowtab;             /* [H][2] */
     uint32_t* pal;             /* [H][4] */
+    float* rowdepth;           /* [H] */
+    float* depth;              /* [n][H][W] when cfg.depth */
     float map_x0f, map_z0f, inv_cellf;
     /* state */
     float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
@@ -181,6 +183,9 @@ static void render_env(struct trs_env* e, int i, float s, float c)
     float camz = ((e->z[i] + k->cam_fwd * c) - e->map_z0f) * e->inv_cellf;
     uint8_t* out = e->img + (size_t)i * H * W * 3;
     float half_w = (float)(W / 2);
+    if (e->depth)
+        for (int v = 0; v < H; ++v)
+            for (int u = 0; u < W; ++u) e->depth[((size_t)i * H + v) * W + u] = e->rowdepth[v];
     for (int v = 0; v < H; ++v) {
         float lz = e->rowtab[2 * v], kk = e->rowtab[2 * v + 1];
         float ax = fmaf(lz, s, camx), az = fmaf(lz, c, camz);
@@ -334,6 +339,7 @@ static int build_track_tables(struct trs_env* e)
             }
         }
         e->rowtab[2 * v] = lz; e->rowtab[2 * v + 1] = kk;
+        e->rowdepth[v] = (lz != 0.0f || kk != 0.0f) ? (float)((k->cam_h / (-dy)) * dz) : (float)k->z_far;
         for (int c = 0; c < 4; ++c)
             e->pal[4 * v + c] = (uint32_t)rgb[c][0] | ((uint32_t)rgb[c][1] << 8) | ((uint32_t)rgb[c][2] << 16);
     }
@@ -376,6 +382,8 @@ EXPORT int trso_create(const trs_config* cfg, int device, trs_env** out)
     if (cfg->render) e->img = calloc((size_t)n * e->H * e->W * 3, 1);
     e->rowtab = calloc((size_t)e->H * 2, sizeof(float));
     e->pal = calloc((size_t)e->H * 4, sizeof(uint32_t));
+    e->rowdepth = calloc((size_t)e->H, sizeof(float));
+    if (cfg->render && cfg->depth) e->depth = calloc((size_t)n * e->H * e->W, sizeof(float));
     *out = e;
     return TRS_OK;
 }
@@ -383,7 +391,7 @@ EXPORT int trso_create(const trs_config* cfg, int device, trs_env** out)
 EXPORT int trso_destroy(trs_env* e)
 {
     if (!e) return TRS_OK;
-    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal);
+    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal); free(e->rowdepth); free(e->depth);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
     free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre);
     free(e);
@@ -461,7 +469,7 @@ EXPORT int trso_get_state(trs_env* e, trs_state_view* o)
     o->n_envs = e->n; o->img_h = e->H; o->img_w = e->W; o->n_points = e->np;
     o->img = e->img; o->pos_x = e->x; o->pos_y = e->y; o->pos_z = e->z; o->speed = e->speed; o->cte = e->cte;
     o->yaw = e->yaw; o->vel = e->v; o->seg_idx = e->seg_idx; o->ep_return = e->ep_return; o->last_return = e->last_return;
-    o->ep_len = e->ep_len; o->done = e->done; o->step_count = e->step_count;
+    o->ep_len = e->ep_len; o->done = e->done; o->step_count = e->step_count; o->depth = e->depth;
     return TRS_OK;
 }
 
@@ -489,6 +497,8 @@ EXPORT int trso_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_TANGENT: src = e->tang; need = (size_t)e->np * 8; break;
     case TRS_F_STEER_FILT: src = e->steer_filt; need = n * 4; break;
     case TRS_F_STATS: src = e->stats; need = sizeof e->stats; break;
+    case TRS_F_DEPTH: src = e->depth; need = n * e->H * e->W * 4; break;
+    case TRS_F_ROWDEPTH: src = e->rowdepth; need = (size_t)e->H * 4; break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
     if (!src) return fail(TRS_ERR_STATE, "field not available");

@@ -196,3 +196,21 @@ def test_full_size_1024_envs_properties(make_env):
     o.step_synthetic(64, 1)
     assert np.array_equal(img_full, o.fetch("img"))
     assert_state_equal(full, o, "1024 envs x 64 steps")
+
+
+# ---------------------------------------------------------------------------------------------- config 5 frame format
+
+def test_depth_channel_and_240x320(make_env):
+    """BASELINE config 5 frame format: 240x320 RGB + binary32 z-depth, bit-exact; depth is constant along a row."""
+    for (h, w, n) in ((240, 320, 9), (120, 160, 21)):
+        g = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True, auto_reset=True)
+        o = make_env("oracle", n_envs=n, img_h=h, img_w=w, depth=True, auto_reset=True)
+        assert np.array_equal(g.fetch("rowdepth"), o.fetch("rowdepth"))
+        for env in (g, o):
+            env.step_synthetic(37, 8)
+        assert np.array_equal(g.fetch("img"), o.fetch("img"))
+        dg, do = g.fetch("depth"), o.fetch("depth")
+        assert dg.shape == (n, h, w) and dg.dtype == np.float32
+        assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+        assert (dg == dg[:, :, :1]).all() and dg[0, 0, 0] == 40.0 and 0.7 < dg[0, -1, 0] < 1.0   # sky = z_far, nearest row ~0.84 units ahead
+        assert g.state_view().depth and not make_env("hip", n_envs=2).state_view().depth

@@ -17,7 +17,7 @@ class TrsConfig(C.Structure):
         ("struct_size", C.c_uint32),
         ("n_envs", C.c_int32), ("env_id_base", C.c_int32),
         ("img_h", C.c_int32), ("img_w", C.c_int32),
-        ("render", C.c_int32), ("auto_reset", C.c_int32), ("reserved0", C.c_int32),
+        ("render", C.c_int32), ("auto_reset", C.c_int32), ("depth", C.c_int32),
         ("seed", C.c_uint64),
         ("dt", C.c_float), ("max_steer", C.c_float), ("inv_wheelbase", C.c_float), ("accel_max", C.c_float),
         ("drag_lin", C.c_float), ("roll_res", C.c_float), ("brake_max", C.c_float),
@@ -37,6 +37,7 @@ class TrsStateView(C.Structure):
         ("yaw", C.c_void_p), ("vel", C.c_void_p), ("seg_idx", C.c_void_p),
         ("ep_return", C.c_void_p), ("last_return", C.c_void_p), ("ep_len", C.c_void_p), ("done", C.c_void_p),
         ("step_count", C.c_uint64),
+        ("depth", C.c_void_p),
     ]
 
 
@@ -62,7 +63,7 @@ class TrsPreConfig(C.Structure):
 FIELDS = {
     "img": 0, "pos_x": 1, "pos_y": 2, "pos_z": 3, "speed": 4, "cte": 5, "yaw": 6, "vel": 7,
     "seg_idx": 8, "ep_return": 9, "last_return": 10, "ep_len": 11, "done": 12,
-    "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17, "stats": 18,
+    "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17, "stats": 18, "depth": 19, "rowdepth": 20,
 }
 
 # every symbol include/trsim.h declares (suffix after the prefix)

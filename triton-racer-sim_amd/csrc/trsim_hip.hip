@@ -77,7 +77,8 @@ struct RParams {                        // raster kernel
     int n_envs, envs_per_wg;
     int H, W, gpr, gpe, rows_per_pass;  // gpr/gpe: 4-pixel groups per row / per env
     int map_w, map_h, map_pitch_b;
-    int off_rowtab, off_pal, blob_bytes;
+    int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
+    int depth;                          // 1 = also write the binary32 z-depth frame
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -196,6 +197,7 @@ struct SParams {
     PParams ph;                         // physics side (blob = px|py|pz|tan image; cam = ring base)
     RParams ra;                         // raster side
     uint8_t* img0; uint8_t* img1;       // frame of absolute step s goes to img[s & 1]
+    float* dep0; float* dep1;           // z-depth frames, same double buffering (NULL unless cfg.depth)
     int n_phys;                         // physics steps this launch advances (0 = raster-only flush)
     int r_first, r_last;                // raster renders launch-local steps r_first..r_last; -1 = the step before this
                                         // launch (camera parameters from the global ring, written by the previous launch)
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
+template <bool DEPTH>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
     const int tid = threadIdx.x;
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     // loop constants.  Per pixel: 1 packed fma (gx,gz), 2 saturating converts + 2 min (= floor + clamp), 3 address
     // ops, 1 LDS map read, shift + bit-field extract, 1 palette address op, 1 LDS palette read.
     const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
+    const float* lrowdepth = reinterpret_cast<const float*>(smem + p.off_depth);
     const float half_w = (float)(p.W / 2);
     const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
     const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (none at W = 160: 16 x 40 = 640)
@@ -485,6 +489,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
         const int col_off = cg * 12;
+        __amdgpu_buffer_rsrc_t drs = rsrc;
+        if constexpr (DEPTH) {
+            float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
+            drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+        }
         f2v rt = lrow[vstart < p.H ? vstart : 0];
         for (int v = vstart; v < p.H; v += p.rows_per_pass) {
             const int vn = v + p.rows_per_pass;
@@ -519,6 +528,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 #else
             const u3v px3 = {w0, w1, w2};
             __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
+            if constexpr (DEPTH) {   // z-depth is constant along a row of a ground-plane camera: 4 pixels = one 16-B store
+                const unsigned dz = __float_as_uint(lrowdepth[v]);
+                const u4v d4 = {dz, dz, dz, dz};
+                __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+            }
 #endif
             rt = rtn;
         }
@@ -696,6 +710,7 @@ struct trs_env {
     // device memory
     unsigned char* slab = nullptr;       // state + controls
     uint8_t* img[2] = {nullptr, nullptr};
+    float* depth[2] = {nullptr, nullptr};
     unsigned char* blob_p = nullptr;     // physics LDS image
     unsigned char* blob_r = nullptr;     // raster LDS image
     float* tangent = nullptr;
@@ -740,6 +755,7 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.ph.synth = synth; sp.ph.n_steps = n_phys; sp.ph.write_cam = 1; sp.ph.dev_step = nullptr; sp.ph.step_off = (uint32_t)step_base;
     sp.ra = e->rp;
     sp.img0 = e->img[0]; sp.img1 = e->img[1];
+    sp.dep0 = e->depth[0]; sp.dep1 = e->depth[1];
     sp.n_phys = n_phys; sp.r_first = r_first; sp.r_last = r_last;
     sp.step_base = (unsigned)step_base;
     sp.lds_off_phys = e->lds_off_phys;
@@ -747,7 +763,11 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
     sp.lds_off_prog = sp.lds_off_cam + std::max(n_phys, 1) * sp.cam_stride * 16;
     const int lds = sp.lds_off_prog + sp.cam_stride * 4;
-    hipLaunchKernelGGL(trs_step_kernel, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
+#ifndef TRS_SINGLE_VARIANT   /* A/B switch: build without the depth instantiation (HIP guide rule 19: co-compiled variants perturb each other) */
+    if (e->rp.depth) hipLaunchKernelGGL(trs_step_kernel<true>, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
+    else
+#endif
+    hipLaunchKernelGGL(trs_step_kernel<false>, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
@@ -866,12 +886,16 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
         for (int b = 0; b < 2; ++b) {
             HIPCHK(hipMalloc((void**)&e->img[b], e->img_bytes));
             HIPCHK(hipMemsetAsync(e->img[b], 0, e->img_bytes, e->sP));
+            if (cfg->depth) {
+                HIPCHK(hipMalloc((void**)&e->depth[b], n * (size_t)e->H * e->W * 4));
+                HIPCHK(hipMemsetAsync(e->depth[b], 0, n * (size_t)e->H * e->W * 4, e->sP));
+            }
         }
     }
     k.n_envs = e->n; k.env_id_base = cfg->env_id_base;
     k.envs_per_wg = (e->n + e->cu_count - 1) / e->cu_count;
     r.n_envs = e->n; r.envs_per_wg = k.envs_per_wg;
-    r.H = e->H; r.W = e->W; r.gpr = e->W / 4; r.gpe = r.gpr * e->H;
+    r.H = e->H; r.W = e->W; r.gpr = e->W / 4; r.gpe = r.gpr * e->H; r.depth = (cfg->render && cfg->depth) ? 1 : 0;
     k.dt = cfg->dt; k.max_steer = cfg->max_steer; k.inv_wheelbase = cfg->inv_wheelbase; k.accel_max = cfg->accel_max;
     k.drag_lin = cfg->drag_lin; k.roll_res = cfg->roll_res; k.brake_max = cfg->brake_max; k.v_max = cfg->v_max;
     k.v_rev_max = cfg->v_rev_max; k.offtrack_cte = cfg->offtrack_cte; k.offtrack_penalty = cfg->offtrack_penalty;
@@ -889,7 +913,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     if (!e) return TRS_OK;
     (void)hipSetDevice(e->device);
     if (e->sP) (void)hipStreamSynchronize(e->sP);
-    (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
+    (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->d_step);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
@@ -928,6 +952,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     size_t roff = align_up(map_bytes, 16);
     r.off_rowtab = (int)roff; roff += align_up((size_t)e->H * 8, 16);
     r.off_pal = (int)roff; roff += (size_t)e->H * 16;
+    r.off_depth = (int)roff; roff += align_up((size_t)e->H * 4, 16);
     r.blob_bytes = (int)roff;
     e->lds_r = (int)align_up(roff, 16);
     if ((size_t)r.blob_bytes > (size_t)kStageRegs * kRasterThreads * 16)
@@ -953,6 +978,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         std::memcpy(hr.data() + (size_t)row * r.map_pitch_b, T.map.data() + (size_t)row * T.info.map_words, (size_t)T.info.map_words * 4);
     std::memcpy(hr.data() + r.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
     std::memcpy(hr.data() + r.off_pal, T.palette.data(), (size_t)e->H * 16);
+    std::memcpy(hr.data() + r.off_depth, T.rowdepth.data(), (size_t)e->H * 4);
 
     (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
     e->blob_p = e->blob_r = nullptr; e->tangent = nullptr; e->start_yaw = nullptr;
@@ -975,7 +1001,10 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifndef TRS_SINGLE_VARIANT
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->pts_bytes));
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
     const size_t n = (size_t)e->n;
@@ -1058,6 +1087,7 @@ TRS_EXPORT int trs_get_state(trs_env* e, trs_state_view* o)
     o->pos_x = k.x; o->pos_y = k.y; o->pos_z = k.z; o->speed = k.speed; o->cte = k.cte; o->yaw = k.yaw; o->vel = k.v;
     o->seg_idx = k.seg_idx; o->ep_return = k.ep_return; o->last_return = k.last_return; o->ep_len = k.ep_len; o->done = k.done;
     o->step_count = e->step_count;
+    o->depth = (e->cfg.render && e->cfg.depth) ? e->depth[(e->step_count + 1) & 1] : nullptr;
     return TRS_OK;
 }
 
@@ -1084,6 +1114,8 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_DONE: src = k.done; need = n; break;
     case TRS_F_STEER_FILT: src = k.steer_filt; need = n * 4; break;
     case TRS_F_STATS: src = e->stats; need = 64 * sizeof(unsigned long long); break;
+    case TRS_F_DEPTH: src = (e->cfg.render && e->cfg.depth) ? e->depth[(e->step_count + 1) & 1] : nullptr; need = n * e->H * e->W * 4; break;
+    case TRS_F_ROWDEPTH: if (e->track_loaded) { src = e->blob_r + e->rp.off_depth; need = (size_t)e->H * 4; } break;
     // the tables live on the host exactly as built; their LDS images on the device are re-laid-out (pitched map)
     case TRS_F_MAP: if (e->track_loaded) { src = e->tab.map.data(); need = e->tab.map.size() * 4; host_src = true; } break;
     case TRS_F_ROWTAB: if (e->track_loaded) { src = e->blob_r + e->rp.off_rowtab; need = (size_t)e->H * 8; } break;

@@ -150,6 +150,7 @@ int build_tables(const trs_config& cfg, const double* xyz, int n_points, TrackTa
     const double cp = std::cos(pitch), sp = std::sin(pitch);
     T.rowtab.assign(2 * (size_t)H, 0.0f);
     T.palette.assign(4 * (size_t)H, 0u);
+    T.rowdepth.assign((size_t)H, (float)cfg.z_far);
     for (int v = 0; v < H; ++v) {
         const double yn = (half_h - ((double)v + 0.5)) / f;
         const double dy = yn * cp - sp, dz = yn * sp + cp;
@@ -172,6 +173,7 @@ int build_tables(const trs_config& cfg, const double* xyz, int n_points, TrackTa
             } else {
                 T.rowtab[2 * v] = (float)(fwd / cell);
                 T.rowtab[2 * v + 1] = (float)((t / f) / cell);
+                T.rowdepth[v] = (float)fwd;
                 const double fw = TRS_FOG_MAX * (fwd / cfg.z_far);
                 for (int c = 0; c < 4; ++c)
                     for (int ch = 0; ch < 3; ++ch)

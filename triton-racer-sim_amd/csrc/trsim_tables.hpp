@@ -23,6 +23,7 @@ struct TrackTables {
     trs_map_info info{};
     std::vector<uint32_t> map;             // [map_h][map_words], 16 cells per word, cell ix at bits 2*(ix&15)
     std::vector<float> rowtab;             // [H][2]
+    std::vector<float> rowdepth;           // [H] z-depth of the ground plane per image row (z_far for sky / far rows)
     std::vector<uint32_t> palette;         // [H][4] 0x00BBGGRR
     float map_x0f = 0, map_z0f = 0, inv_cellf = 0;
 };

@@ -20,7 +20,7 @@ _FIELD_DTYPES = {
     "img": np.uint8, "pos_x": np.float32, "pos_y": np.float32, "pos_z": np.float32, "speed": np.float32,
     "cte": np.float32, "yaw": np.float32, "vel": np.float32, "seg_idx": np.int32, "ep_return": np.float32,
     "last_return": np.float32, "ep_len": np.int32, "done": np.uint8, "map": np.uint32, "rowtab": np.float32,
-    "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32, "stats": np.uint64,
+    "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32, "stats": np.uint64, "depth": np.float32, "rowdepth": np.float32,
 }
 
 
@@ -57,14 +57,14 @@ class _DevicePtr:
 
 class BatchedEnv:
     def __init__(self, n_envs=1, track="generated_track", device=0, img_h=120, img_w=160, render=True,
-                 auto_reset=False, env_id_base=0, seed=None, _api=None, **overrides):
+                 auto_reset=False, env_id_base=0, seed=None, depth=False, _api=None, **overrides):
         # `_api` exists for tests only (they pass the oracle's function table to diff both through one
         # wrapper); the product path always binds the HIP library and raises if it is not built.
         self.api = _api if _api is not None else _ffi.load_hip_library()
         cfg = _ffi.TrsConfig()
         self.api.default_config(C.byref(cfg))
         cfg.n_envs, cfg.env_id_base, cfg.img_h, cfg.img_w = int(n_envs), int(env_id_base), int(img_h), int(img_w)
-        cfg.render, cfg.auto_reset = int(bool(render)), int(bool(auto_reset))
+        cfg.render, cfg.auto_reset, cfg.depth = int(bool(render)), int(bool(auto_reset)), int(bool(depth))
         if seed is not None:
             cfg.seed = int(seed)
         for k, v in overrides.items():
@@ -143,7 +143,7 @@ class BatchedEnv:
         mi = self.map_info
         return {
             "img": (self.n, self.H, self.W, 3), "map": (mi.map_h, mi.map_words) if mi else None,
-            "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2), "stats": (64,),
+            "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2), "stats": (64,), "depth": (self.n, self.H, self.W), "rowdepth": (self.H,),
         }.get(name, (self.n,))
 
     def fetch(self, name):
