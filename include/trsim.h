@@ -184,6 +184,42 @@ int trs_preprocess_host(trs_env* env, const trs_pre_config* cfg, const uint8_t* 
 int trs_normalize(trs_env* env, const uint8_t* d_src, float* d_dst, int n_images);
 int trs_normalize_host(trs_env* env, const uint8_t* h_src, float* h_dst, int n_images);
 
+/* ---- pilot in the loop: cnn_2d_speed_control (BASELINE config 5) ---- */
+
+/* Post-processing constants of KerasPilot (components/keras_pilot.py:31-38; core/config.py:65-66,76-80). */
+typedef struct trs_pilot_config {
+    uint32_t struct_size;
+    float   spd_ctl_threshold;            /* 1.1 */
+    int32_t spd_ctl_break;                /* 0: reverse throttle when overspeeding; 1: brake instead (keras_pilot.py:88-90) */
+    float   spd_ctl_reverse_multiplier;   /* 1.0 */
+    float   spd_ctl_break_multiplier;     /* 1.0 */
+    int32_t smooth_steering_enabled;      /* keras_pilot.py:147-153 */
+    float   smooth_steering_threshold;    /* 0.9 */
+} trs_pilot_config;
+
+void trs_default_pilot_config(trs_pilot_config* cfg);
+
+/* Load the weights of Keras_2D_CNN.get_model(input_shape=(img_h,img_w,3), num_outputs=2) (components/keras_train.py:127-174,
+ * selected for cnn_2d_speed_control at :393-395): 11 layers, in order conv1..conv7, dense1, dense2, dense3, output_layer;
+ * h_arrays[2*i] = kernel in Keras layout ([KH][KW][CIN][COUT] / [IN][OUT], float32), h_arrays[2*i+1] = bias.  Replaces
+ * load_model(model_path) (components/keras_pilot.py:26); weights are rounded to bfloat16 for the MFMA convolutions. */
+int trs_pilot_load(trs_env* env, const float* const* h_arrays, int n_arrays);
+
+/* model(img_arr) of KerasPilot.step (keras_pilot.py:49-55,81): uint8 frames -> raw outputs float[n_images][2]
+ * (steering, speed/20).  d_frames NULL = the env's latest frames (n_images == n_envs). */
+int trs_pilot_forward(trs_env* env, const uint8_t* d_frames, int n_images, float* d_out);
+int trs_pilot_forward_host(trs_env* env, const uint8_t* h_frames, int n_images, float* h_out);
+
+/* Activations of one layer of the last forward pass as float32 (tests): layer 0..6 = conv1..conv7 output
+ * [n][OH][OW][C], 7 = dense1 [n][100]. */
+int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats);
+
+/* Closed loop for n_steps (the reference's tick order, car_templates/manage.py:46-75: the pilot acts on the frame the
+ * sim stored on the previous tick): controls = KerasPilot.step(frame, speed) for ModelType.CNN_2D_SPD_CTL
+ * (keras_pilot.py:78-95: cap steering, predicted speed x 20, calcThrottle / calcBreak of utils/mapping.py:23-35),
+ * then one env step with those controls.  Before the first frame exists the controls are (0, 0, 0) (keras_pilot.py:46-47). */
+int trs_step_pilot(trs_env* env, const trs_pilot_config* cfg, int n_steps);
+
 /* stream control + device-side timing (HIP events on the handle's stream) */
 int trs_sync(trs_env* env);
 int trs_event_record(trs_env* env, int slot);                 /* slot 0..7 */

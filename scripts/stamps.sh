@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 C=triton-racer-sim_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ffp-contract=off -fno-fast-math -DTRS_STAMPS=1 -o /tmp/libtrsim_stamps.so $C/trsim_hip.hip $C/trsim_tables.cpp 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ffp-contract=off -fno-fast-math -DTRS_STAMPS=1 -o /tmp/libtrsim_stamps.so $C/trsim_hip.hip $C/trsim_pilot.hip $C/trsim_tables.cpp 2>/dev/null
 TRS_HIP_LIB=/tmp/libtrsim_stamps.so python - "$@" <<'PY'
 import sys, numpy as np
 sys.path.insert(0, '.')

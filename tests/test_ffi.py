@@ -17,7 +17,7 @@ def header_functions():
 
 
 def test_header_declares_what_the_binding_binds():
-    assert header_functions() == sorted("trs_" + s for s in _ffi.SYMBOLS)
+    assert header_functions() == sorted("trs_" + s for s in _ffi.SYMBOLS + _ffi.PILOT_SYMBOLS)
 
 
 def test_hip_library_exports_every_symbol():
@@ -29,6 +29,7 @@ def test_hip_library_exports_every_symbol():
 def test_oracle_exports_the_same_abi(oracle_api):
     for s in _ffi.SYMBOLS:
         assert hasattr(oracle_api.cdll, "trso_" + s), s
+    assert not oracle_api.has_pilot        # the CNN's checker is a PyTorch fp32 reference (tests/test_pilot.py), not the C oracle
 
 
 def test_struct_layouts_match_c(oracle_api, hip_api):

@@ -1,0 +1,153 @@
+"""cnn_2d_speed_control in the loop.  The checker for this floating-point kernel is a plain PyTorch
+fp32 restatement of the reference's architecture (components/keras_train.py:127-174: conv 5x5/2 x3, conv 3x3 x4,
+'valid', ReLU; NHWC flatten; dense 100/50/25 ReLU; linear 2) and of KerasPilot's post-processing
+(components/keras_pilot.py:78-95, utils/mapping.py:23-35).  The HIP path uses bf16 operands with fp32 accumulation and
+stores activations as bf16, so two references are used:
+  * "mirror", layer by layer: fp32 math on bf16-rounded weights, fed the kernel's own previous activation — differs from
+    the kernel only by fp32 summation order, which can move a value across a bf16 rounding boundary: per element
+    |got - ref| <= 2^-7 |ref| + 1e-3 (one bf16 ulp is up to 2^-7 relative at the bottom of a binade, + an absolute floor)
+    and fewer than 1 % of the elements differ at all;
+  * "pure": fp32 everywhere (what TensorFlow would compute): tolerance 5e-2 on the two outputs."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SPEC = [(5, 2, 3, 24), (5, 2, 24, 32), (5, 2, 32, 64), (3, 1, 64, 64), (3, 1, 64, 64), (3, 1, 64, 128), (3, 1, 128, 128)]
+
+
+def make_weights(h, w, seed=0):
+    """Glorot-uniform kernels (Keras default), small random biases; Keras layouts."""
+    rng = np.random.default_rng(seed)
+    ws = []
+    ih, iw = h, w
+    for k, s, cin, cout in SPEC:
+        lim = math.sqrt(6.0 / (k * k * cin + k * k * cout))
+        ws += [rng.uniform(-lim, lim, (k, k, cin, cout)).astype(np.float32), rng.uniform(-0.05, 0.05, cout).astype(np.float32)]
+        ih, iw = (ih - k) // s + 1, (iw - k) // s + 1
+    dims = [ih * iw * 128, 100, 50, 25, 2]
+    for a, b in zip(dims[:-1], dims[1:]):
+        lim = math.sqrt(6.0 / (a + b))
+        ws += [rng.uniform(-lim, lim, (a, b)).astype(np.float32), rng.uniform(-0.05, 0.05, b).astype(np.float32)]
+    return ws
+
+
+def torch_layer(i, x_nhwc, ws, mirror=True):
+    """Layer i (0..6 conv, 7 dense1) of the reference architecture in fp32 on an NHWC input; with ``mirror`` the weights are
+    rounded to bf16 (conv1's are divided by 255 first, as the kernel folds the pilot's /255 into them) and so is the output."""
+    import torch
+    import torch.nn.functional as F
+    bf = (lambda t: t.bfloat16().float()) if mirror else (lambda t: t)
+    x = torch.from_numpy(np.ascontiguousarray(x_nhwc, dtype=np.float32))
+    if i == 7:
+        z = F.relu(x.reshape(x.shape[0], -1) @ bf(torch.from_numpy(ws[14])) + torch.from_numpy(ws[15]))     # Keras Flatten on NHWC
+        return z.numpy()
+    k, s, cin, cout = SPEC[i]
+    wk = torch.from_numpy(ws[2 * i])
+    if i == 0:
+        if mirror:
+            wk = wk / 255.0
+        else:
+            x = x / 255.0                                               # keras_pilot.py:49-50
+    wk = bf(wk).permute(3, 2, 0, 1).contiguous()
+    y = F.relu(F.conv2d(x.permute(0, 3, 1, 2), wk, torch.from_numpy(ws[2 * i + 1]), stride=s))
+    return bf(y).permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def torch_tail(h1, ws):
+    import torch
+    import torch.nn.functional as F
+    z = torch.from_numpy(h1)
+    z = F.relu(z @ torch.from_numpy(ws[16]) + torch.from_numpy(ws[17]))
+    z = F.relu(z @ torch.from_numpy(ws[18]) + torch.from_numpy(ws[19]))
+    return (z @ torch.from_numpy(ws[20]) + torch.from_numpy(ws[21])).numpy()
+
+
+def torch_pure(frames, ws):
+    x = frames
+    for i in range(8):
+        x = torch_layer(i, x, ws, mirror=False)
+    return torch_tail(x, ws)
+
+
+def pilot_postprocess(out, speed, cfg):
+    """KerasPilot.step, ModelType.CNN_2D_SPD_CTL (keras_pilot.py:78-95) with the reference's scalar helpers restated."""
+    steer = float(min(max(out[0], -1.0), 1.0))
+    pred = float(out[1]) * 20
+    thr = cfg.get("spd_ctl_reverse_multiplier", 1.0) * math.atan((pred * cfg.get("spd_ctl_threshold", 1.1) - speed) * 2) / (math.pi / 2)
+    if -0.2 < thr < 0.0:
+        thr = 0.0
+    brk = 0.0
+    if cfg.get("spd_ctl_break", False):
+        thr = 1.0 if pred - speed > 0.0 else 0.0
+        brk = -1.0 * cfg.get("spd_ctl_break_multiplier", 1.0) * math.atan((pred * cfg.get("spd_ctl_threshold", 1.1) - speed) * 1.0) / (math.pi / 2)
+        if brk < 0.4:
+            brk = 0.0
+    return steer, thr, brk
+
+
+@pytest.mark.parametrize("size", [(120, 160), (240, 320)])
+def test_forward_matches_torch_fp32(make_env, size):
+    h, w = size
+    n = 6
+    env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+    ws = make_weights(h, w, seed=3)
+    env.pilot_load(ws)
+    env.step_synthetic(12, 1)
+    frames = env.fetch("img")
+    rng = np.random.default_rng(0)
+    frames = np.concatenate([frames[:4], rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)])     # rendered + noise frames
+    out = env.pilot_forward_host(frames)
+    # layer by layer: the torch layer is fed the kernel's OWN previous activation, so the only difference left is the fp32
+    # summation order, which can flip the final bf16 rounding of an element by one ulp (up to 2^-7 relative)
+    x, shape = frames, None
+    for layer in range(8):
+        want = torch_layer(layer, x, ws)
+        got = env.pilot_layer(layer, want.shape)
+        diff = np.abs(got - want)
+        assert (diff <= 2.0 ** -7 * np.abs(want) + 1e-3).all(), f"layer {layer}: worst {float(diff.max())}"
+        assert np.mean(diff > 1e-6) < 0.01, f"layer {layer}: {100 * np.mean(diff > 1e-6):.2f}% of the elements differ"
+        x = got
+    assert np.max(np.abs(out - torch_tail(x, ws))) <= 1e-4          # fp32 tail on identical inputs
+    pure = torch_pure(frames, ws)                                     # fp32 everywhere: bounds the total bf16 effect
+    assert np.max(np.abs(out - pure)) <= 5e-2, float(np.max(np.abs(out - pure)))
+    assert np.std(out[:, 0]) > 1e-4                                  # the outputs do depend on the frame
+
+
+def test_closed_loop_controls_follow_the_reference_tick_order(make_env):
+    """trs_step_pilot == [controls = post(model(previous frame), speed); env.step(controls)] done by hand, and the
+    first tick uses (0, 0, 0) because no frame exists yet (keras_pilot.py:46-47)."""
+    n = 16
+    ws = make_weights(120, 160, seed=5)
+    cfg = {"spd_ctl_threshold": 1.1, "spd_ctl_reverse_multiplier": 1.0}
+    a = make_env("hip", n_envs=n)
+    b = make_env("hip", n_envs=n)
+    a.pilot_load(ws); b.pilot_load(ws)
+    a.step_pilot(6, cfg)
+    b.step(0.0, 0.0, 0.0)                                            # tick 1: no frame yet
+    for _ in range(5):
+        out = b.pilot_forward_host(b.fetch("img"))
+        spd = b.fetch("speed")
+        ctl = np.array([pilot_postprocess(out[i], float(spd[i]), cfg) for i in range(n)], dtype=np.float32)
+        b.step(ctl[:, 0], ctl[:, 1], ctl[:, 2])
+    for name in ("pos_x", "pos_z", "yaw", "speed"):
+        assert np.max(np.abs(a.fetch(name) - b.fetch(name))) <= 1e-4, name   # float atan on device vs math.atan: ~1e-7 per tick
+    assert np.array_equal(a.fetch("seg_idx"), b.fetch("seg_idx"))
+    assert np.array_equal(a.fetch("img"), b.fetch("img"))
+
+
+def test_break_mode_and_errors(make_env):
+    env = make_env("hip", n_envs=4)
+    with pytest.raises(RuntimeError, match="no pilot loaded"):
+        env.step_pilot(1)
+    with pytest.raises(RuntimeError, match="22 arrays"):
+        env.pilot_load(make_weights(120, 160)[:10])
+    env.pilot_load(make_weights(120, 160, seed=1))
+    env.step_pilot(4, {"spd_ctl_break": True, "smooth_steering_enabled": True, "smooth_steering_threshold": 0.0})
+    assert env.fetch("ep_len").max() >= 2
+    with pytest.raises(RuntimeError, match="camera"):
+        phys = make_env("hip", n_envs=2, render=False)
+        phys.pilot_load(make_weights(120, 160))
+        phys.step_pilot(1)

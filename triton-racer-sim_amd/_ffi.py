@@ -75,6 +75,18 @@ SYMBOLS = [
 ]
 
 
+class TrsPilotConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("spd_ctl_threshold", C.c_float), ("spd_ctl_break", C.c_int32),
+        ("spd_ctl_reverse_multiplier", C.c_float), ("spd_ctl_break_multiplier", C.c_float),
+        ("smooth_steering_enabled", C.c_int32), ("smooth_steering_threshold", C.c_float),
+    ]
+
+
+# HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
+PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_debug_layer", "step_pilot"]
+
+
 class Api:
     """Typed function table of one loaded library (``trs_*`` for HIP, ``trso_*`` for the test oracle)."""
 
@@ -106,10 +118,24 @@ class Api:
             "normalize": (i32, [vp, vp, vp, i32]),
             "normalize_host": (i32, [vp, vp, vp, i32]),
         }
+        pilot = {
+            "default_pilot_config": (None, [C.POINTER(TrsPilotConfig)]),
+            "pilot_load": (i32, [vp, C.POINTER(C.c_void_p), i32]),
+            "pilot_forward": (i32, [vp, vp, i32, vp]),
+            "pilot_forward_host": (i32, [vp, vp, i32, vp]),
+            "pilot_debug_layer": (i32, [vp, i32, vp, C.c_size_t]),
+            "step_pilot": (i32, [vp, C.POINTER(TrsPilotConfig), i32]),
+        }
         for name, (res, args) in sigs.items():
             fn = getattr(cdll, prefix + name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)
+        self.has_pilot = hasattr(cdll, prefix + "pilot_load")
+        if self.has_pilot:
+            for name, (res, args) in pilot.items():
+                fn = getattr(cdll, prefix + name)
+                fn.restype, fn.argtypes = res, args
+                setattr(self, name, fn)
 
     def check(self, rc, what):
         if rc != 0:

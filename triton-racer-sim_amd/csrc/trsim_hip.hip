@@ -32,6 +32,7 @@
 
 #include "../../include/trsim.h"
 #include "../../include/trsim_spec.h"
+#include "trsim_internal.hpp"
 #include "trsim_tables.hpp"
 
 #ifndef TRS_ABLATE
@@ -732,6 +733,7 @@ struct trs_env {
     uint8_t* ctl_reset = nullptr;
     size_t img_bytes = 0;
     int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
+    void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
 };
 
 namespace {
@@ -913,6 +915,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     if (!e) return TRS_OK;
     (void)hipSetDevice(e->device);
     if (e->sP) (void)hipStreamSynchronize(e->sP);
+    if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->d_step);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
@@ -1355,3 +1358,18 @@ TRS_EXPORT int trs_event_elapsed_ms(trs_env* e, int a, int b, float* ms)
 }
 
 TRS_EXPORT const char* trs_last_error(void) { return g_err.c_str(); }
+
+// ---- internal accessors for trsim_pilot.hip (not exported) ----------------------------------------------
+bool trs_internal_view(trs_env* e, TrsEnvView* v)
+{
+    if (!e || !v) return false;
+    v->device = e->device; v->n = e->n; v->H = e->H; v->W = e->W; v->render = e->cfg.render;
+    v->stream = e->sP;
+    v->latest_frame = (e->cfg.render && e->step_count > 0) ? e->img[(e->step_count + 1) & 1] : nullptr;
+    v->speed = e->pp.speed;
+    v->ctl_steer = e->ctl_steer; v->ctl_thr = e->ctl_thr; v->ctl_brk = e->ctl_brk;
+    v->step_count = e->step_count;
+    return true;
+}
+void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
+int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }

@@ -1,0 +1,22 @@
+// trsim_internal.hpp — what trsim_pilot.hip needs from the env handle defined in trsim_hip.hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/trsim.h"
+
+struct TrsEnvView {
+    int device, n, H, W, render;
+    hipStream_t stream;
+    const uint8_t* latest_frame;      // uint8[n][H][W][3] of the last completed step, or nullptr
+    const float* speed;               // 'gym/speed'
+    float *ctl_steer, *ctl_thr, *ctl_brk;   // the handle's own control staging arrays (device)
+    uint64_t step_count;
+};
+
+bool trs_internal_view(trs_env* e, TrsEnvView* out);
+void** trs_internal_pilot_slot(trs_env* e);
+int trs_internal_fail(int code, const std::string& msg);
+void trs_pilot_free(void* ctx);       // defined in trsim_pilot.hip, called by trs_destroy

@@ -1,0 +1,473 @@
+// trsim_pilot.hip — cnn_2d_speed_control in the loop (BASELINE config 5).
+//
+// Model: Keras_2D_CNN.get_model(input_shape, num_outputs=2) of the reference
+// (TritonRacerSim/components/keras_train.py:127-174, chosen for cnn_2d_speed_control at :393-395): conv 5x5/2 x3
+// (24, 32, 64), conv 3x3/1 x4 (64, 64, 128, 128), all 'valid' + ReLU, flatten (NHWC order), dense 100/50/25 + ReLU,
+// linear output 2.  Dropout is identity at inference.  57.8 M MAC per 120x160 frame.
+//
+// Convolutions are implicit GEMMs on the matrix cores, one kernel for every layer:
+//   C[pixel][cout] = sum_k A[pixel][k] * B[k][cout],  k = (kh, kw, cin) cut into granules of 8 input channels
+//   v_mfma_f32_32x32x16_bf16: a wave owns 32 output pixels x all (padded) output channels; per 16-deep k-step the
+//   lane (row r = lane & 31, half h = lane >> 5) needs A[r][8h .. 8h+7] = ONE granule = one 16-byte load straight
+//   from the NHWC bf16 activation in global memory (no im2col buffer, no LDS for A); B granules [g][cout][8] are
+//   staged per workgroup in LDS in exactly the fragment order, so a B fragment is one ds_read_b128.
+//   conv1 reads the uint8 frame directly: a k-step is one kernel row = 15 contiguous bytes (5 px x RGB) + 1 pad,
+//   fetched with 3 aligned dwords + v_alignbyte, converted exactly to bf16; the 1/255 of the pilot's normalisation
+//   (components/keras_pilot.py:49-50) is folded into conv1's weights.
+//   dense1 (4608 -> 100) is the same kernel as a 1x1 convolution over "pixels" = frames.
+// The fp32 tail (dense2, dense3, output) and KerasPilot's post-processing (keras_pilot.py:78-95; calcThrottle /
+// calcBreak of utils/mapping.py:23-35) run in one small kernel that writes the env's next controls.
+//
+// Numerics: bf16 operands, fp32 accumulate, activations stored as bf16 — checked against a PyTorch fp32 reference
+// with the same bf16-rounded weights (tests/test_pilot.py, tolerance stated there).  Bound: MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/trsim.h"
+#include "trsim_internal.hpp"
+
+#define TRS_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+constexpr int kConvBlock = 256;           // 4 waves x 32 output pixels = 128 GEMM rows per workgroup
+constexpr int kRowsPerWg = 128;
+constexpr int kLayers = 11;               // conv1..7, dense1..3, output
+constexpr int kLdsWeightBytes = 64 * 1024;
+
+struct ConvParams {
+    const void* in;            // bf16 NHWC [N][IH][IW][CIN]   (conv1: uint8 [N][IH][IW][3])
+    const u4v* w;              // [G_pad][COUT_PAD] granules of 8 bf16
+    const float* bias;         // [COUT_PAD]
+    const int* goff;           // [G_pad] byte offset of granule g relative to the output pixel's input base
+    void* out;                 // bf16 NHWC [N][OH][OW][COUT]  or float when out_f32
+    int in_bytes;              // size of `in` (buffer-load bounds)
+    int N, IH, IW, CIN, OH, OW, COUT, COUT_PAD, S;
+    int G, G_pad, M;           // granules (even-padded), GEMM rows = N*OH*OW
+    int gchunk;                // granules per LDS stage (even)
+    int relu, out_f32, in_px_bytes;   // in_px_bytes: bytes per input pixel (CIN*2, conv1: 3)
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{   // round to nearest even (inputs are finite)
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <int NB, bool U8IN>
+__global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [gchunk][COUT_PAD] granules
+    int* lgoff = reinterpret_cast<int*>(psmem + (size_t)p.gchunk * p.COUT_PAD * 16);   // [G_pad]
+    for (int i = tid; i < p.G_pad; i += kConvBlock) lgoff[i] = p.goff[i];
+
+    // GEMM row of this lane for the A operand: one output pixel
+    const int m = blockIdx.x * kRowsPerWg + wave * 32 + r;
+    const int mm = min(m, p.M - 1);
+    const int ohw = p.OH * p.OW;
+    const int n = mm / ohw, rem = mm - n * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+    const int pixbase = ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const float b = p.bias[nb * 32 + r];                                // C/D layout: column = lane & 31 in every register
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = b;
+    }
+
+    for (int c0 = 0; c0 < p.G_pad; c0 += p.gchunk) {
+        const int gc = min(p.gchunk, p.G_pad - c0);
+        __syncthreads();                                                    // previous chunk fully consumed (and lgoff written)
+        for (int i = tid; i < gc * p.COUT_PAD; i += kConvBlock) lw[i] = p.w[(size_t)c0 * p.COUT_PAD + i];
+        __syncthreads();
+        for (int g2 = 0; g2 < gc; g2 += 2) {
+            const int g = c0 + g2 + h;                                      // this lane's granule of the k-step
+            bf16x8 a;
+            if constexpr (U8IN) {
+                // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords + alignbyte
+                const int addr = pixbase + lgoff[g];
+                const int al = addr & ~3, sh = addr & 3;
+                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
+                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
+                const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
+                const unsigned lo = sh ? ((w0 >> (8 * sh)) | (w1 << (32 - 8 * sh))) : w0;
+                const unsigned hi = sh ? ((w1 >> (8 * sh)) | (w2 << (32 - 8 * sh))) : w1;
+                unsigned short e[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] = (unsigned short)(__float_as_uint((float)((lo >> (8 * j)) & 255u)) >> 16);       // 0..255 is exact in bf16
+                    e[4 + j] = (unsigned short)(__float_as_uint((float)((hi >> (8 * j)) & 255u)) >> 16);
+                }
+                const u4v packed = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
+                a = __builtin_bit_cast(bf16x8, packed);
+            } else {
+                const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
+                a = __builtin_bit_cast(bf16x8, raw);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, lw[(g2 + h) * p.COUT_PAD + nb * 32 + r]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int row0 = blockIdx.x * kRowsPerWg + wave * 32;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = nb * 32 + r;
+        if (col >= p.COUT) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row >= p.M) continue;
+            float v = acc[nb][i];
+            if (p.relu) v = v > 0.0f ? v : 0.0f;
+            if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
+            else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2bf(v);
+        }
+    }
+}
+
+// dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
+struct TailParams {
+    const float* h1;           // [n][100] dense1 output (after ReLU), fp32
+    const float *w2, *b2, *w3, *b3, *w4, *b4;    // Keras layouts [IN][OUT]
+    float* raw_out;            // [n][2] or nullptr
+    const float* speed;        // 'gym/speed' or nullptr (no post-processing)
+    float *steer, *thr, *brk;  // next controls
+    int n, act;
+    float threshold, rev_mult, brk_mult, smooth_thr;
+    int use_break, smooth;
+};
+
+__global__ __launch_bounds__(64) void trs_pilot_tail_kernel(const TailParams p)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= p.n) return;
+    float a1[100], a2[50], a3[25];
+    for (int k = 0; k < 100; ++k) a1[k] = p.h1[(size_t)i * 100 + k];
+    for (int o = 0; o < 50; ++o) { float s = p.b2[o]; for (int k = 0; k < 100; ++k) s = fmaf(a1[k], p.w2[k * 50 + o], s); a2[o] = s > 0.f ? s : 0.f; }
+    for (int o = 0; o < 25; ++o) { float s = p.b3[o]; for (int k = 0; k < 50; ++k) s = fmaf(a2[k], p.w3[k * 25 + o], s); a3[o] = s > 0.f ? s : 0.f; }
+    float out[2];
+    for (int o = 0; o < 2; ++o) { float s = p.b4[o]; for (int k = 0; k < 25; ++k) s = fmaf(a3[k], p.w4[k * 2 + o], s); out[o] = s; }
+    if (p.raw_out) { p.raw_out[2 * i] = out[0]; p.raw_out[2 * i + 1] = out[1]; }
+    if (!p.act) return;
+    float steering = out[0] < -1.0f ? -1.0f : (out[0] > 1.0f ? 1.0f : out[0]);     // __cap (keras_pilot.py:142-145)
+    const float predicted = out[1] * 20.0f;                                         // :83
+    const float real = p.speed[i];
+    const float kHalfPi = 1.57079632679489661923f;
+    float delta = predicted * p.threshold - real;                                   // calcThrottle (mapping.py:23-28)
+    float throttle = p.rev_mult * atanf(delta * 2.0f) / kHalfPi;
+    if (throttle > -0.2f && throttle < 0.0f) throttle = 0.0f;
+    float breaking = 0.0f;
+    if (p.use_break) {                                                              // keras_pilot.py:88-90, mapping.py:30-35
+        throttle = (predicted - real > 0.0f) ? 1.0f : 0.0f;
+        breaking = -1.0f * p.brk_mult * atanf(delta * 1.0f) / kHalfPi;
+        if (breaking < 0.4f) breaking = 0.0f;
+    }
+    if (p.smooth) {                                                                 // keras_pilot.py:147-153
+        if (steering > p.smooth_thr) steering = 1.0f;
+        else if (steering < -p.smooth_thr) steering = -1.0f;
+    }
+    p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
+}
+
+__global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0.f; b[i] = 0.f; c[i] = 0.f; }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) return trs_internal_fail(TRS_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct ConvLayer {
+    int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad, gchunk, lds;
+    bool u8in, out_f32, relu;
+    u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
+};
+
+struct PilotCtx {
+    int n_cap = 0, H = 0, W = 0;
+    ConvLayer L[8];                       // conv1..7 + dense1 (1x1 "conv" over frames)
+    void* act[8] = {};                    // outputs of L[i] for n_cap frames (bf16; act[7] float)
+    size_t act_elems[8] = {};             // per frame
+    float *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr, *w4 = nullptr, *b4 = nullptr;
+    float* raw = nullptr;                 // [n_cap][2]
+    uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
+    int last_n = 0;
+};
+
+unsigned short host_f2bf(float f)
+{
+    uint32_t u; std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+void free_ctx(PilotCtx* c)
+{
+    if (!c) return;
+    for (auto& l : c->L) { (void)hipFree(l.w); (void)hipFree(l.bias); (void)hipFree(l.goff); }
+    for (auto& a : c->act) (void)hipFree(a);
+    (void)hipFree(c->w2); (void)hipFree(c->b2); (void)hipFree(c->w3); (void)hipFree(c->b3); (void)hipFree(c->w4); (void)hipFree(c->b4);
+    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames);
+    delete c;
+}
+
+template <typename T>
+int upload(T** dst, const std::vector<T>& v)
+{
+    HIPCHK(hipMalloc((void**)dst, v.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TRS_OK;
+}
+
+int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s)
+{
+    ConvParams p{};
+    p.in = in; p.w = l.w; p.bias = l.bias; p.goff = l.goff; p.out = out;
+    if (in_bytes > 0x7FFFFFFFull) return trs_internal_fail(TRS_ERR_LIMIT, "activation larger than 2 GiB: lower the batch");
+    p.in_bytes = (int)in_bytes;
+    p.N = n_img; p.IH = l.IH; p.IW = l.IW; p.CIN = l.CIN; p.OH = l.OH; p.OW = l.OW; p.COUT = l.COUT; p.COUT_PAD = l.COUT_PAD; p.S = l.S;
+    p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
+    p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
+    const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
+    const int nb = l.COUT_PAD / 32;
+#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid), dim3(kConvBlock), l.lds, s, p)
+    if (l.u8in) LAUNCH(1, true);
+    else if (nb == 1) LAUNCH(1, false);
+    else if (nb == 2) LAUNCH(2, false);
+    else LAUNCH(4, false);
+#undef LAUNCH
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
+{
+    const void* in = d_frames;
+    size_t in_bytes = (size_t)n * c->H * c->W * 3;
+    for (int i = 0; i < 8; ++i) {
+        int rc = launch_conv(c->L[i], in, in_bytes, c->act[i], i == 7 ? n : n, v.stream);
+        if (rc) return rc;
+        in = c->act[i];
+        in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
+    }
+    c->last_n = n;
+    return TRS_OK;
+}
+
+int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act)
+{
+    TailParams t{};
+    t.h1 = static_cast<const float*>(c->act[7]);
+    t.w2 = c->w2; t.b2 = c->b2; t.w3 = c->w3; t.b3 = c->b3; t.w4 = c->w4; t.b4 = c->b4;
+    t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
+    if (act) {
+        t.speed = v.speed; t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
+        t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
+        t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
+    }
+    hipLaunchKernelGGL(trs_pilot_tail_kernel, dim3((n + 63) / 64), dim3(64), 0, v.stream, t);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+}  // namespace
+
+void trs_pilot_free(void* ctx) { free_ctx(static_cast<PilotCtx*>(ctx)); }
+
+TRS_EXPORT void trs_default_pilot_config(trs_pilot_config* c)
+{
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = (uint32_t)sizeof *c;
+    c->spd_ctl_threshold = 1.1f; c->spd_ctl_break = 0; c->spd_ctl_reverse_multiplier = 1.0f; c->spd_ctl_break_multiplier = 1.0f;
+    c->smooth_steering_enabled = 0; c->smooth_steering_threshold = 0.9f;
+}
+
+TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    if (!arr || n_arrays != 2 * kLayers) return trs_internal_fail(TRS_ERR_ARG, "expected 22 arrays: kernel and bias of conv1..conv7, dense1..dense3, output_layer");
+    for (int i = 0; i < n_arrays; ++i) if (!arr[i]) return trs_internal_fail(TRS_ERR_ARG, "null weight array");
+    HIPCHK(hipSetDevice(v.device));
+    void** slot = trs_internal_pilot_slot(e);
+    if (*slot) { HIPCHK(hipStreamSynchronize(v.stream)); free_ctx(static_cast<PilotCtx*>(*slot)); *slot = nullptr; }
+    PilotCtx* c = new PilotCtx();
+    c->n_cap = v.n; c->H = v.H; c->W = v.W;
+    static const int spec[7][4] = {{5, 2, 3, 24}, {5, 2, 24, 32}, {5, 2, 32, 64}, {3, 1, 64, 64}, {3, 1, 64, 64}, {3, 1, 64, 128}, {3, 1, 128, 128}};
+    int ih = v.H, iw = v.W;
+    for (int i = 0; i < 8; ++i) {
+        ConvLayer& l = c->L[i];
+        if (i < 7) { l.KH = l.KW = spec[i][0]; l.S = spec[i][1]; l.CIN = spec[i][2]; l.COUT = spec[i][3]; l.IH = ih; l.IW = iw; }
+        else { l.KH = l.KW = 1; l.S = 1; l.CIN = ih * iw * 128; l.COUT = 100; l.IH = 1; l.IW = 1; }     // dense1 over the NHWC flatten
+        l.OH = (l.IH - l.KH) / l.S + 1; l.OW = (l.IW - l.KW) / l.S + 1;
+        if (l.OH < 1 || l.OW < 1) { free_ctx(c); return trs_internal_fail(TRS_ERR_LIMIT, "image too small for Keras_2D_CNN"); }
+        l.COUT_PAD = (l.COUT + 31) / 32 * 32;
+        l.u8in = (i == 0); l.relu = true; l.out_f32 = (i == 7);
+        l.G = l.u8in ? 2 * l.KH : l.KH * l.KW * l.CIN / 8;
+        l.G_pad = (l.G + 1) & ~1;
+        l.gchunk = std::max(2, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~1));
+        l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
+        // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
+        const float* K = arr[2 * i];
+        const float* B = arr[2 * i + 1];
+        std::vector<unsigned short> wp((size_t)l.G_pad * l.COUT_PAD * 8, 0);
+        std::vector<int> goff(l.G_pad, 0);
+        for (int g = 0; g < l.G; ++g) {
+            if (l.u8in) {
+                const int kh = g >> 1, half = g & 1;
+                goff[g] = kh * l.IW * 3 + 8 * half;
+                for (int j = 0; j < 8; ++j) {
+                    const int f = 8 * half + j;                       // byte f of the 16-byte row window = (kw, c), 15 is padding
+                    if (f >= 15) continue;
+                    const int kw = f / 3, ch = f % 3;
+                    for (int co = 0; co < l.COUT; ++co)
+                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + ch) * l.COUT + co] / 255.0f);
+                }
+            } else {
+                const int c8n = l.CIN / 8, kk = g / c8n, c8 = g % c8n, kh = kk / l.KW, kw = kk % l.KW;
+                goff[g] = ((kh * l.IW + kw) * l.CIN + c8 * 8) * 2;
+                for (int j = 0; j < 8; ++j)
+                    for (int co = 0; co < l.COUT; ++co)
+                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + c8 * 8 + j) * l.COUT + co]);
+            }
+        }
+        for (int g = l.G; g < l.G_pad; ++g) goff[g] = goff[l.G - 1];       // padding granule: valid address, zero weights
+        std::vector<float> bias(l.COUT_PAD, 0.0f);
+        for (int co = 0; co < l.COUT; ++co) bias[co] = B[co];
+        std::vector<u4v> wv(wp.size() / 8);
+        std::memcpy(wv.data(), wp.data(), wp.size() * 2);
+        int rc = upload(&l.w, wv); if (!rc) rc = upload(&l.bias, bias); if (!rc) rc = upload(&l.goff, goff);
+        if (rc) { free_ctx(c); return rc; }
+        c->act_elems[i] = (size_t)l.OH * l.OW * l.COUT;
+        HIPCHK(hipMalloc(&c->act[i], (size_t)c->n_cap * c->act_elems[i] * (l.out_f32 ? 4 : 2) + 64));
+        ih = l.OH; iw = l.OW;
+    }
+    auto up = [&](float** dst, const float* src, size_t n) -> int { std::vector<float> t(src, src + n); return upload(dst, t); };
+    int rc = up(&c->w2, arr[16], 100 * 50); if (!rc) rc = up(&c->b2, arr[17], 50);
+    if (!rc) rc = up(&c->w3, arr[18], 50 * 25); if (!rc) rc = up(&c->b3, arr[19], 25);
+    if (!rc) rc = up(&c->w4, arr[20], 25 * 2); if (!rc) rc = up(&c->b4, arr[21], 2);
+    if (rc) { free_ctx(c); return rc; }
+    HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
+    for (const ConvLayer& l : c->L) {
+        const int nb = l.COUT_PAD / 32;
+        const void* fn = l.u8in ? (const void*)trs_conv_mfma_kernel<1, true> : nb == 1 ? (const void*)trs_conv_mfma_kernel<1, false>
+                       : nb == 2 ? (const void*)trs_conv_mfma_kernel<2, false> : (const void*)trs_conv_mfma_kernel<4, false>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    }
+    *slot = c;
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_pilot_forward(trs_env* e, const uint8_t* d_frames, int n_images, float* d_out)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (n_images < 1 || n_images > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "n_images must be in [1, n_envs]");
+    HIPCHK(hipSetDevice(v.device));
+    if (!d_frames) {
+        if (!v.latest_frame || n_images != v.n) return trs_internal_fail(TRS_ERR_ARG, "latest-frame source needs a rendered step and n_images == n_envs");
+        d_frames = v.latest_frame;
+    }
+    int rc = forward(c, v, d_frames, n_images);
+    if (rc) return rc;
+    return run_tail(c, v, n_images, d_out ? d_out : c->raw, nullptr, false);
+}
+
+TRS_EXPORT int trs_pilot_forward_host(trs_env* e, const uint8_t* h_frames, int n_images, float* h_out)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (!h_frames || !h_out || n_images < 1 || n_images > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "bad argument (n_images must be in [1, n_envs])");
+    HIPCHK(hipSetDevice(v.device));
+    const size_t bytes = (size_t)n_images * c->H * c->W * 3;
+    if (bytes > c->tmp_cap) {
+        HIPCHK(hipStreamSynchronize(v.stream));
+        (void)hipFree(c->tmp_frames); c->tmp_frames = nullptr; c->tmp_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->tmp_frames, bytes + 64));
+        c->tmp_cap = bytes;
+    }
+    HIPCHK(hipMemcpyAsync(c->tmp_frames, h_frames, bytes, hipMemcpyHostToDevice, v.stream));
+    int rc = trs_pilot_forward(e, c->tmp_frames, n_images, c->raw);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_out, c->raw, (size_t)n_images * 2 * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+    HIPCHK(hipStreamSynchronize(v.stream));
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t n_floats)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c || !c->last_n) return trs_internal_fail(TRS_ERR_STATE, "no forward pass yet");
+    if (layer < 0 || layer > 7 || !h_dst) return trs_internal_fail(TRS_ERR_ARG, "bad layer");
+    const size_t total = (size_t)c->last_n * c->act_elems[layer];
+    if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
+    HIPCHK(hipSetDevice(v.device));
+    HIPCHK(hipStreamSynchronize(v.stream));
+    if (c->L[layer].out_f32) { HIPCHK(hipMemcpy(h_dst, c->act[layer], total * 4, hipMemcpyDeviceToHost)); return TRS_OK; }
+    std::vector<unsigned short> tmp(total);
+    HIPCHK(hipMemcpy(tmp.data(), c->act[layer], total * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < total; ++i) { uint32_t u = (uint32_t)tmp[i] << 16; std::memcpy(&h_dst[i], &u, 4); }
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_steps)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (!cfg || cfg->struct_size != sizeof(trs_pilot_config)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.struct_size mismatch");
+    if (n_steps < 1) return trs_internal_fail(TRS_ERR_ARG, "n_steps < 1");
+    if (!v.render) return trs_internal_fail(TRS_ERR_STATE, "the pilot needs a camera (render = 1)");
+    HIPCHK(hipSetDevice(v.device));
+    for (int k = 0; k < n_steps; ++k) {
+        trs_internal_view(e, &v);
+        if (v.latest_frame) {                       // KerasPilot.step on the frame of the previous tick
+            int rc = forward(c, v, v.latest_frame, v.n);
+            if (!rc) rc = run_tail(c, v, v.n, c->raw, cfg, true);
+            if (rc) return rc;
+        } else {                                    // args[0] is None -> (0.0, 0.0, 0.0) (keras_pilot.py:46-47)
+            hipLaunchKernelGGL(trs_zero_controls_kernel, dim3((v.n + 255) / 256), dim3(256), 0, v.stream, v.ctl_steer, v.ctl_thr, v.ctl_brk, v.n);
+            HIPCHK(hipGetLastError());
+        }
+        int rc = trs_step(e, v.ctl_steer, v.ctl_thr, v.ctl_brk, nullptr, 1);
+        if (rc) return rc;
+    }
+    return TRS_OK;
+}

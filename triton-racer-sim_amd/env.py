@@ -228,6 +228,44 @@ class BatchedEnv:
         self.api.check(self.api.normalize_host(self._h, src.ctypes.data, dst.ctypes.data, int(src.shape[0])), "normalize_host")
         return dst
 
+    # -- pilot in the loop (cnn_2d_speed_control) -------------------------------------------------
+    def pilot_load(self, weights):
+        """``weights``: 22 float32 arrays — kernel, bias of conv1..conv7, dense1..dense3, output_layer in Keras
+        layouts (``[KH][KW][CIN][COUT]`` / ``[IN][OUT]``), e.g. ``model.get_weights()`` of the reference's
+        ``Keras_2D_CNN.get_model(input_shape, 2)`` (``components/keras_train.py:127-174``)."""
+        arrs = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self.api.check(self.api.pilot_load(self._h, ptrs, len(arrs)), "pilot_load")
+
+    def pilot_config(self, cfg=None):
+        pc = _ffi.TrsPilotConfig()
+        self.api.default_pilot_config(C.byref(pc))
+        cfg = cfg or {}
+        pc.spd_ctl_threshold = float(cfg.get("spd_ctl_threshold", 1.1))
+        pc.spd_ctl_break = int(bool(cfg.get("spd_ctl_break", False)))
+        pc.spd_ctl_reverse_multiplier = float(cfg.get("spd_ctl_reverse_multiplier", 1.0))
+        pc.spd_ctl_break_multiplier = float(cfg.get("spd_ctl_break_multiplier", 1.0))
+        pc.smooth_steering_enabled = int(bool(cfg.get("smooth_steering_enabled", False)))
+        pc.smooth_steering_threshold = float(cfg.get("smooth_steering_threshold", 0.9))
+        return pc
+
+    def pilot_forward_host(self, frames):
+        """Raw model outputs ``float32[n, 2]`` (steering, speed / 20) for host frames ``uint8[n,H,W,3]``."""
+        src = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.H, self.W, 3)
+        out = np.empty((src.shape[0], 2), dtype=np.float32)
+        self.api.check(self.api.pilot_forward_host(self._h, src.ctypes.data, int(src.shape[0]), out.ctypes.data), "pilot_forward_host")
+        return out
+
+    def pilot_layer(self, layer, shape):
+        out = np.empty(shape, dtype=np.float32)
+        self.api.check(self.api.pilot_debug_layer(self._h, int(layer), out.ctypes.data, out.size), "pilot_debug_layer")
+        return out
+
+    def step_pilot(self, n_steps=1, cfg=None):
+        """Closed loop: controls = KerasPilot.step(previous frame, speed), then one env step; all on the device."""
+        pc = cfg if isinstance(cfg, _ffi.TrsPilotConfig) else self.pilot_config(cfg)
+        self.api.check(self.api.step_pilot(self._h, C.byref(pc), int(n_steps)), "step_pilot")
+
     # -- timing (HIP events on the handle's stream) -------------------------------------------
     def event_record(self, slot):
         self.api.check(self.api.event_record(self._h, int(slot)), "event_record")
