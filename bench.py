@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--img-w", type=int, default=160)
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
+    ap.add_argument("--pilot", action="store_true", help="closed loop with cnn_2d_speed_control inference on the device frame each step (BASELINE configs[4] shape)")
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
@@ -143,6 +144,26 @@ def main():
                         depth=args.depth)
     env = shard.env
     spl = max(1, args.steps_per_launch)
+    if args.pilot:
+        import numpy as np
+        rng = np.random.default_rng(0)
+        spec = [(5, 2, 3, 24), (5, 2, 24, 32), (5, 2, 32, 64), (3, 1, 64, 64), (3, 1, 64, 64), (3, 1, 64, 128), (3, 1, 128, 128)]
+        ws, ih, iw, macs = [], args.img_h, args.img_w, 0
+        for k, s_, cin, cout in spec:
+            ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
+            lim = (6.0 / (k * k * (cin + cout))) ** 0.5
+            ws += [rng.uniform(-lim, lim, (k, k, cin, cout)).astype("float32"), np.zeros(cout, "float32")]
+            macs += ih * iw * cout * k * k * cin
+        dims = [ih * iw * 128, 100, 50, 25, 2]
+        for a_, b_ in zip(dims[:-1], dims[1:]):
+            lim = (6.0 / (a_ + b_)) ** 0.5
+            ws += [rng.uniform(-lim, lim, (a_, b_)).astype("float32"), np.zeros(b_, "float32")]
+            macs += a_ * b_
+        env.pilot_load(ws)
+        pilot_flops = 2.0 * macs
+        run = lambda k_: env.step_pilot(k_)
+    else:
+        run = lambda k_: env.step_synthetic(k_, spl)
 
     def barrier():
         env.sync()
@@ -154,12 +175,12 @@ def main():
     if dist is not None:   # warm the communicator outside the timed region
         warm = torch.zeros(n * world, device="cuda")
         dist.all_gather_into_tensor(warm, torch.zeros(n, device="cuda"))
-    env.step_synthetic(max(args.warmup, 1), spl)
+    run(max(args.warmup, 1))
 
     barrier()
     t0 = time.perf_counter()
     env.event_record(0)
-    env.step_synthetic(args.steps, spl)
+    run(args.steps)
     env.event_record(1)
     gathered = None
     if dist is not None:
@@ -210,6 +231,12 @@ def main():
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },
         }
+        if args.pilot:
+            tf = pilot_flops * n * args.steps / (kernel_ms * 1e-3) / 1e12
+            line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
+            line["dtype"] += " / bf16 MFMA convolutions, f32 accumulate"
+            line["pilot"] = {"flops_per_frame": pilot_flops, "achieved_tflops": round(tf, 2), "mfma_peak_tflops": 2500.0,
+                             "frac_of_mfma_peak": round(tf / 2500.0, 5), "note": "env step + 8 conv/dense launches + tail per step; the roofline object above still prices the env frame bytes only"}
         if gathered is not None:
             line["config"]["allgather_returns_mean"] = round(float(gathered.mean().item()), 4)
         if world == 1 and not args.no_cpu_baseline:

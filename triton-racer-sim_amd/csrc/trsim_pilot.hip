@@ -56,6 +56,7 @@ struct ConvParams {
     int G, G_pad, M;           // granules (even-padded), GEMM rows = N*OH*OW
     int gchunk;                // granules per LDS stage (even)
     int relu, out_f32, in_px_bytes;   // in_px_bytes: bytes per input pixel (CIN*2, conv1: 3)
+    int ksplit;                // > 1: blockIdx.y owns a slice of the granules and adds its partial sums atomically (fp32 out, no ReLU)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
@@ -84,24 +85,28 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
     const int pixbase = ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
 
+    // split-K (dense1: 8 row tiles only): blockIdx.y takes granules [gs, ge) in whole LDS chunks
+    const int nchunks = (p.G_pad + p.gchunk - 1) / p.gchunk;
+    const int cps = (nchunks + p.ksplit - 1) / p.ksplit;
+    const int gs = blockIdx.y * cps * p.gchunk, ge = min(p.G_pad, (blockIdx.y + 1) * cps * p.gchunk);
+
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const float b = p.bias[nb * 32 + r];                                // C/D layout: column = lane & 31 in every register
+        const float b = blockIdx.y == 0 ? p.bias[nb * 32 + r] : 0.0f;      // C/D layout: column = lane & 31 in every register
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = b;
     }
 
-    for (int c0 = 0; c0 < p.G_pad; c0 += p.gchunk) {
-        const int gc = min(p.gchunk, p.G_pad - c0);
+    for (int c0 = gs; c0 < ge; c0 += p.gchunk) {
+        const int gc = min(p.gchunk, ge - c0);
         __syncthreads();                                                    // previous chunk fully consumed (and lgoff written)
         for (int i = tid; i < gc * p.COUT_PAD; i += kConvBlock) lw[i] = p.w[(size_t)c0 * p.COUT_PAD + i];
         __syncthreads();
-        for (int g2 = 0; g2 < gc; g2 += 2) {
-            const int g = c0 + g2 + h;                                      // this lane's granule of the k-step
-            bf16x8 a;
+        // two k-steps per trip, both A fragments requested before the first MFMA (G_pad and gchunk are multiples of 4)
+        auto load_a = [&](int g) -> bf16x8 {
             if constexpr (U8IN) {
-                // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords + alignbyte
+                // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, funnel shift
                 const int addr = pixbase + lgoff[g];
                 const int al = addr & ~3, sh = addr & 3;
                 const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
@@ -117,15 +122,24 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
                 }
                 const u4v packed = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
                                     (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-                a = __builtin_bit_cast(bf16x8, packed);
+                return __builtin_bit_cast(bf16x8, packed);
             } else {
                 const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
-                a = __builtin_bit_cast(bf16x8, raw);
+                return __builtin_bit_cast(bf16x8, raw);
             }
+        };
+        for (int g2 = 0; g2 < gc; g2 += 4) {
+            const bf16x8 a0 = load_a(c0 + g2 + h);                           // this lane's granule of k-step 0
+            const bf16x8 a1 = load_a(c0 + g2 + 2 + h);                       // ... and of k-step 1
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const bf16x8 b = __builtin_bit_cast(bf16x8, lw[(g2 + h) * p.COUT_PAD + nb * 32 + r]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[nb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, lw[(g2 + 2 + h) * p.COUT_PAD + nb * 32 + r]);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[nb], 0, 0, 0);
             }
         }
     }
@@ -141,6 +155,7 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
             const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (row >= p.M) continue;
             float v = acc[nb][i];
+            if (p.ksplit > 1) { atomicAdd(&static_cast<float*>(p.out)[(size_t)row * p.COUT + col], v); continue; }
             if (p.relu) v = v > 0.0f ? v : 0.0f;
             if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
             else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2bf(v);
@@ -160,16 +175,23 @@ struct TailParams {
     int use_break, smooth;
 };
 
-__global__ __launch_bounds__(64) void trs_pilot_tail_kernel(const TailParams p)
+__global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    // one wave per frame: lane o owns output neuron o of the current layer; activations travel through LDS
+    __shared__ float s1[4][100], s2[4][50], s3[4][25], s4[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
     if (i >= p.n) return;
-    float a1[100], a2[50], a3[25];
-    for (int k = 0; k < 100; ++k) a1[k] = p.h1[(size_t)i * 100 + k];
-    for (int o = 0; o < 50; ++o) { float s = p.b2[o]; for (int k = 0; k < 100; ++k) s = fmaf(a1[k], p.w2[k * 50 + o], s); a2[o] = s > 0.f ? s : 0.f; }
-    for (int o = 0; o < 25; ++o) { float s = p.b3[o]; for (int k = 0; k < 50; ++k) s = fmaf(a2[k], p.w3[k * 25 + o], s); a3[o] = s > 0.f ? s : 0.f; }
-    float out[2];
-    for (int o = 0; o < 2; ++o) { float s = p.b4[o]; for (int k = 0; k < 25; ++k) s = fmaf(a3[k], p.w4[k * 2 + o], s); out[o] = s; }
+    for (int k = lane; k < 100; k += 64) { const float x = p.h1[(size_t)i * 100 + k]; s1[wv][k] = x > 0.f ? x : 0.f; }   // dense1's ReLU
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 50) { float s = p.b2[lane]; for (int k = 0; k < 100; ++k) s = fmaf(s1[wv][k], p.w2[k * 50 + lane], s); s2[wv][lane] = s > 0.f ? s : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 25) { float s = p.b3[lane]; for (int k = 0; k < 50; ++k) s = fmaf(s2[wv][k], p.w3[k * 25 + lane], s); s3[wv][lane] = s > 0.f ? s : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 2) { float s = p.b4[lane]; for (int k = 0; k < 25; ++k) s = fmaf(s3[wv][k], p.w4[k * 2 + lane], s); s4[wv][lane] = s; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+    const float out[2] = {s4[wv][0], s4[wv][1]};
     if (p.raw_out) { p.raw_out[2 * i] = out[0]; p.raw_out[2 * i + 1] = out[1]; }
     if (!p.act) return;
     float steering = out[0] < -1.0f ? -1.0f : (out[0] > 1.0f ? 1.0f : out[0]);     // __cap (keras_pilot.py:142-145)
@@ -207,7 +229,7 @@ __global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
     } while (0)
 
 struct ConvLayer {
-    int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad, gchunk, lds;
+    int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad, gchunk, lds, ksplit = 1;
     bool u8in, out_f32, relu;
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -257,9 +279,11 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.N = n_img; p.IH = l.IH; p.IW = l.IW; p.CIN = l.CIN; p.OH = l.OH; p.OW = l.OW; p.COUT = l.COUT; p.COUT_PAD = l.COUT_PAD; p.S = l.S;
     p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
+    p.ksplit = l.ksplit;
+    if (l.ksplit > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)p.M * l.COUT * sizeof(float), s));   // partial sums are added atomically
     const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
     const int nb = l.COUT_PAD / 32;
-#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid), dim3(kConvBlock), l.lds, s, p)
+#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, l.ksplit), dim3(kConvBlock), l.lds, s, p)
     if (l.u8in) LAUNCH(1, true);
     else if (nb == 1) LAUNCH(1, false);
     else if (nb == 2) LAUNCH(2, false);
@@ -294,7 +318,7 @@ int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_
         t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
         t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
     }
-    hipLaunchKernelGGL(trs_pilot_tail_kernel, dim3((n + 63) / 64), dim3(64), 0, v.stream, t);
+    hipLaunchKernelGGL(trs_pilot_tail_kernel, dim3((n + 3) / 4), dim3(256), 0, v.stream, t);
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
@@ -334,9 +358,14 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         l.COUT_PAD = (l.COUT + 31) / 32 * 32;
         l.u8in = (i == 0); l.relu = true; l.out_f32 = (i == 7);
         l.G = l.u8in ? 2 * l.KH : l.KH * l.KW * l.CIN / 8;
-        l.G_pad = (l.G + 1) & ~1;
-        l.gchunk = std::max(2, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~1));
+        l.G_pad = (l.G + 3) & ~3;
+        l.gchunk = std::max(4, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~3));
         l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
+        if (i == 7) {      // dense1: few row tiles, long K -> one LDS chunk per workgroup along K (ReLU moves into the tail kernel)
+            l.gchunk = std::min(l.gchunk, 16);
+            l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
+            l.ksplit = (l.G_pad + l.gchunk - 1) / l.gchunk;
+        }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
         const float* K = arr[2 * i];
         const float* B = arr[2 * i + 1];
@@ -439,7 +468,11 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
     HIPCHK(hipSetDevice(v.device));
     HIPCHK(hipStreamSynchronize(v.stream));
-    if (c->L[layer].out_f32) { HIPCHK(hipMemcpy(h_dst, c->act[layer], total * 4, hipMemcpyDeviceToHost)); return TRS_OK; }
+    if (c->L[layer].out_f32) {
+        HIPCHK(hipMemcpy(h_dst, c->act[layer], total * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < total; ++i) h_dst[i] = h_dst[i] > 0.0f ? h_dst[i] : 0.0f;    // dense1's ReLU lives in the tail kernel
+        return TRS_OK;
+    }
     std::vector<unsigned short> tmp(total);
     HIPCHK(hipMemcpy(tmp.data(), c->act[layer], total * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < total; ++i) { uint32_t u = (uint32_t)tmp[i] << 16; std::memcpy(&h_dst[i], &u, 4); }
