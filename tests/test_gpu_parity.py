@@ -214,3 +214,33 @@ def test_depth_channel_and_240x320(make_env):
         assert np.array_equal(dg.view(np.uint32), do.view(np.uint32))
         assert (dg == dg[:, :, :1]).all() and dg[0, 0, 0] == 40.0 and 0.7 < dg[0, -1, 0] < 1.0   # sky = z_far, nearest row ~0.84 units ahead
         assert g.state_view().depth and not make_env("hip", n_envs=2).state_view().depth
+
+
+# ---------------------------------------------------------------------------------------------- device-pointer boundary
+
+def test_device_pointer_controls_from_torch(make_env):
+    """trs_step with DEVICE arrays (torch CUDA tensors) == the host-array path == the oracle; outputs read zero-copy."""
+    torch = pytest.importorskip("torch")
+    n = 200
+    rng = np.random.default_rng(11)
+    g = make_env("hip", n_envs=n, auto_reset=True)
+    h = make_env("hip", n_envs=n, auto_reset=True)
+    o = make_env("oracle", n_envs=n, auto_reset=True)
+    for k in range(12):
+        st = rng.uniform(-1, 1, n).astype(np.float32)
+        th = rng.uniform(0, 1, n).astype(np.float32)
+        br = rng.uniform(0, 0.3, n).astype(np.float32)
+        rs = (rng.random(n) < 0.05).astype(np.uint8)
+        d_st, d_th, d_br, d_rs = (torch.from_numpy(a).cuda() for a in (st, th, br, rs))
+        torch.cuda.synchronize()                                         # the handle runs on its own stream
+        g.step_device(d_st.data_ptr(), d_th.data_ptr(), d_br.data_ptr(), d_rs.data_ptr(), n_steps=3)
+        g.sync()
+        for env in (h, o):
+            env.step(st, th, br, reset=rs, n_steps=3)
+    assert_state_equal(g, o, "device-pointer controls")
+    assert_state_equal(g, h, "device vs host controls")
+    frames = torch.as_tensor(g.device_array("img"), device="cuda")
+    assert frames.shape == (n, 120, 160, 3) and frames.dtype == torch.uint8
+    assert np.array_equal(frames.cpu().numpy(), o.fetch("img"))
+    ret = torch.as_tensor(g.device_array("ep_return"), device="cuda")
+    assert np.array_equal(ret.cpu().numpy(), o.fetch("ep_return"))
