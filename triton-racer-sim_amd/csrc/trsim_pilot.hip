@@ -43,7 +43,7 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int kConvBlock = 256;           // 4 waves x 32 output pixels = 128 GEMM rows per workgroup
 constexpr int kRowsPerWg = 128;
 constexpr int kLayers = 11;               // conv1..7, dense1..3, output
-constexpr int kLdsWeightBytes = 64 * 1024;
+constexpr int kLdsWeightBytes = 32 * 1024;   // per weight stage; 32 KB measured best of 8/16/32/64 (more workgroups per CU hide the A-load latency)
 
 struct ConvParams {
     const void* in;            // bf16 NHWC [N][IH][IW][CIN]   (conv1: uint8 [N][IH][IW][3])
