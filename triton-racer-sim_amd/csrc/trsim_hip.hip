@@ -45,7 +45,7 @@ namespace {
 
 constexpr int kBlock = 960;            // 15 waves: 4800 four-pixel groups of a 120x160 image = 5 x 960
 constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
-constexpr int kRing = 4;               // camera-parameter ring between the physics and the raster side (2 would do)
+constexpr int kRing = 4;               // global camera-parameter ring: the last step of launch i is the first frame of launch i+1
 [[maybe_unused]] constexpr int kRasterStampThread = 640;  // diagnostic stamps: wave 0 and the first physics wave
 
 struct PParams {                        // physics kernel
@@ -58,21 +58,18 @@ struct PParams {                        // physics kernel
     const unsigned char* blob;          // physics LDS image: px | py | pz | tangent
     const float* start_yaw;             // [np]
     const float* tangent_g;             // [np][2] global copy, used when the table does not fit in LDS
-    const uint32_t* dev_step;           // device-resident step counter base (graph replays) or nullptr
     unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
     int n_envs, env_id_base, envs_per_wg, np;
     int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
     float map_x0f, map_z0f, inv_cellf;
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
     float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
-    int auto_reset, synth, n_steps, cam_slot, write_cam;
+    int auto_reset, synth, n_steps, write_cam;
     uint32_t step_off;
     unsigned long long seed;
 };
 
-struct RParams {                        // raster kernel
-    const float4* cam;                  // this step's slot of the ring: [n_envs]
-    uint8_t* img;                       // this step's image buffer
+struct RParams {                        // raster side of the step kernel
     const unsigned char* blob;          // raster LDS image: map (pitched rows) @0 | rowtab | palette
     unsigned long long* stats;
     int n_envs, envs_per_wg;
@@ -717,7 +714,6 @@ struct trs_env {
     float* tangent = nullptr;
     float* start_yaw = nullptr;
     float4* cam = nullptr;               // [kRing][n]
-    uint32_t* d_step = nullptr;
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
@@ -754,7 +750,7 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     SParams sp;
     sp.ph = e->pp;
     sp.ph.ctl_steer = st; sp.ph.ctl_thr = th; sp.ph.ctl_brk = br; sp.ph.ctl_reset = rs;
-    sp.ph.synth = synth; sp.ph.n_steps = n_phys; sp.ph.write_cam = 1; sp.ph.dev_step = nullptr; sp.ph.step_off = (uint32_t)step_base;
+    sp.ph.synth = synth; sp.ph.n_steps = n_phys; sp.ph.write_cam = 1; sp.ph.step_off = (uint32_t)step_base;
     sp.ra = e->rp;
     sp.img0 = e->img[0]; sp.img1 = e->img[1];
     sp.dep0 = e->depth[0]; sp.dep1 = e->depth[1];
@@ -805,7 +801,7 @@ int run_physics_steps(trs_env* e, const float* st, const float* th, const float*
         const int now = std::min(per_launch, n - done);
         PParams p = e->pp;
         p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = done == 0 ? rs : nullptr;
-        p.synth = synth; p.n_steps = now; p.cam_slot = 0; p.write_cam = 0; p.dev_step = nullptr; p.step_off = (uint32_t)e->step_count;
+        p.synth = synth; p.n_steps = now; p.write_cam = 0; p.step_off = (uint32_t)e->step_count;
         hipLaunchKernelGGL(trs_physics_kernel, dim3((e->n + kPhysBlock / 64 - 1) / (kPhysBlock / 64)), dim3(kPhysBlock), e->lds_p, e->sP, p);
         HIPCHK(hipGetLastError());
         e->step_count += (uint64_t)now;
@@ -876,8 +872,6 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     k.done = c; c += ba; k.pending = c; c += ba; e->ctl_reset = c; c += ba;
     HIPCHK(hipMalloc((void**)&e->stats, 64 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(e->stats, 0, 64 * sizeof(unsigned long long), e->sP));
-    HIPCHK(hipMalloc((void**)&e->d_step, 64));
-    HIPCHK(hipMemsetAsync(e->d_step, 0, 64, e->sP));
     HIPCHK(hipMalloc((void**)&e->cam, (size_t)kRing * n * sizeof(float4)));
     HIPCHK(hipMemsetAsync(e->cam, 0, (size_t)kRing * n * sizeof(float4), e->sP));
     k.stats = e->stats; k.cam = e->cam;
@@ -917,7 +911,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     if (e->sP) (void)hipStreamSynchronize(e->sP);
     if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
-    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->d_step);
+    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
