@@ -162,15 +162,17 @@ typedef struct trs_pre_config {
     int32_t  n_filters;              /* <= 4 */
     uint8_t  hsv_lo[4][3], hsv_hi[4][3];   /* preprocessing_color_filter_hsvs (config.py:23), OpenCV 8-bit HSV, H in [0,180) */
     int32_t  dst_channel[4];         /* preprocessing_color_filter_destination_channels (config.py:24) */
-    int32_t  edge_detection_enabled; /* Canny (img_preprocessing.py:76-79): NOT implemented yet -> TRS_ERR_ARG when set */
-    int32_t  reserved;
+    int32_t  edge_detection_enabled; /* preprocessing_edge_detection_enabled (config.py:25): cv2.Canny(img, a, b) layer (img_preprocessing.py:76-79) */
+    int32_t  edge_threshold_a;       /* preprocessing_edge_detection_threshold_a, 60 (config.py:26) */
+    int32_t  edge_threshold_b;       /* preprocessing_edge_detection_threshold_b, 100 (config.py:27) */
+    int32_t  edge_dst_channel;       /* preprocessing_edge_detection_destination_channel, 2 (config.py:28) */
 } trs_pre_config;
 
 void trs_default_pre_config(trs_pre_config* cfg);
 
-/* ImgPreprocessing.__process without the Canny layer (img_preprocessing.py:37-54,57-74,81-102) for n_images frames
- * of the env's image size: brightness/contrast trim in binary32 exactly as numpy evaluates it (mean over rows
- * 40..118, :88-99), then the HSV in-range masks written over their destination channels.
+/* ImgPreprocessing.__process (img_preprocessing.py:37-102) for n_images frames of the env's image size: brightness /
+ * contrast trim in binary32 exactly as numpy evaluates it (mean over rows 40..118, :88-99), the HSV in-range masks
+ * (:65-74) and the Canny edge layer (:76-79; frames up to 26,000 pixels) written over their destination channels (:57-63).
  * d_src NULL = the env's latest frame (n_images must then be n_envs); d_dst NULL = the env's own processed-image
  * buffer (returned through *d_out).  Device pointers; asynchronous on the handle's stream. */
 int trs_preprocess(trs_env* env, const trs_pre_config* cfg, const uint8_t* d_src, uint8_t* d_dst, int n_images,

@@ -578,8 +578,68 @@ static void rgb2hsv_u8(int r, int g, int b, int* ho, int* so, int* vo)
     *ho = h > 255 ? 255 : h; *so = sat > 255 ? 255 : sat; *vo = v;
 }
 
+
+/* cv2.Canny(img, a, b) on an 8-bit 3-channel image, aperture 3, L1 gradient — OpenCV's published algorithm: per-channel
+ * 3x3 Sobel with replicated borders, the channel with the largest |dx|+|dy| wins (first on ties), non-maximum suppression
+ * in three direction classes with the fixed-point tangent test (tan 22.5 deg = 13573 / 2^15), magnitudes outside the image
+ * are 0, 8-connected hysteresis between floor(min(a,b)) and floor(max(a,b)).  PARITY UNPINNED (cv2 is not installed). */
+static void canny_u8c3(const uint8_t* img, int H, int W, int ta, int tb, uint8_t* edge)
+{
+    const int low = ta < tb ? ta : tb, high = ta < tb ? tb : ta;
+    const int MW = W + 2;
+    int* mag = calloc((size_t)(H + 2) * MW, sizeof(int));
+    short* gx = malloc(sizeof(short) * (size_t)H * W), *gy = malloc(sizeof(short) * (size_t)H * W);
+    uint8_t* map = malloc((size_t)H * W);
+    int* stack = malloc(sizeof(int) * (size_t)H * W);
+    int sp = 0;
+#define PX(y, x, c) ((int)img[(((size_t)((y) < 0 ? 0 : ((y) >= H ? H - 1 : (y)))) * W + ((x) < 0 ? 0 : ((x) >= W ? W - 1 : (x)))) * 3 + (c)])
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int bn = -1, bdx = 0, bdy = 0;
+            for (int c = 0; c < 3; ++c) {
+                int dx = (PX(y - 1, x + 1, c) + 2 * PX(y, x + 1, c) + PX(y + 1, x + 1, c)) - (PX(y - 1, x - 1, c) + 2 * PX(y, x - 1, c) + PX(y + 1, x - 1, c));
+                int dy = (PX(y + 1, x - 1, c) + 2 * PX(y + 1, x, c) + PX(y + 1, x + 1, c)) - (PX(y - 1, x - 1, c) + 2 * PX(y - 1, x, c) + PX(y - 1, x + 1, c));
+                int nrm = abs(dx) + abs(dy);
+                if (nrm > bn) { bn = nrm; bdx = dx; bdy = dy; }
+            }
+            mag[(size_t)(y + 1) * MW + x + 1] = bn; gx[(size_t)y * W + x] = (short)bdx; gy[(size_t)y * W + x] = (short)bdy;
+        }
+#undef PX
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int* m0 = mag + (size_t)(y + 1) * MW + x + 1;
+            const int m = *m0;
+            int ismax = 0;
+            if (m > low) {
+                const int xs = gx[(size_t)y * W + x], ys = gy[(size_t)y * W + x];
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * 13573;
+                if (ay < tg22x) ismax = m > m0[-1] && m >= m0[1];
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) ismax = m > m0[-MW] && m >= m0[MW];
+                    else { const int s = (xs ^ ys) < 0 ? -1 : 1; ismax = m > m0[-MW - s] && m > m0[MW + s]; }
+                }
+            }
+            uint8_t v = 1;
+            if (ismax) { if (m > high) { v = 2; stack[sp++] = y * W + x; } else v = 0; }
+            map[(size_t)y * W + x] = v;
+        }
+    while (sp) {
+        const int p = stack[--sp], y = p / W, x = p % W;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if ((dy || dx) && yy >= 0 && yy < H && xx >= 0 && xx < W && map[(size_t)yy * W + xx] == 0) { map[(size_t)yy * W + xx] = 2; stack[sp++] = yy * W + xx; }
+            }
+    }
+    for (size_t i = 0; i < (size_t)H * W; ++i) edge[i] = map[i] == 2 ? 255 : 0;
+    free(mag); free(gx); free(gy); free(map); free(stack);
+}
+
 static void preprocess_image(const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int H, int W)
 {
+    uint8_t* trimmed = c->edge_detection_enabled ? malloc((size_t)H * W * 3) : NULL;
     int r0 = 40 < H ? 40 : H, r1 = 119 < H ? 119 : H;
     uint64_t sum[3] = {0, 0, 0};
     for (int y = r0; y < r1; ++y)
@@ -603,6 +663,7 @@ static void preprocess_image(const trs_pre_config* c, const uint8_t* src, uint8_
             t[ch] = (int)x;                                 /* astype(uint8): truncation */
         }
         int o[3] = {t[0], t[1], t[2]};
+        if (trimmed) { trimmed[3 * i] = (uint8_t)t[0]; trimmed[3 * i + 1] = (uint8_t)t[1]; trimmed[3 * i + 2] = (uint8_t)t[2]; }
         if (c->color_filter_enabled) {
             int h, sa, v;
             rgb2hsv_u8(t[0], t[1], t[2], &h, &sa, &v);
@@ -614,12 +675,18 @@ static void preprocess_image(const trs_pre_config* c, const uint8_t* src, uint8_
         }
         dst[3 * i] = (uint8_t)o[0]; dst[3 * i + 1] = (uint8_t)o[1]; dst[3 * i + 2] = (uint8_t)o[2];
     }
+    if (trimmed) {      /* the edge layer is computed on the trimmed image and merged last (img_preprocessing.py:48-53) */
+        uint8_t* edge = malloc((size_t)H * W);
+        canny_u8c3(trimmed, H, W, c->edge_threshold_a, c->edge_threshold_b, edge);
+        for (size_t i = 0; i < (size_t)H * W; ++i) dst[3 * i + c->edge_dst_channel] = edge[i];
+        free(edge); free(trimmed);
+    }
 }
 
 static int check_pre(const trs_pre_config* c)
 {
     if (!c || c->struct_size != sizeof(trs_pre_config)) return fail(TRS_ERR_ARG, "trs_pre_config.struct_size mismatch");
-    if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "Canny edge detection is not implemented");
+    if (c->edge_detection_enabled && (c->edge_dst_channel < 0 || c->edge_dst_channel > 2)) return fail(TRS_ERR_ARG, "edge_dst_channel out of range");
     if (c->n_filters < 0 || c->n_filters > 4) return fail(TRS_ERR_ARG, "n_filters out of range");
     for (int f = 0; f < c->n_filters; ++f) if (c->dst_channel[f] < 0 || c->dst_channel[f] > 2) return fail(TRS_ERR_ARG, "dst_channel out of range");
     return TRS_OK;
@@ -634,6 +701,7 @@ EXPORT void trso_default_pre_config(trs_pre_config* c)
     const uint8_t lo[2][3] = {{0, 0, 130}, {25, 180, 155}}, hi[2][3] = {{180, 64, 255}, {43, 255, 255}};
     memcpy(c->hsv_lo, lo, sizeof lo); memcpy(c->hsv_hi, hi, sizeof hi);
     c->dst_channel[0] = 0; c->dst_channel[1] = 1;
+    c->edge_threshold_a = 60; c->edge_threshold_b = 100; c->edge_dst_channel = 2;
 }
 
 EXPORT int trso_preprocess_host(trs_env* e, const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int n)

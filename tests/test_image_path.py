@@ -93,13 +93,44 @@ def test_oracle_colour_masks_against_float_hsv(make_env):
     assert set(np.unique(got[..., :2])) <= {0, 255}
 
 
-def test_oracle_rejects_canny_and_bad_channels(make_env):
+def test_oracle_rejects_bad_channels(make_env):
     env = make_env("oracle", n_envs=1, track=None, render=False)
-    with pytest.raises(RuntimeError, match="Canny"):
-        env.preprocess_host(frames(1), {"preprocessing_edge_detection_enabled": True})
     with pytest.raises(RuntimeError, match="dst_channel"):
         env.preprocess_host(frames(1), {"preprocessing_color_filter_enabled": True, "preprocessing_color_filter_hsvs": [((0, 0, 0), (180, 255, 255))],
                                         "preprocessing_color_filter_destination_channels": [3]})
+    with pytest.raises(RuntimeError, match="edge_dst_channel"):
+        env.preprocess_host(frames(1), {"preprocessing_edge_detection_enabled": True, "preprocessing_edge_detection_destination_channel": 5})
+
+
+EDGE = {"preprocessing_edge_detection_enabled": True}
+
+
+def test_oracle_canny_properties(make_env):
+    """cv2 is absent, so the Canny restatement is checked through properties of the algorithm it states."""
+    env = make_env("oracle", n_envs=1, track=None, render=False)
+    img = np.zeros((1, 120, 160, 3), np.uint8)
+    img[0, :, 80:] = 200                                                # one vertical step edge: |dx| = 4*200, dy = 0
+    out = env.preprocess_host(img, EDGE)[0]
+    cols = np.flatnonzero(out[:, :, 2].any(0))
+    assert out[:, :, 2].max() == 255 and len(cols) == 1 and cols[0] in (79, 80)   # thinned to ONE column by the NMS
+    assert (out[:, cols[0], 2] == 255).all()                            # replicated borders: the edge runs to both image borders
+    assert np.array_equal(out[..., :2], img[0, ..., :2])                # the other channels keep the (identity-)trimmed image
+    # thresholds are put in order; a gradient between them survives only when connected to a strong one
+    weak = np.zeros((1, 120, 160, 3), np.uint8)
+    weak[0, :, 80:] = 16                                                # |dx| = 4 * 16 = 64: between the thresholds 60 and 100
+    for a, b in ((60, 100), (100, 60)):
+        cfg = dict(EDGE, preprocessing_edge_detection_threshold_a=a, preprocessing_edge_detection_threshold_b=b)
+        assert env.preprocess_host(weak, cfg)[0, :, :, 2].max() == 0    # weak only: dropped
+    weak[0, :60, 80:] = 40                                              # upper half strong (|dx| = 160): the weak half hangs on it
+    e = env.preprocess_host(weak, EDGE)[0, :, :, 2]
+    assert e[5:50, 78:82].any(1).all() and e[70:115, 78:82].any(1).all()
+    weak[0, 56:64] = 0                                                  # cut the connection; the band's lower corner stays weak (L1 = 48 + 48 < 100)
+    e = env.preprocess_host(weak, EDGE)[0, :, :, 2]
+    assert e[5:50, 78:82].any(1).all() and not e[66:].any()
+    # merge order (img_preprocessing.py:43-53): the edge layer is merged after the colour masks
+    both = dict(EDGE, preprocessing_color_filter_enabled=True, preprocessing_color_filter_hsvs=[((0, 0, 0), (180, 255, 255))],
+                preprocessing_color_filter_destination_channels=[2])
+    assert np.array_equal(env.preprocess_host(img, both)[0, :, :, 2], out[:, :, 2])
 
 
 def test_component_handoff_semantics(oracle_api):
@@ -128,6 +159,15 @@ def test_gpu_preprocess_and_normalize_equal_oracle(make_env, size):
                         "preprocessing_color_filter_destination_channels": [2, 0, 2]}]:
         assert np.array_equal(g.preprocess_host(src, cfg), o.preprocess_host(src, cfg)), (size, cfg)
     assert np.array_equal(g.normalize_host(src), o.normalize_host(src))
+    edge_cfgs = [EDGE, dict(EDGE, preprocessing_color_filter_enabled=True, preprocessing_dynamic_brightness_enabled=True,
+                            preprocessing_edge_detection_threshold_a=30, preprocessing_edge_detection_threshold_b=20,
+                            preprocessing_edge_detection_destination_channel=0)]
+    for cfg in edge_cfgs:
+        if h * w > 26000:
+            with pytest.raises(RuntimeError, match="too large for the LDS-resident Canny"):
+                g.preprocess_host(src, cfg)
+        else:
+            assert np.array_equal(g.preprocess_host(src, cfg), o.preprocess_host(src, cfg)), (size, cfg)
 
 
 @pytest.mark.gpu
@@ -138,7 +178,8 @@ def test_gpu_preprocess_latest_frames_on_device(make_env):
     o = make_env("oracle", n_envs=48, auto_reset=True)
     for env in (g, o):
         env.step_synthetic(20, 1)
-    cfg = {"preprocessing_color_filter_enabled": True, "preprocessing_dynamic_brightness_enabled": True}
+    cfg = {"preprocessing_color_filter_enabled": True, "preprocessing_dynamic_brightness_enabled": True,
+           "preprocessing_edge_detection_enabled": True}
     want = o.preprocess_host(o.fetch("img"), cfg)
     handle = g.preprocess_latest(cfg)
     got = g.preprocess_host(g.fetch("img"), cfg)                          # same frames through the host path

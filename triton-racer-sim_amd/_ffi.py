@@ -55,7 +55,8 @@ class TrsPreConfig(C.Structure):
         ("contrast_ratio", C.c_float), ("contrast_offset", C.c_float),
         ("color_filter_enabled", C.c_int32), ("n_filters", C.c_int32),
         ("hsv_lo", (C.c_uint8 * 3) * 4), ("hsv_hi", (C.c_uint8 * 3) * 4), ("dst_channel", C.c_int32 * 4),
-        ("edge_detection_enabled", C.c_int32), ("reserved", C.c_int32),
+        ("edge_detection_enabled", C.c_int32), ("edge_threshold_a", C.c_int32), ("edge_threshold_b", C.c_int32),
+        ("edge_dst_channel", C.c_int32),
     ]
 
 

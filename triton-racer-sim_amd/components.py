@@ -141,8 +141,7 @@ class HipImgPreprocessing(Component):
     """``cam/img -> cam/processed_img`` with the reference's hand-off semantics
     (``components/img_preprocessing.py:18-35``): ``step`` deposits the new frame and returns the frame processed
     from the PREVIOUS deposit (the reference's filter thread is one tick behind the loop; ``None`` until the
-    first result exists).  The filter itself (trim, HSV masks, merge; ``:37-74,81-102``) runs on the GPU.
-    Canny (``:76-79``) is not implemented: enabling it raises."""
+    first result exists).  The filter itself (trim, HSV masks, Canny, merge; ``:37-102``) runs on the GPU."""
 
     def __init__(self, cfg=None, device=0, _api=None):
         Component.__init__(self, inputs=["cam/img"], outputs=["cam/processed_img"], threaded=False)

@@ -557,6 +557,8 @@ struct PreParams {
     double baseline;
     unsigned lo[4], hi[4];              // packed h | s<<8 | v<<16
     int dst_ch[4];
+    int edge, edge_low, edge_high, edge_ch;   // Canny layer (edge kernel only)
+    int off_mag, off_map, off_tab;      // edge kernel: LDS offsets behind the trimmed frame
 };
 
 __device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
@@ -642,6 +644,175 @@ __global__ __launch_bounds__(256) void trs_preprocess_kernel(const PreParams p)
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
         __syncthreads();   // s_part / s_delta are reused by the next frame of this workgroup
+    }
+}
+
+// ImgPreprocessing with the Canny edge layer (components/img_preprocessing.py:37-54,76-79): cv2.Canny(img, a, b) on the trimmed
+// 3-channel frame, OpenCV's algorithm (see oracle/trsim_oracle.c canny_u8c3 for the statement).  One 512-thread workgroup per
+// frame; LDS holds the trimmed frame (H*W*3 B), the gradient magnitudes with a zero border ((H+2)*(W+2) int16) and the
+// edge map (H*W B: winning channel, then 0 = weak / 1 = no / 2 = edge).  Hysteresis = repeated 8-neighbour sweeps until
+// a block-wide OR reports no change.  Frames up to ~26,000 pixels (LDS); bound: LDS latency, not HBM.
+constexpr int kEdgeBlock = 512;
+
+__device__ __forceinline__ int edge_px(const unsigned char* simg, int H, int W, int y, int x, int c)
+{
+    y = y < 0 ? 0 : (y >= H ? H - 1 : y);
+    x = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    return simg[(y * W + x) * 3 + c];
+}
+
+__device__ __forceinline__ void edge_sobel(const unsigned char* simg, int H, int W, int y, int x, int c, int& dx, int& dy)
+{
+    const int a = edge_px(simg, H, W, y - 1, x - 1, c), b = edge_px(simg, H, W, y - 1, x, c), d = edge_px(simg, H, W, y - 1, x + 1, c);
+    const int e = edge_px(simg, H, W, y, x - 1, c), f = edge_px(simg, H, W, y, x + 1, c);
+    const int g = edge_px(simg, H, W, y + 1, x - 1, c), h = edge_px(simg, H, W, y + 1, x, c), i = edge_px(simg, H, W, y + 1, x + 1, c);
+    dx = (d + 2 * f + i) - (a + 2 * e + g);
+    dy = (g + 2 * h + i) - (a + 2 * b + d);
+}
+
+__global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const PreParams p)
+{
+    unsigned char* const simg = smem;
+    short* const mag = reinterpret_cast<short*>(smem + p.off_mag);
+    unsigned char* const map = smem + p.off_map;
+    int* const s_tab = reinterpret_cast<int*>(smem + p.off_tab);
+    unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [8][3]
+    float* const s_delta = reinterpret_cast<float*>(s_part + 24);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, MW = W + 2, npx = H * W;
+    const size_t frame_bytes = (size_t)p.gpe * 12;
+    for (int i = tid; i < 512; i += kEdgeBlock) s_tab[i] = p.hsv_tab[i];
+    for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        for (int i = tid; i < (H + 2) * MW; i += kEdgeBlock) mag[i] = 0;
+        // ---- channel sums over the brightness rows -> delta (as trs_preprocess_kernel) ----
+        unsigned sr = 0, sg = 0, sb = 0;
+        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += kEdgeBlock) {
+            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+            sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
+            sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
+            sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+        if (lane == 0) { s_part[wave * 3] = sr; s_part[wave * 3 + 1] = sg; s_part[wave * 3 + 2] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            const double cnt = (double)(p.r1 - p.r0) * (double)W;
+            double cur = 0.0;
+            for (int ch = 0; ch < 3; ++ch) {
+                unsigned long long tot = 0;
+                for (int w = 0; w < kEdgeBlock / 64; ++w) tot += s_part[w * 3 + ch];
+                cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
+            }
+            cur = cur + 0.0;
+            *s_delta = (float)((p.baseline - cur) / 3);
+        }
+        __syncthreads();
+        const float deltaf = *s_delta, off = p.offset, con = p.contrast;
+        // ---- trimmed frame -> LDS ----
+        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
+            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+            unsigned out[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const unsigned src = k < 4 ? w.x : (k < 8 ? w.y : w.z);
+                float x = (float)((src >> (8 * (k & 3))) & 255u);
+                if (p.dynamic) x = x + deltaf;
+                x = x - off; x = x * con; x = x + off;
+                x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+                out[k >> 2] |= (unsigned)(int)x << (8 * (k & 3));
+            }
+            unsigned* d = reinterpret_cast<unsigned*>(simg + g * 12);
+            d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+        }
+        __syncthreads();
+        // ---- Sobel per channel, the channel with the largest |dx| + |dy| wins (first on ties) ----
+        for (int px = tid; px < npx; px += kEdgeBlock) {
+            const int y = px / W, x = px - y * W;
+            int bn = -1, bc = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int dx, dy;
+                edge_sobel(simg, H, W, y, x, c, dx, dy);
+                const int nrm = abs(dx) + abs(dy);
+                if (nrm > bn) { bn = nrm; bc = c; }
+            }
+            mag[(y + 1) * MW + x + 1] = (short)bn;
+            map[px] = (unsigned char)bc;
+        }
+        __syncthreads();
+        // ---- non-maximum suppression + double threshold ----
+        for (int px = tid; px < npx; px += kEdgeBlock) {
+            const int y = px / W, x = px - y * W;
+            const short* m0 = mag + (y + 1) * MW + x + 1;
+            const int m = *m0;
+            bool ismax = false;
+            if (m > p.edge_low) {
+                int xs, ys;
+                edge_sobel(simg, H, W, y, x, map[px], xs, ys);
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * 13573;
+                if (ay < tg22x) ismax = m > m0[-1] && m >= m0[1];
+                else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) ismax = m > m0[-MW] && m >= m0[MW];
+                    else { const int sgn = (xs ^ ys) < 0 ? -1 : 1; ismax = m > m0[-MW - sgn] && m > m0[MW + sgn]; }
+                }
+            }
+            map[px] = ismax ? (m > p.edge_high ? 2 : 0) : 1;
+        }
+        __syncthreads();
+        // ---- hysteresis: weak pixels 8-connected to an edge become edges; sweep until nothing changes ----
+        for (int iter = 0; iter < npx; ++iter) {
+            int changed = 0;
+            for (int px = tid; px < npx; px += kEdgeBlock) {
+                if (map[px] != 0) continue;
+                const int y = px / W, x = px - y * W;
+                bool hit = false;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int yy = y + dy, xx = x + dx;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W && map[yy * W + xx] == 2) hit = true;
+                    }
+                if (hit) { map[px] = 2; changed = 1; }
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        // ---- colour masks on the trimmed frame, merge, edge layer last (img_preprocessing.py:43-53) ----
+        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
+            unsigned ob[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = g * 4 + q;
+                const int r = simg[px * 3], gg = simg[px * 3 + 1], b = simg[px * 3 + 2];
+                int o0 = r, o1 = gg, o2 = b;
+                if (p.color) {
+                    const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
+                    const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
+                    const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
+                    int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
+                    h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
+                    if (h < 0) h += 180;
+                    const int hh = min(h, 255), ss = min(sat, 255);
+                    for (int f = 0; f < p.n_filters; ++f) {
+                        const int lh = p.lo[f] & 255, ls = (p.lo[f] >> 8) & 255, lv = (p.lo[f] >> 16) & 255;
+                        const int uh = p.hi[f] & 255, us = (p.hi[f] >> 8) & 255, uv = (p.hi[f] >> 16) & 255;
+                        const int mk = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
+                        const int dc = p.dst_ch[f];
+                        o0 = dc == 0 ? mk : o0; o1 = dc == 1 ? mk : o1; o2 = dc == 2 ? mk : o2;
+                    }
+                }
+                const int ev = map[px] == 2 ? 255 : 0;
+                o0 = p.edge_ch == 0 ? ev : o0; o1 = p.edge_ch == 1 ? ev : o1; o2 = p.edge_ch == 2 ? ev : o2;
+                ob[3 * q] = (unsigned)o0; ob[3 * q + 1] = (unsigned)o1; ob[3 * q + 2] = (unsigned)o2;
+            }
+            const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
+                             ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
+            __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
+        }
+        __syncthreads();   // LDS is reused by the next frame of this workgroup
     }
 }
 
@@ -1183,7 +1354,7 @@ namespace {
 int check_pre(const trs_pre_config* c)
 {
     if (!c || c->struct_size != sizeof(trs_pre_config)) return fail(TRS_ERR_ARG, "trs_pre_config.struct_size mismatch");
-    if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "Canny edge detection is not implemented");
+    if (c->edge_detection_enabled && (c->edge_dst_channel < 0 || c->edge_dst_channel > 2)) return fail(TRS_ERR_ARG, "edge_dst_channel out of range");
     if (c->n_filters < 0 || c->n_filters > 4) return fail(TRS_ERR_ARG, "n_filters out of range");
     for (int f = 0; f < c->n_filters; ++f)
         if (c->dst_channel[f] < 0 || c->dst_channel[f] > 2) return fail(TRS_ERR_ARG, "dst_channel out of range");
@@ -1232,6 +1403,7 @@ TRS_EXPORT void trs_default_pre_config(trs_pre_config* c)
     const uint8_t lo[2][3] = {{0, 0, 130}, {25, 180, 155}}, hi[2][3] = {{180, 64, 255}, {43, 255, 255}};
     std::memcpy(c->hsv_lo, lo, sizeof lo); std::memcpy(c->hsv_hi, hi, sizeof hi);
     c->dst_channel[0] = 0; c->dst_channel[1] = 1;
+    c->edge_threshold_a = 60; c->edge_threshold_b = 100; c->edge_dst_channel = 2;
 }
 
 TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t* d_src, uint8_t* d_dst, int n_images, const uint8_t** d_out)
@@ -1264,6 +1436,21 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
         p.lo[f] = c->hsv_lo[f][0] | (c->hsv_lo[f][1] << 8) | (c->hsv_lo[f][2] << 16);
         p.hi[f] = c->hsv_hi[f][0] | (c->hsv_hi[f][1] << 8) | (c->hsv_hi[f][2] << 16);
         p.dst_ch[f] = c->dst_channel[f];
+    }
+    if (c->edge_detection_enabled) {
+        p.edge = 1; p.edge_ch = c->edge_dst_channel;
+        p.edge_low = std::min(c->edge_threshold_a, c->edge_threshold_b);          // cv::Canny swaps the thresholds into order
+        p.edge_high = std::max(c->edge_threshold_a, c->edge_threshold_b);
+        const size_t npx = (size_t)e->H * e->W;
+        p.off_mag = (int)align_up(npx * 3, 16);
+        p.off_map = p.off_mag + (int)align_up((size_t)(e->H + 2) * (e->W + 2) * 2, 16);
+        p.off_tab = p.off_map + (int)align_up(npx, 16);
+        const int lds = p.off_tab + 512 * 4 + 24 * 4 + 16;
+        if (lds > 160 * 1024) return fail(TRS_ERR_LIMIT, "frame too large for the LDS-resident Canny layer (about 26,000 pixels)");
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_preprocess_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(trs_preprocess_edge_kernel, dim3(std::min(n_images, e->cu_count)), dim3(kEdgeBlock), lds, e->sP, p);
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
     }
     const int grid = std::min(n_images, e->cu_count * 8);
     hipLaunchKernelGGL(trs_preprocess_kernel, dim3(grid), dim3(256), 0, e->sP, p);

@@ -194,6 +194,9 @@ class BatchedEnv:
         pc.contrast_offset = float(cfg.get("preprocessing_contrast_enhancement_offset", 125))
         pc.color_filter_enabled = int(bool(cfg.get("preprocessing_color_filter_enabled", False)))
         pc.edge_detection_enabled = int(bool(cfg.get("preprocessing_edge_detection_enabled", False)))
+        pc.edge_threshold_a = int(cfg.get("preprocessing_edge_detection_threshold_a", 60))
+        pc.edge_threshold_b = int(cfg.get("preprocessing_edge_detection_threshold_b", 100))
+        pc.edge_dst_channel = int(cfg.get("preprocessing_edge_detection_destination_channel", 2))
         if "preprocessing_color_filter_hsvs" in cfg:
             bounds = cfg["preprocessing_color_filter_hsvs"]
             chans = cfg.get("preprocessing_color_filter_destination_channels", list(range(len(bounds))))
