@@ -186,6 +186,15 @@ int trs_preprocess_host(trs_env* env, const trs_pre_config* cfg, const uint8_t* 
 int trs_normalize(trs_env* env, const uint8_t* d_src, float* d_dst, int n_images);
 int trs_normalize_host(trs_env* env, const uint8_t* h_src, float* h_dst, int n_images);
 
+/* DriverAssistance.step (components/driver_assistance.py:13-31) for N cars, in place on device control arrays:
+ * mode 0 = 'steering' (|steering| <= k / speed, throttle -0.1 when limited), mode 1 = 'speed' (throttle = brake = 0
+ * above k / steering).  d_speed NULL = the env's own 'gym/speed'.  Evaluated in binary64 like the reference's Python
+ * floats, stored as binary32. */
+int trs_driver_assist(trs_env* env, int mode, double k, float* d_steering, float* d_throttle, float* d_brake,
+                      const float* d_speed, int n);
+int trs_driver_assist_host(trs_env* env, int mode, double k, float* h_steering, float* h_throttle, float* h_brake,
+                           const float* h_speed, int n);
+
 /* ---- pilot in the loop: cnn_2d_speed_control (BASELINE config 5) ---- */
 
 /* Post-processing constants of KerasPilot (components/keras_pilot.py:31-38; core/config.py:65-66,76-80). */

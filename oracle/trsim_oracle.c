@@ -740,6 +740,28 @@ EXPORT int trso_normalize(trs_env* e, const uint8_t* src, float* dst, int n)
     return trso_normalize_host(e, src, dst, n);
 }
 
+/* DriverAssistance.step restated (/root/reference/TritonRacerSim/components/driver_assistance.py:13-31); PINNED by
+ * tests/golden/driver_assistance.json (captured from the reference). */
+EXPORT int trso_driver_assist_host(trs_env* e, int mode, double k, float* st, float* th, float* br, const float* sp, int n)
+{
+    if (!e || !st || !th || !br || !sp || n < 0 || (mode != 0 && mode != 1)) return fail(TRS_ERR_ARG, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        double steering = st[i], throttle = th[i], breaking = br[i], speed = sp[i];
+        if (mode == 0 && speed != 0) {
+            double max_steering = k / speed;
+            if (steering > max_steering) { steering = max_steering; throttle = -0.1; }
+            else if (steering < max_steering * -1) { steering = max_steering * -1; throttle = -0.1; }
+        } else if (mode == 1 && steering != 0) {
+            double max_speed = k / steering;
+            if (speed > max_speed) { throttle = 0.0; breaking = 0.0; }
+        }
+        st[i] = (float)steering; th[i] = (float)throttle; br[i] = (float)breaking;
+    }
+    return TRS_OK;
+}
+EXPORT int trso_driver_assist(trs_env* e, int mode, double k, float* st, float* th, float* br, const float* sp, int n)
+{ if (e && !sp) sp = e->speed; return trso_driver_assist_host(e, mode, k, st, th, br, sp, n); }
+
 /* oracle-only: number of OpenMP threads used by step / locate (cpu_baseline "cores") */
 EXPORT int trso_set_threads(trs_env* e, int n)
 {

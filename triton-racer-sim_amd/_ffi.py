@@ -73,6 +73,7 @@ SYMBOLS = [
     "get_state", "copy_to_host", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
     "default_pre_config", "preprocess", "preprocess_host", "normalize", "normalize_host",
+    "driver_assist", "driver_assist_host",
 ]
 
 
@@ -118,6 +119,8 @@ class Api:
             "preprocess_host": (i32, [vp, C.POINTER(TrsPreConfig), vp, vp, i32]),
             "normalize": (i32, [vp, vp, vp, i32]),
             "normalize_host": (i32, [vp, vp, vp, i32]),
+            "driver_assist": (i32, [vp, i32, C.c_double, vp, vp, vp, vp, i32]),
+            "driver_assist_host": (i32, [vp, i32, C.c_double, vp, vp, vp, vp, i32]),
         }
         pilot = {
             "default_pilot_config": (None, [C.POINTER(TrsPilotConfig)]),

@@ -825,6 +825,24 @@ __global__ __launch_bounds__(256) void trs_normalize_kernel(const uint32_t* src,
     }
 }
 
+// DriverAssistance.step for N cars (components/driver_assistance.py:13-31), in place; binary64 like the reference's Python floats
+__global__ void trs_driver_assist_kernel(int mode, double k, float* st, float* th, float* br, const float* sp, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double steering = st[i], throttle = th[i], breaking = br[i];
+    const double speed = sp[i];
+    if (mode == 0 && speed != 0) {
+        const double max_steering = k / speed;
+        if (steering > max_steering) { steering = max_steering; throttle = -0.1; }
+        else if (steering < max_steering * -1) { steering = max_steering * -1; throttle = -0.1; }
+    } else if (mode == 1 && steering != 0) {
+        const double max_speed = k / steering;
+        if (speed > max_speed) { throttle = 0.0; breaking = 0.0; }
+    }
+    st[i] = (float)steering; th[i] = (float)throttle; br[i] = (float)breaking;
+}
+
 // Batched LocationTracker.__find_closest (components/track_data_process.py:89-101): one wave per query,
 // track staged in LDS once per workgroup, queries grid-strided.
 __global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int pts_bytes, int off_py, int off_pz, int np,
@@ -1504,6 +1522,38 @@ TRS_EXPORT int trs_normalize_host(trs_env* e, const uint8_t* h_src, float* h_dst
     HIPCHK(hipMemcpyAsync(h_dst, e->tmp_f, bytes * sizeof(float), hipMemcpyDeviceToHost, e->sP));
     HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
+}
+
+TRS_EXPORT int trs_driver_assist(trs_env* e, int mode, double k, float* d_st, float* d_th, float* d_br, const float* d_sp, int n)
+{
+    if (!e || !d_st || !d_th || !d_br || n < 0 || (mode != 0 && mode != 1)) return fail(TRS_ERR_ARG, "bad argument (mode 0 = steering, 1 = speed)");
+    if (!d_sp) { if (n != e->n) return fail(TRS_ERR_ARG, "the env's own speed needs n == n_envs"); d_sp = e->pp.speed; }
+    HIPCHK(hipSetDevice(e->device));
+    if (n == 0) return TRS_OK;
+    hipLaunchKernelGGL(trs_driver_assist_kernel, dim3((n + 255) / 256), dim3(256), 0, e->sP, mode, k, d_st, d_th, d_br, d_sp, n);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_driver_assist_host(trs_env* e, int mode, double k, float* h_st, float* h_th, float* h_br, const float* h_sp, int n)
+{
+    if (!e || !h_st || !h_th || !h_br || !h_sp || n < 0) return fail(TRS_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (n == 0) return TRS_OK;
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * 16));
+    float *ds = d, *dt = d + n, *db = d + 2 * (size_t)n, *dp = d + 3 * (size_t)n;
+    hipError_t err = hipSuccess;
+    const float* srcs[4] = {h_st, h_th, h_br, h_sp};
+    float* dsts[4] = {ds, dt, db, dp};
+    for (int a = 0; a < 4 && err == hipSuccess; ++a) err = hipMemcpyAsync(dsts[a], srcs[a], (size_t)n * 4, hipMemcpyHostToDevice, e->sP);
+    int rc = err == hipSuccess ? trs_driver_assist(e, mode, k, ds, dt, db, dp, n) : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
+    float* outs[3] = {h_st, h_th, h_br};
+    for (int a = 0; a < 3 && rc == TRS_OK; ++a)
+        if (hipMemcpyAsync(outs[a], dsts[a], (size_t)n * 4, hipMemcpyDeviceToHost, e->sP) != hipSuccess) rc = fail(TRS_ERR_DEVICE, "copy back failed");
+    (void)hipStreamSynchronize(e->sP);
+    (void)hipFree(d);
+    return rc;
 }
 
 TRS_EXPORT int trs_map_info_get(trs_env* e, trs_map_info* o)

@@ -231,6 +231,14 @@ class BatchedEnv:
         self.api.check(self.api.normalize_host(self._h, src.ctypes.data, dst.ctypes.data, int(src.shape[0])), "normalize_host")
         return dst
 
+    def driver_assist_host(self, steering, throttle, brake, speed, mode="steering", k=5):
+        """``DriverAssistance.step`` (``components/driver_assistance.py:13-31``) for N cars on the device; returns new float32 arrays."""
+        arrs = [np.array(a, dtype=np.float32, copy=True).reshape(-1) for a in (steering, throttle, brake, speed)]
+        n = arrs[0].size
+        self.api.check(self.api.driver_assist_host(self._h, {"steering": 0, "speed": 1}[mode], float(k), arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                                    arrs[2].ctypes.data, arrs[3].ctypes.data, n), "driver_assist_host")
+        return arrs[0], arrs[1], arrs[2]
+
     # -- pilot in the loop (cnn_2d_speed_control) -------------------------------------------------
     def pilot_load(self, weights):
         """``weights``: 22 float32 arrays — kernel, bias of conv1..conv7, dense1..dense3, output_layer in Keras
