@@ -18,6 +18,9 @@
  *       TritonRacerSim/components/track_data_process.py:89-104) runs in
  *       binary64 on the binary64 track points: d_i = (|x-xi| + |y-yi|) + |z-zi|,
  *       best initialised to 100.0, strict '<', lowest index wins.
+ *       An implementation may first scan only the points of the 3x3 block of TRS_NEAR_GRID_CELL-sized (x, z) cells around
+ *       the query: every point outside the block is at least one cell size away in x or z, so a block result with
+ *       d < TRS_NEAR_GRID_CELL is the global result (no outside point can beat or tie it); otherwise it must scan all points.
  *
  * ---- trs_sincos(a), |a| <= pi + 1e-3 -------------------------------------
  *   q  = rint(a * TRS_TWO_OVER_PI)              (round-half-even)
@@ -101,7 +104,9 @@
 #define TRS_DEF_CENTRE_HALF     0.075
 #define TRS_DEF_DASH_PERIOD     3.0
 #define TRS_DEF_DASH_ON         1.5
-#define TRS_DEF_MAP_MARGIN      6.0            /* world units of class-0 border around the track bbox */
+#define TRS_DEF_MAP_MARGIN      2.5            /* world units of class-0 border around the track bbox (>= road_half + edge_half + one cell;
+                                                  lookups outside the map clamp to this grass border) */
+#define TRS_NEAR_GRID_CELL      4.0            /* nearest-point accelerator: 3x3 block of cells of this size; exact by the rule below */
 #define TRS_MAP_CELL_MIN        0.125          /* cell sizes are 0.125 * 2^k so 1/cell is exact */
 #define TRS_MAP_LDS_BUDGET      (96 * 1024)    /* the packed 2-bit map must fit this many bytes */
 

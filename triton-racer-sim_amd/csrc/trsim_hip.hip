@@ -61,6 +61,8 @@ struct PParams {                        // physics kernel
     unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
     int n_envs, env_id_base, envs_per_wg, np;
     int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
+    int off_gstart, off_gpts, grid_nx, grid_nz;   // nearest-point accelerator: uint16 cell starts / point lists in the LDS image
+    double grid_x0, grid_z0;
     float map_x0f, map_z0f, inv_cellf;
     float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
     float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
@@ -211,6 +213,68 @@ __device__ __forceinline__ T coherent_load(const T* ptr)
     return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Nearest raw track point of (qx, qy, qz) by one wave: binary64 L1, strict '<' with the lowest index winning ties
+// (reference LocationTracker.__find_closest, components/track_data_process.py:89-104).  First the 3x3 block of 4-unit
+// cells around the query (typically ~100 of the 1185 points); a block result below one cell size is provably the global
+// one (include/trsim_spec.h R3), otherwise every point is scanned.  All lanes get the result.
+struct NearParams { int np, off_py, off_pz, off_gstart, off_gpts, nx, nz; double x0, z0; };
+
+__device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned char* lphys, double qx, double qy, double qz, int lane,
+                                             double& best_out, int& idx_out)
+{
+    const double* lpx = reinterpret_cast<const double*>(lphys);
+    const double* lpy = reinterpret_cast<const double*>(lphys + g.off_py);
+    const double* lpz = reinterpret_cast<const double*>(lphys + g.off_pz);
+    if (g.nx > 0) {
+        const double fx = floor((qx - g.x0) * (1.0 / TRS_NEAR_GRID_CELL)), fz = floor((qz - g.z0) * (1.0 / TRS_NEAR_GRID_CELL));
+        if (fx >= -1.0 && fx <= (double)g.nx && fz >= -1.0 && fz <= (double)g.nz) {
+            const unsigned short* gstart = reinterpret_cast<const unsigned short*>(lphys + g.off_gstart);
+            const unsigned short* gpts = reinterpret_cast<const unsigned short*>(lphys + g.off_gpts);
+            const int cx = (int)fx, cz = (int)fz;
+            const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.nx - 1);
+            double best = TRS_LOST_L1;
+            int bi = 0;
+            if (x_lo <= x_hi)
+                for (int rz = max(cz - 1, 0); rz <= min(cz + 1, g.nz - 1); ++rz) {
+                    const int lo = gstart[rz * g.nx + x_lo], hi = gstart[rz * g.nx + x_hi + 1];      // the three cells of a row are contiguous
+                    for (int i = lo + lane; i < hi; i += 64) {
+                        const int idx = gpts[i];
+                        const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
+                        if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
+                    }
+                }
+            wave_argmin(best, bi);
+            const int idx = __builtin_amdgcn_readlane(bi, 63);
+            const double bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+            if (bd < TRS_NEAR_GRID_CELL) { best_out = bd; idx_out = idx; return; }
+        }
+    }
+    double best = TRS_LOST_L1;
+    int bi = 0;
+    int i = lane;
+    for (; i + 64 < g.np; i += 128) {                       // two points per trip: the LDS reads of one overlap the arithmetic of the other
+        const int i2 = i + 64;
+        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
+        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
+        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
+        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
+        if (d1 < best) { best = d1; bi = i; }
+        if (d2 < best) { best = d2; bi = i2; }
+    }
+    if (i < g.np) {
+        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
+        if (d1 < best) { best = d1; bi = i; }
+    }
+    wave_argmin(best, bi);
+    idx_out = __builtin_amdgcn_readlane(bi, 63);
+    best_out = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+}
+
+__device__ __forceinline__ NearParams near_of(const PParams& p)
+{
+    return NearParams{p.np, p.off_py, p.off_pz, p.off_gstart, p.off_gpts, p.grid_nx, p.grid_nz, p.grid_x0, p.grid_z0};
+}
+
 // Per-env state held in registers by the wave that owns the env (every lane holds the same values).
 struct EnvRegs {
     float x, y, z, yaw, v, sf, epr, speed, cte;
@@ -284,27 +348,9 @@ __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* 
         z1 = s.z + (v2 * hc) * p.dt;
         y0 = s.y;
     }
-    // nearest raw track point: binary64 L1, lane-strided scan (two points per trip), DPP argmin, broadcast from lane 63
-    const double qx = (double)x1, qy = (double)y0, qz = (double)z1;
-    double best = TRS_LOST_L1;
-    int bi = 0;
-    int i = lane;
-    for (; i + 64 < p.np; i += 128) {
-        const int i2 = i + 64;
-        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
-        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
-        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
-        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
-        if (d1 < best) { best = d1; bi = i; }
-        if (d2 < best) { best = d2; bi = i2; }
-    }
-    if (i < p.np) {
-        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-        if (d1 < best) { best = d1; bi = i; }
-    }
-    wave_argmin(best, bi);
-    const int idx = __builtin_amdgcn_readlane(bi, 63);
-    const double bestd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+    double bestd;
+    int idx;
+    wave_nearest(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
 
     const float y1 = (float)lpy[idx];
     const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
@@ -845,30 +891,22 @@ __global__ void trs_driver_assist_kernel(int mode, double k, float* st, float* t
 
 // Batched LocationTracker.__find_closest (components/track_data_process.py:89-101): one wave per query,
 // track staged in LDS once per workgroup, queries grid-strided.
-__global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int pts_bytes, int off_py, int off_pz, int np,
+__global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int stage_bytes, const NearParams g,
                                                                const double* q, int nq, int32_t* out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         const uint4* src = reinterpret_cast<const uint4*>(blob);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = tid; i < (pts_bytes >> 4); i += kLocBlock) dst[i] = src[i];
+        for (int i = tid; i < (stage_bytes >> 4); i += kLocBlock) dst[i] = src[i];
     }
     __syncthreads();
-    const double* lpx = reinterpret_cast<const double*>(smem);
-    const double* lpy = reinterpret_cast<const double*>(smem + off_py);
-    const double* lpz = reinterpret_cast<const double*>(smem + off_pz);
     constexpr int kW = kLocBlock / 64;
     for (int qi = blockIdx.x * kW + wave; qi < nq; qi += gridDim.x * kW) {
-        const double qx = q[3 * qi], qy = q[3 * qi + 1], qz = q[3 * qi + 2];
-        double best = TRS_LOST_L1;
-        int bi = 0;
-        for (int i = lane; i < np; i += 64) {
-            const double d = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-            if (d < best) { best = d; bi = i; }
-        }
-        wave_argmin(best, bi);
-        if (lane == 63) out[qi] = bi;      // wave_argmin leaves the result in lane 63
+        double best;
+        int idx;
+        wave_nearest(g, smem, q[3 * qi], q[3 * qi + 1], q[3 * qi + 2], lane, best, idx);
+        if (lane == 0) out[qi] = idx;
     }
 }
 
@@ -1145,8 +1183,13 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         return fail(TRS_ERR_LIMIT, "map + camera tables exceed the step kernel's LDS staging capacity");
     // tangents ride in LDS when the fused kernel's image (raster tables + points + tangents) still fits a CU's 160 KiB
     e->lds_off_phys = e->lds_r;
-    k.tan_in_lds = ((size_t)e->lds_off_phys + off + tan_bytes <= 160 * 1024) ? 1 : 0;
+    const size_t grid_bytes = align_up(T.grid_start.size() * 2, 16) + align_up(T.grid_pts.size() * 2, 16);
+    k.tan_in_lds = ((size_t)e->lds_off_phys + off + grid_bytes + tan_bytes <= 160 * 1024) ? 1 : 0;
     if (k.tan_in_lds) off += tan_bytes;
+    // nearest-point accelerator tables ride behind the points (uint16 cell starts + point lists)
+    k.grid_nx = T.grid_nx; k.grid_nz = T.grid_nz; k.grid_x0 = T.grid_x0; k.grid_z0 = T.grid_z0;
+    k.off_gstart = (int)off; off += align_up(T.grid_start.size() * 2, 16);
+    k.off_gpts = (int)off; off += align_up(T.grid_pts.size() * 2, 16);
     k.blob_bytes = (int)off;
     k.off_scratch = (int)off;
     e->lds_p = (int)align_up(off + scratch, 16);
@@ -1158,6 +1201,8 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     std::memcpy(hp.data() + k.off_py, T.py.data(), (size_t)n_points * 8);
     std::memcpy(hp.data() + k.off_pz, T.pz.data(), (size_t)n_points * 8);
     if (k.tan_in_lds) std::memcpy(hp.data() + k.off_tan, T.tangent.data(), (size_t)n_points * 8);
+    if (!T.grid_start.empty()) std::memcpy(hp.data() + k.off_gstart, T.grid_start.data(), T.grid_start.size() * 2);
+    if (!T.grid_pts.empty()) std::memcpy(hp.data() + k.off_gpts, T.grid_pts.data(), T.grid_pts.size() * 2);
 
     std::vector<unsigned char> hr(roff, 0);
     for (int row = 0; row < T.info.map_h; ++row)
@@ -1191,7 +1236,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
 #ifndef TRS_SINGLE_VARIANT
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->pts_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, k.blob_bytes));
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
     const size_t n = (size_t)e->n;
     std::vector<float> sx(n), sy(n), sz(n), syaw(n);
@@ -1355,9 +1400,10 @@ TRS_EXPORT int trs_locate(trs_env* e, const double* h_xyz, int nq, int32_t* h_id
     constexpr int kW = kLocBlock / 64;
     int grid = (nq + kW - 1) / kW;
     grid = std::min(grid, e->cu_count * 2);
-    hipLaunchKernelGGL(trs_locate_kernel, dim3(grid), dim3(kLocBlock), e->pts_bytes, e->sP,
-                       (const unsigned char*)e->blob_p, e->pts_bytes, e->pp.off_py, e->pp.off_pz, e->pp.np,
-                       (const double*)e->loc_q, nq, e->loc_out);
+    const PParams& pk = e->pp;
+    const NearParams near{pk.np, pk.off_py, pk.off_pz, pk.off_gstart, pk.off_gpts, pk.grid_nx, pk.grid_nz, pk.grid_x0, pk.grid_z0};
+    hipLaunchKernelGGL(trs_locate_kernel, dim3(grid), dim3(kLocBlock), pk.blob_bytes, e->sP,
+                       (const unsigned char*)e->blob_p, pk.blob_bytes, near, (const double*)e->loc_q, nq, e->loc_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_idx, e->loc_out, (size_t)nq * 4, hipMemcpyDeviceToHost, e->sP));
     HIPCHK(hipStreamSynchronize(e->sP));

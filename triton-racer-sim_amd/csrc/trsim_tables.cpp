@@ -70,6 +70,34 @@ int build_tables(const trs_config& cfg, const double* xyz, int n_points, TrackTa
         T.start_yaw[i] = (float)std::atan2(tx, tz);
     }
 
+    // ---- nearest-point accelerator grid (exactness rule: trsim_spec.h R3) ---------------------------
+    {
+        double gx0 = T.px[0], gx1 = T.px[0], gz0 = T.pz[0], gz1 = T.pz[0];
+        for (int i = 1; i < n_points; ++i) {
+            gx0 = std::min(gx0, T.px[i]); gx1 = std::max(gx1, T.px[i]);
+            gz0 = std::min(gz0, T.pz[i]); gz1 = std::max(gz1, T.pz[i]);
+        }
+        const double g = TRS_NEAR_GRID_CELL;
+        T.grid_x0 = gx0; T.grid_z0 = gz0;
+        T.grid_nx = (int)std::floor((gx1 - gx0) / g) + 1;
+        T.grid_nz = (int)std::floor((gz1 - gz0) / g) + 1;
+        if (n_points > 65535 || (long long)T.grid_nx * T.grid_nz > 60000) { T.grid_nx = T.grid_nz = 0; }   // accelerator off: full scans only
+        else {
+            const int ncell = T.grid_nx * T.grid_nz;
+            std::vector<int> cell(n_points), count(ncell + 1, 0);
+            for (int i = 0; i < n_points; ++i) {
+                const int cx = (int)std::floor((T.px[i] - gx0) / g), cz = (int)std::floor((T.pz[i] - gz0) / g);
+                cell[i] = cz * T.grid_nx + cx;
+                ++count[cell[i] + 1];
+            }
+            for (int c = 0; c < ncell; ++c) count[c + 1] += count[c];
+            T.grid_start.assign(count.begin(), count.end());
+            T.grid_pts.assign(n_points, 0);
+            std::vector<int> fill(count.begin(), count.end() - 1);
+            for (int i = 0; i < n_points; ++i) T.grid_pts[fill[cell[i]]++] = (uint16_t)i;
+        }
+    }
+
     // ---- surface-class map -------------------------------------------------------------------
     const std::vector<Pt> line = dedup_closed(T);
     const int m = (int)line.size();

@@ -26,6 +26,11 @@ struct TrackTables {
     std::vector<float> rowdepth;           // [H] z-depth of the ground plane per image row (z_far for sky / far rows)
     std::vector<uint32_t> palette;         // [H][4] 0x00BBGGRR
     float map_x0f = 0, map_z0f = 0, inv_cellf = 0;
+    // nearest-point accelerator (trsim_spec.h R3): points bucketed by (x, z) cell, ascending index inside a cell
+    int grid_nx = 0, grid_nz = 0;
+    double grid_x0 = 0, grid_z0 = 0;
+    std::vector<uint16_t> grid_start;      // [grid_nx * grid_nz + 1]
+    std::vector<uint16_t> grid_pts;        // [n_points]
 };
 
 // returns TRS_OK or a negative trs_status, message in `err`
