@@ -189,6 +189,17 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = env.event_elapsed_ms(0, 1)
 
+    # informational only (never part of `value`): the same workload with 8 steps per launch, timed separately
+    also = None
+    if render and not args.pilot and spl == 1 and world == 1:
+        env.sync()
+        env.event_record(2)
+        env.step_synthetic(args.steps, 8)
+        env.event_record(3)
+        ms8 = env.event_elapsed_ms(2, 3)
+        also = {"steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms8 * 1e-3), 1),
+                                       "frac_of_hbm_peak": round(algorithmic_bytes(args.img_h, args.img_w, render, args.depth) * n * args.steps / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                       "note": "physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -231,6 +242,8 @@ def main():
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },
         }
+        if also:
+            line["also"] = also
         if args.pilot:
             tf = pilot_flops * n * args.steps / (kernel_ms * 1e-3) / 1e12
             line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
