@@ -245,11 +245,16 @@ def main():
         if also:
             line["also"] = also
         if args.pilot:
+            # closed loop with the CNN: the convolutions dominate (MFMA-bound class); the device time of a step spans
+            # the env launch, 8 conv/dense launches and the tail, so the figure below is a whole-step rate, a lower bound
+            # on the conv kernels' own rate
             tf = pilot_flops * n * args.steps / (kernel_ms * 1e-3) / 1e12
             line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
             line["dtype"] += " / bf16 MFMA convolutions, f32 accumulate"
-            line["pilot"] = {"flops_per_frame": pilot_flops, "achieved_tflops": round(tf, 2), "mfma_peak_tflops": 2500.0,
-                             "frac_of_mfma_peak": round(tf / 2500.0, 5), "note": "env step + 8 conv/dense launches + tail per step; the roofline object above still prices the env frame bytes only"}
+            line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
+                                "traffic": None, "kernel": "trs_conv_mfma_kernel (8 launches/step) + trs_step_kernel + trs_pilot_tail_kernel",
+                                "flops_per_frame": pilot_flops, "avg_step_us": round(kernel_ms * 1e3 / args.steps, 3),
+                                "note": "whole closed-loop step by HIP events; per-layer times in profiles/r01_pilot_layers_first_build.txt"}
         if gathered is not None:
             line["config"]["allgather_returns_mean"] = round(float(gathered.mean().item()), 4)
         if world == 1 and not args.no_cpu_baseline:
