@@ -195,6 +195,44 @@ int trs_driver_assist(trs_env* env, int mode, double k, float* d_steering, float
 int trs_driver_assist_host(trs_env* env, int mode, double k, float* h_steering, float* h_throttle, float* h_brake,
                            const float* h_speed, int n);
 
+/* ControlMultiplexer.step (components/controlmultiplexer.py:24-43) for N cars, one call = one tick of the Car loop.
+ * Per car: mode HUMAN -> (usr steering, usr throttle, usr breaking); AI_STEERING -> (ai steering, usr throttle,
+ * usr breaking); AI -> (ai steering, ai throttle, ai breaking) (:26-31); any other mode value leaves that car's outputs
+ * untouched (the reference returns an empty tuple and the pool keeps its values).  Entering AI from another mode (:33)
+ * starts the enabled launch locks (:45-70), which override steering / throttle (:37-40) until they end.  The reference
+ * ends a lock from a thread that sleeps `duration` seconds; with the env's fixed tick this becomes `*_lock_ticks`
+ * ticks = ceil(duration x loop_hz) counted from the tick of the transition, and the reference's re-trigger behaviour is
+ * kept: EVERY trigger schedules its own end, so a lock restarted while an older one is pending ends when the OLDER
+ * sleep elapses (up to 8 pending ends per car are tracked).  State (last mode, lock flags, pending ends, tick
+ * counter) lives in the handle; n <= n_envs. */
+enum { TRS_MODE_HUMAN = 0, TRS_MODE_AI_STEERING = 1, TRS_MODE_AI = 2 };   /* DriveMode (components/controller.py:7-10) */
+
+typedef struct trs_mux_config {
+    uint32_t struct_size;
+    int32_t  throttle_lock_enabled;   /* ai_launch_boost_throttle_enabled, False (core/config.py:57) */
+    float    throttle_lock_value;     /* ai_launch_boost_throttle_value, 1.0 (config.py:58) */
+    int32_t  throttle_lock_ticks;     /* ai_launch_boost_throttle_duration 5 s (config.py:59) x 20 Hz = 100; >= 1 */
+    int32_t  steering_lock_enabled;   /* ai_launch_lock_steering_enabled, False (config.py:61) */
+    float    steering_lock_value;     /* ai_launch_lock_steering_value, 0.0 (config.py:62) */
+    int32_t  steering_lock_ticks;     /* ai_launch_lock_steering_duration 3 s (config.py:63) x 20 Hz = 60; >= 1 */
+} trs_mux_config;
+
+void trs_default_mux_config(trs_mux_config* cfg);
+
+/* Device pointers (float[n], mode uint8[n]); d_mux_* are what the next trs_step consumes ('mux/steering',
+ * 'mux/throttle', 'mux/breaking').  Asynchronous on the handle's stream. */
+int trs_control_mux(trs_env* env, const trs_mux_config* cfg, const uint8_t* d_mode,
+                    const float* d_usr_steering, const float* d_usr_throttle, const float* d_usr_breaking,
+                    const float* d_ai_steering, const float* d_ai_throttle, const float* d_ai_breaking,
+                    float* d_mux_steering, float* d_mux_throttle, float* d_mux_breaking, int n);
+/* Host arrays in and out (h_mux_* are read first: a car with an unknown mode keeps its values), synchronous. */
+int trs_control_mux_host(trs_env* env, const trs_mux_config* cfg, const uint8_t* h_mode,
+                         const float* h_usr_steering, const float* h_usr_throttle, const float* h_usr_breaking,
+                         const float* h_ai_steering, const float* h_ai_throttle, const float* h_ai_breaking,
+                         float* h_mux_steering, float* h_mux_throttle, float* h_mux_breaking, int n);
+/* Back to the constructor's state (controlmultiplexer.py:10-20): last mode HUMAN, no lock, tick 0. */
+int trs_control_mux_reset(trs_env* env);
+
 /* ---- pilot in the loop: cnn_2d_speed_control (BASELINE config 5) ---- */
 
 /* Post-processing constants of KerasPilot (components/keras_pilot.py:31-38; core/config.py:65-66,76-80). */

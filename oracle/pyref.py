@@ -77,3 +77,53 @@ def time_reference_loop(budget_s=2.0):
         tick(pool, parts)
         ticks += 1
     return ticks / (time.perf_counter() - t0)
+
+
+class MuxModel:
+    """Event-queue model of ONE ControlMultiplexer
+    (/root/reference/TritonRacerSim/components/controlmultiplexer.py:24-70) under ideal timing: tick k happens at
+    time k / hz, a lock-end thread started at tick k clears its flag at tick k + ticks, before that tick's step.
+    Independent of the C oracle's bookkeeping (a heap of end events instead of a trigger ring).  Parity unpinned
+    (the reference file needs pygame to import)."""
+    HUMAN, AI_STEERING, AI = 0, 1, 2
+
+    def __init__(self, throttle=(False, 1.0, 100), steering=(False, 0.0, 60)):
+        self.thr_en, self.thr_val, self.thr_ticks = throttle
+        self.st_en, self.st_val, self.st_ticks = steering
+        self.last_mode = self.HUMAN
+        self.throttle_lock_active = False
+        self.steering_lock_active = False
+        self.events = []            # (tick, which)
+        self.now = 0
+
+    def step(self, mode, usr, ai, keep):
+        """usr / ai: (steering, throttle, breaking); keep: what the pool holds (returned for an unknown mode)."""
+        import heapq
+        while self.events and self.events[0][0] <= self.now:
+            _, which = heapq.heappop(self.events)
+            if which == "t":
+                self.throttle_lock_active = False
+            else:
+                self.steering_lock_active = False
+        out = None
+        if mode == self.HUMAN:
+            out = (usr[0], usr[1], usr[2])
+        elif mode == self.AI_STEERING:
+            out = (ai[0], usr[1], usr[2])
+        elif mode == self.AI:
+            out = (ai[0], ai[1], ai[2])
+        if self.last_mode != self.AI and mode == self.AI:
+            if self.thr_en:
+                self.throttle_lock_active = True
+                heapq.heappush(self.events, (self.now + self.thr_ticks, "t"))
+            if self.st_en:
+                self.steering_lock_active = True
+                heapq.heappush(self.events, (self.now + self.st_ticks, "s"))
+        if out is not None:
+            if self.steering_lock_active:
+                out = (self.st_val, out[1], out[2])
+            if self.throttle_lock_active:
+                out = (out[0], self.thr_val, out[2])
+        self.last_mode = mode
+        self.now += 1
+        return keep if out is None else out

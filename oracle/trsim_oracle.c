@@ -35,6 +35,7 @@
 static __thread char g_err[256];
 static int fail(int code, const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
 
+struct mux_car;
 struct trs_env {
     trs_config cfg;
     int n, H, W;
@@ -58,6 +59,8 @@ struct trs_env {
     uint8_t *done, *pending, *was_reset;
     uint8_t* img;
     uint8_t* pre;              /* processed-image buffer (trso_preprocess with dst == NULL) */
+    struct mux_car* mux;       /* ControlMultiplexer state per car (trso_control_mux) */
+    int mux_tick;
     uint64_t step_count;
     uint64_t stats[64];        /* [0] off-track events, [1] resets */
 };
@@ -393,7 +396,7 @@ EXPORT int trso_destroy(trs_env* e)
     if (!e) return TRS_OK;
     free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal); free(e->rowdepth); free(e->depth);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
-    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre);
+    free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre); free(e->mux);
     free(e);
     return TRS_OK;
 }
@@ -761,6 +764,84 @@ EXPORT int trso_driver_assist_host(trs_env* e, int mode, double k, float* st, fl
 }
 EXPORT int trso_driver_assist(trs_env* e, int mode, double k, float* st, float* th, float* br, const float* sp, int n)
 { if (e && !sp) sp = e->speed; return trso_driver_assist_host(e, mode, k, st, th, br, sp, n); }
+
+/* ControlMultiplexer.step restated (/root/reference/TritonRacerSim/components/controlmultiplexer.py:24-70) on the env's
+ * fixed tick: a lock-end thread's sleep of `duration` seconds becomes an END EVENT `ticks` ticks after its trigger.
+ * Parity UNPINNED by the reference (controlmultiplexer.py imports pygame through controller.py, absent here; the
+ * reference holds no test for it); checked against the independent event-queue model in oracle/pyref.py. */
+#define MUX_PENDING 8
+struct mux_car {
+    int last_mode;                       /* :10 DriveMode.HUMAN */
+    int steering_lock_active, throttle_lock_active;   /* :12,:17 */
+    int n_trig;                          /* triggers seen; the last MUX_PENDING are kept */
+    int trig_tick[MUX_PENDING];
+};
+
+EXPORT void trso_default_mux_config(trs_mux_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->throttle_lock_enabled = 0; c->throttle_lock_value = 1.0f; c->throttle_lock_ticks = 100;
+    c->steering_lock_enabled = 0; c->steering_lock_value = 0.0f; c->steering_lock_ticks = 60;
+}
+
+EXPORT int trso_control_mux_reset(trs_env* e)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    free(e->mux);
+    e->mux = calloc((size_t)e->n, sizeof(struct mux_car));
+    if (!e->mux) return fail(TRS_ERR_DEVICE, "out of memory");
+    for (int i = 0; i < e->n; ++i) e->mux[i].last_mode = TRS_MODE_HUMAN;
+    e->mux_tick = 0;
+    return TRS_OK;
+}
+
+EXPORT int trso_control_mux_host(trs_env* e, const trs_mux_config* c, const uint8_t* mode, const float* us, const float* ut, const float* ub,
+                                 const float* as, const float* at, const float* ab, float* os, float* ot, float* ob, int n)
+{
+    if (!e || !c || !mode || !us || !ut || !ub || !as || !at || !ab || !os || !ot || !ob) return fail(TRS_ERR_ARG, "null argument");
+    if (c->struct_size != sizeof(trs_mux_config)) return fail(TRS_ERR_ARG, "trs_mux_config.struct_size mismatch");
+    if (n < 0 || n > e->n) return fail(TRS_ERR_ARG, "n must be in [0, n_envs] (the lock state is kept per env)");
+    if ((c->throttle_lock_enabled && c->throttle_lock_ticks < 1) || (c->steering_lock_enabled && c->steering_lock_ticks < 1))
+        return fail(TRS_ERR_ARG, "lock ticks must be >= 1");
+    if (!e->mux) { int rc = trso_control_mux_reset(e); if (rc) return rc; }
+    const int now = e->mux_tick;
+    for (int i = 0; i < n; ++i) {
+        struct mux_car* m = &e->mux[i];
+        /* __end_throttle_lock / __end_steering_lock (:51-54, :67-70): one per trigger, each clears the flag when it wakes */
+        int kept = m->n_trig < MUX_PENDING ? m->n_trig : MUX_PENDING;
+        for (int q = 0; q < kept; ++q) {
+            int t0 = m->trig_tick[q];
+            if (c->throttle_lock_enabled && now - t0 == c->throttle_lock_ticks) m->throttle_lock_active = 0;
+            if (c->steering_lock_enabled && now - t0 == c->steering_lock_ticks) m->steering_lock_active = 0;
+        }
+        float r0 = 0, r1 = 0, r2 = 0; int have = 1;
+        switch (mode[i]) {
+        case TRS_MODE_HUMAN:       r0 = us[i]; r1 = ut[i]; r2 = ub[i]; break;    /* :26-27 */
+        case TRS_MODE_AI_STEERING: r0 = as[i]; r1 = ut[i]; r2 = ub[i]; break;    /* :28-29 */
+        case TRS_MODE_AI:          r0 = as[i]; r1 = at[i]; r2 = ab[i]; break;    /* :30-31 */
+        default: have = 0;
+        }
+        if (m->last_mode != TRS_MODE_AI && mode[i] == TRS_MODE_AI) {             /* :33 */
+            int started = 0;
+            if (c->throttle_lock_enabled) { m->throttle_lock_active = 1; started = 1; }   /* :45-49 */
+            if (c->steering_lock_enabled) { m->steering_lock_active = 1; started = 1; }   /* :60-65 */
+            if (started) { m->trig_tick[m->n_trig % MUX_PENDING] = now; m->n_trig++; }
+        }
+        if (have) {
+            if (m->steering_lock_active) r0 = c->steering_lock_value;            /* :37-38 */
+            if (m->throttle_lock_active) r1 = c->throttle_lock_value;            /* :39-40 */
+            os[i] = r0; ot[i] = r1; ob[i] = r2;
+        }
+        m->last_mode = mode[i];                                                  /* :42 */
+    }
+    e->mux_tick = now + 1;
+    return TRS_OK;
+}
+EXPORT int trso_control_mux(trs_env* e, const trs_mux_config* c, const uint8_t* mode, const float* us, const float* ut, const float* ub,
+                            const float* as, const float* at, const float* ab, float* os, float* ot, float* ob, int n)
+{ return trso_control_mux_host(e, c, mode, us, ut, ub, as, at, ab, os, ot, ob, n); }
 
 /* oracle-only: number of OpenMP threads used by step / locate (cpu_baseline "cores") */
 EXPORT int trso_set_threads(trs_env* e, int n)

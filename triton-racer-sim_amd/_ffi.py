@@ -74,7 +74,16 @@ SYMBOLS = [
     "event_elapsed_ms", "device_count", "last_error",
     "default_pre_config", "preprocess", "preprocess_host", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
+    "default_mux_config", "control_mux", "control_mux_host", "control_mux_reset",
 ]
+
+
+class TrsMuxConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("throttle_lock_enabled", C.c_int32), ("throttle_lock_value", C.c_float), ("throttle_lock_ticks", C.c_int32),
+        ("steering_lock_enabled", C.c_int32), ("steering_lock_value", C.c_float), ("steering_lock_ticks", C.c_int32),
+    ]
 
 
 class TrsPilotConfig(C.Structure):
@@ -121,6 +130,10 @@ class Api:
             "normalize_host": (i32, [vp, vp, vp, i32]),
             "driver_assist": (i32, [vp, i32, C.c_double, vp, vp, vp, vp, i32]),
             "driver_assist_host": (i32, [vp, i32, C.c_double, vp, vp, vp, vp, i32]),
+            "default_mux_config": (None, [C.POINTER(TrsMuxConfig)]),
+            "control_mux": (i32, [vp, C.POINTER(TrsMuxConfig), vp] + [vp] * 9 + [i32]),
+            "control_mux_host": (i32, [vp, C.POINTER(TrsMuxConfig), vp] + [vp] * 9 + [i32]),
+            "control_mux_reset": (i32, [vp]),
         }
         pilot = {
             "default_pilot_config": (None, [C.POINTER(TrsPilotConfig)]),

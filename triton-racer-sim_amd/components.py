@@ -165,3 +165,40 @@ class HipImgPreprocessing(Component):
 
     def getName(self):
         return "Image Preprocessing"
+
+
+MUX_INPUTS = ["usr/mode", "usr/steering", "usr/throttle", "usr/breaking", "ai/steering", "ai/throttle", "ai/breaking"]   # controlmultiplexer.py:9
+MUX_OUTPUTS = ["mux/steering", "mux/throttle", "mux/breaking"]
+
+
+class BatchedControlMultiplexer(Component):
+    """``ControlMultiplexer`` (reference ``components/controlmultiplexer.py:6-70``) for N cars per tick: same ports,
+    same config keys (``ai_launch_*``, ``core/config.py:57-63``); every port carries an array (or a scalar that is
+    broadcast), ``usr/mode`` a sequence of ``DriveMode`` members / their strings / codes 0..2.  The selection and the
+    AI-launch locks run on the GPU (``trs_control_mux``); a lock's duration in seconds becomes
+    ``ceil(duration * loop_hz)`` ticks of the loop.  ``None`` controls are read as 0 (the batched ports are numeric)."""
+
+    def __init__(self, cfg=None, n_cars=1, loop_hz=20, env=None, device=0, _api=None):
+        Component.__init__(self, inputs=list(MUX_INPUTS), outputs=list(MUX_OUTPUTS), threaded=False)
+        self.cfg = dict(cfg or {})
+        self.n = int(n_cars)
+        self._own_env = env is None
+        self.env = env if env is not None else BatchedEnv(n_envs=self.n, track=None, device=device, render=False, _api=_api)
+        self.mux = self.env.mux_config(self.cfg, loop_hz)
+        self.last = (np.zeros(self.n, np.float32),) * 3
+
+    def step(self, *args):
+        mode = args[0]
+        if mode is None or np.isscalar(mode) or hasattr(mode, "value"):
+            mode = [mode] * self.n
+        clean = lambda a: 0.0 if a is None else a
+        usr, ai = tuple(clean(a) for a in args[1:4]), tuple(clean(a) for a in args[4:7])
+        self.last = self.env.control_mux_host(mode, usr, ai, keep=self.last, cfg=self.mux)
+        return self.last
+
+    def onShutdown(self):
+        if self._own_env:
+            self.env.close()
+
+    def getName(self):
+        return "Control Multiplexer"

@@ -889,6 +889,64 @@ __global__ void trs_driver_assist_kernel(int mode, double k, float* st, float* t
     st[i] = (float)steering; th[i] = (float)throttle; br[i] = (float)breaking;
 }
 
+// ControlMultiplexer.step for N cars (components/controlmultiplexer.py:24-43); semantics in include/trsim.h.
+// Per-car state: int32 st[10] = 8 pending trigger ticks | ring head | last_mode + (steering lock << 8) + (throttle lock << 16)
+constexpr int kMuxWords = 10;
+constexpr int kMuxNone = INT32_MIN / 2;
+struct MuxParams {
+    const uint8_t* mode;
+    const float *us, *ut, *ub, *as, *at, *ab;
+    float *os, *ot, *ob;
+    int32_t* state;
+    int n, tick;
+    int en_t, ticks_t, en_s, ticks_s;
+    float val_t, val_s;
+};
+
+__global__ void trs_control_mux_kernel(const MuxParams p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    int32_t* st = p.state + (size_t)i * kMuxWords;
+    int flags = st[9];
+    int last_mode = flags & 255, act_s = (flags >> 8) & 1, act_t = (flags >> 16) & 1;
+    // lock-end threads whose sleep elapses at this tick run before the step (:51-54, :67-70)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int trig = st[j];
+        if (p.en_t && trig + p.ticks_t == p.tick) act_t = 0;
+        if (p.en_s && trig + p.ticks_s == p.tick) act_s = 0;
+    }
+    const int mode = p.mode[i];
+    float s = 0.f, t = 0.f, b = 0.f;
+    const bool known = mode <= TRS_MODE_AI;
+    if (mode == TRS_MODE_HUMAN) { s = p.us[i]; t = p.ut[i]; b = p.ub[i]; }                    // :26-27
+    else if (mode == TRS_MODE_AI_STEERING) { s = p.as[i]; t = p.ut[i]; b = p.ub[i]; }         // :28-29
+    else if (mode == TRS_MODE_AI) { s = p.as[i]; t = p.at[i]; b = p.ab[i]; }                  // :30-31
+    if (last_mode != TRS_MODE_AI && mode == TRS_MODE_AI && (p.en_t || p.en_s)) {             // :33-35 AI launch detection
+        if (p.en_t) act_t = 1;
+        if (p.en_s) act_s = 1;
+        const int head = st[8];
+        st[head & 7] = p.tick;
+        st[8] = head + 1;
+    }
+    if (known) {
+        if (act_s) s = p.val_s;                                                               // :37-38
+        if (act_t) t = p.val_t;                                                               // :39-40
+        p.os[i] = s; p.ot[i] = t; p.ob[i] = b;
+    }
+    st[9] = (mode & 255) | (act_s << 8) | (act_t << 16);                                      // :42
+}
+
+__global__ void trs_control_mux_init_kernel(int32_t* state, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t* st = state + (size_t)i * kMuxWords;
+    for (int j = 0; j < 8; ++j) st[j] = kMuxNone;
+    st[8] = 0; st[9] = TRS_MODE_HUMAN;
+}
+
 // Batched LocationTracker.__find_closest (components/track_data_process.py:89-101): one wave per query,
 // track staged in LDS once per workgroup, queries grid-strided.
 __global__ __launch_bounds__(kLocBlock) void trs_locate_kernel(const unsigned char* blob, int stage_bytes, const NearParams g,
@@ -944,6 +1002,7 @@ struct trs_env {
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
+    int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
     int* hsv_tab = nullptr;
     PParams pp{};
@@ -1140,6 +1199,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
+    (void)hipFree(e->mux_state);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->sP) (void)hipStreamDestroy(e->sP);
@@ -1597,6 +1657,80 @@ TRS_EXPORT int trs_driver_assist_host(trs_env* e, int mode, double k, float* h_s
     float* outs[3] = {h_st, h_th, h_br};
     for (int a = 0; a < 3 && rc == TRS_OK; ++a)
         if (hipMemcpyAsync(outs[a], dsts[a], (size_t)n * 4, hipMemcpyDeviceToHost, e->sP) != hipSuccess) rc = fail(TRS_ERR_DEVICE, "copy back failed");
+    (void)hipStreamSynchronize(e->sP);
+    (void)hipFree(d);
+    return rc;
+}
+
+TRS_EXPORT void trs_default_mux_config(trs_mux_config* c)
+{
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->throttle_lock_enabled = 0; c->throttle_lock_value = 1.0f; c->throttle_lock_ticks = 100;   // core/config.py:57-59 at 20 Hz
+    c->steering_lock_enabled = 0; c->steering_lock_value = 0.0f; c->steering_lock_ticks = 60;    // core/config.py:61-63
+}
+
+static int mux_state_ready(trs_env* e)
+{
+    if (e->mux_state) return TRS_OK;
+    HIPCHK(hipMalloc((void**)&e->mux_state, (size_t)e->n * kMuxWords * sizeof(int32_t)));
+    hipLaunchKernelGGL(trs_control_mux_init_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->sP, e->mux_state, e->n);
+    HIPCHK(hipGetLastError());
+    e->mux_tick = 0;
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_control_mux_reset(trs_env* e)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(e->device));
+    if (e->mux_state) { HIPCHK(hipFree(e->mux_state)); e->mux_state = nullptr; }
+    return mux_state_ready(e);
+}
+
+TRS_EXPORT int trs_control_mux(trs_env* e, const trs_mux_config* c, const uint8_t* d_mode, const float* d_us, const float* d_ut, const float* d_ub,
+                               const float* d_as, const float* d_at, const float* d_ab, float* d_os, float* d_ot, float* d_ob, int n)
+{
+    if (!e || !c || !d_mode || !d_us || !d_ut || !d_ub || !d_as || !d_at || !d_ab || !d_os || !d_ot || !d_ob) return fail(TRS_ERR_ARG, "null argument");
+    if (c->struct_size != sizeof(trs_mux_config)) return fail(TRS_ERR_ARG, "trs_mux_config.struct_size mismatch");
+    if (n < 0 || n > e->n) return fail(TRS_ERR_ARG, "n must be in [0, n_envs] (the lock state is kept per env)");
+    if ((c->throttle_lock_enabled && c->throttle_lock_ticks < 1) || (c->steering_lock_enabled && c->steering_lock_ticks < 1))
+        return fail(TRS_ERR_ARG, "lock ticks must be >= 1");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = mux_state_ready(e);
+    if (rc) return rc;
+    MuxParams p{};
+    p.mode = d_mode; p.us = d_us; p.ut = d_ut; p.ub = d_ub; p.as = d_as; p.at = d_at; p.ab = d_ab; p.os = d_os; p.ot = d_ot; p.ob = d_ob;
+    p.state = e->mux_state; p.n = n; p.tick = e->mux_tick;
+    p.en_t = c->throttle_lock_enabled != 0; p.ticks_t = c->throttle_lock_ticks; p.val_t = c->throttle_lock_value;
+    p.en_s = c->steering_lock_enabled != 0; p.ticks_s = c->steering_lock_ticks; p.val_s = c->steering_lock_value;
+    if (n > 0) {
+        hipLaunchKernelGGL(trs_control_mux_kernel, dim3((n + 255) / 256), dim3(256), 0, e->sP, p);
+        HIPCHK(hipGetLastError());
+    }
+    e->mux_tick += 1;
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_control_mux_host(trs_env* e, const trs_mux_config* c, const uint8_t* h_mode, const float* h_us, const float* h_ut, const float* h_ub,
+                                    const float* h_as, const float* h_at, const float* h_ab, float* h_os, float* h_ot, float* h_ob, int n)
+{
+    if (!e || !h_mode || !h_us || !h_ut || !h_ub || !h_as || !h_at || !h_ab || !h_os || !h_ot || !h_ob || n < 0) return fail(TRS_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (n == 0) return trs_control_mux(e, c, h_mode, h_us, h_ut, h_ub, h_as, h_at, h_ab, h_os, h_ot, h_ob, 0);
+    float* d = nullptr;
+    const size_t nn = (size_t)n;
+    HIPCHK(hipMalloc((void**)&d, nn * 4 * 9 + nn));
+    uint8_t* dm = reinterpret_cast<uint8_t*>(d + 9 * nn);
+    const float* srcs[9] = {h_us, h_ut, h_ub, h_as, h_at, h_ab, h_os, h_ot, h_ob};
+    hipError_t err = hipMemcpyAsync(dm, h_mode, nn, hipMemcpyHostToDevice, e->sP);
+    for (int a = 0; a < 9 && err == hipSuccess; ++a) err = hipMemcpyAsync(d + a * nn, srcs[a], nn * 4, hipMemcpyHostToDevice, e->sP);
+    int rc = err == hipSuccess ? trs_control_mux(e, c, dm, d, d + nn, d + 2 * nn, d + 3 * nn, d + 4 * nn, d + 5 * nn, d + 6 * nn, d + 7 * nn, d + 8 * nn, n)
+                               : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
+    float* outs[3] = {h_os, h_ot, h_ob};
+    for (int a = 0; a < 3 && rc == TRS_OK; ++a)
+        if (hipMemcpyAsync(outs[a], d + (6 + a) * nn, nn * 4, hipMemcpyDeviceToHost, e->sP) != hipSuccess) rc = fail(TRS_ERR_DEVICE, "copy back failed");
     (void)hipStreamSynchronize(e->sP);
     (void)hipFree(d);
     return rc;

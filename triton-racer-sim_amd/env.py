@@ -239,6 +239,58 @@ class BatchedEnv:
                                                     arrs[2].ctypes.data, arrs[3].ctypes.data, n), "driver_assist_host")
         return arrs[0], arrs[1], arrs[2]
 
+    # -- ControlMultiplexer for N cars (components/controlmultiplexer.py:24-43) --------------------
+    MODES = {"human": 0, "ai_steering": 1, "ai": 2}
+
+    def mux_config(self, cfg=None, loop_hz=20):
+        """``trs_mux_config`` from the reference's ``ai_launch_*`` keys (``core/config.py:57-63``); a duration in
+        seconds becomes ``ceil(duration * loop_hz)`` ticks of the fixed-step env (at least 1)."""
+        import math
+        mc = _ffi.TrsMuxConfig()
+        self.api.default_mux_config(C.byref(mc))
+        cfg = cfg or {}
+        mc.throttle_lock_enabled = int(bool(cfg.get("ai_launch_boost_throttle_enabled", False)))
+        mc.throttle_lock_value = float(cfg.get("ai_launch_boost_throttle_value", 1.0))
+        mc.throttle_lock_ticks = max(1, math.ceil(float(cfg.get("ai_launch_boost_throttle_duration", 5)) * loop_hz))
+        mc.steering_lock_enabled = int(bool(cfg.get("ai_launch_lock_steering_enabled", False)))
+        mc.steering_lock_value = float(cfg.get("ai_launch_lock_steering_value", 0.0))
+        mc.steering_lock_ticks = max(1, math.ceil(float(cfg.get("ai_launch_lock_steering_duration", 3)) * loop_hz))
+        return mc
+
+    @classmethod
+    def encode_modes(cls, modes):
+        """``usr/mode`` values (``DriveMode`` members, their ``.value`` strings or the integers 0..2) -> uint8 codes;
+        anything else becomes 255 = 'leave this car's outputs alone'."""
+        if isinstance(modes, np.ndarray) and modes.dtype == np.uint8:
+            return np.ascontiguousarray(modes).reshape(-1)
+        out = np.empty(len(modes), np.uint8)
+        for i, m in enumerate(modes):
+            m = getattr(m, "value", m)
+            if isinstance(m, str):
+                out[i] = cls.MODES.get(m, 255)
+            elif isinstance(m, (int, np.integer)) and 0 <= int(m) <= 2:
+                out[i] = int(m)
+            else:
+                out[i] = 255
+        return out
+
+    def control_mux_host(self, modes, usr, ai, keep=None, cfg=None, loop_hz=20):
+        """One tick of ``ControlMultiplexer.step`` for n cars on the device.  ``usr`` / ``ai``: (steering, throttle,
+        breaking) arrays; ``keep``: the values a car with an unknown mode retains (default zeros).  Returns the three
+        ``mux/*`` arrays (float32)."""
+        mode = self.encode_modes(modes)
+        n = mode.size
+        f = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (n,)))
+        ins = [f(a) for a in (*usr, *ai)]
+        outs = [np.array(f(a), copy=True) for a in (keep if keep is not None else (0.0, 0.0, 0.0))]
+        mc = cfg if isinstance(cfg, _ffi.TrsMuxConfig) else self.mux_config(cfg, loop_hz)
+        self.api.check(self.api.control_mux_host(self._h, C.byref(mc), mode.ctypes.data, *[a.ctypes.data for a in ins],
+                                                 *[a.ctypes.data for a in outs], n), "control_mux_host")
+        return tuple(outs)
+
+    def control_mux_reset(self):
+        self.api.check(self.api.control_mux_reset(self._h), "control_mux_reset")
+
     # -- pilot in the loop (cnn_2d_speed_control) -------------------------------------------------
     def pilot_load(self, weights):
         """``weights``: 22 float32 arrays — kernel, bias of conv1..conv7, dense1..dense3, output_layer in Keras
