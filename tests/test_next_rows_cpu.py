@@ -99,3 +99,37 @@ import pytest  # noqa: E402
 @pytest.mark.gpu
 def test_driver_assist_gpu(make_env):
     check_assist(make_env("hip", n_envs=1, track=None, render=False))
+
+
+def test_batched_writer_and_loader_walk(tmp_path):
+    """N tubs written per tick; the reader restates DataLoader.load's walk (keras_train.py:33-57): it starts at
+    record 1, stops at the first missing file, divides the image by 255 and picks labels per loader class."""
+    from triton_racer_sim_amd.recorder import BatchedDataStorage, load_records
+    n, ticks = 3, 5
+    store = BatchedDataStorage(n, storage_root=str(tmp_path))
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (ticks, n, 120, 160, 3), dtype=np.uint8)
+    frames[:, :, 40:80] //= 4                                             # smooth-ish rows so JPEG stays close
+    speed = rng.uniform(0, 20, (ticks, n)).astype(np.float32)
+    steer = rng.uniform(-1, 1, (ticks, n)).astype(np.float32)
+    for t in range(ticks):
+        store.step(frames[t], np.full(n, 0.5, np.float32), steer[t], None, speed[t], np.full(n, 2.5), speed[t], speed[t], speed[t],
+                   np.zeros(n), False, np.array([True, True, t != 2]))
+    store.onShutdown()
+    assert sorted(os.listdir(tmp_path)) == ["records_1", "records_2", "records_3"]
+    assert len(os.listdir(tmp_path / "records_1")) == 2 * ticks and len(os.listdir(tmp_path / "records_3")) == 2 * (ticks - 1)
+    rec = json.load(open(tmp_path / "records_2" / "record_3.json"))
+    assert rec["cam/img"] == "img_3.jpg" and rec["mux/break"] is None and abs(rec["gym/speed"] - float(speed[3, 1])) < 1e-6
+    imgs, feats, labels = load_records([str(tmp_path / "records_1"), str(tmp_path / "records_3")], "speed_ctl")
+    assert imgs.shape == (4 + 3, 120, 160, 3) and imgs.dtype == np.float32 and 0.0 <= imgs.min() and imgs.max() <= 1.0
+    assert feats.shape == (7, 0) and labels.shape == (7, 2)
+    assert np.allclose(labels[:4, 0], steer[1:5, 0]) and np.allclose(labels[:4, 1], speed[1:5, 0] / 20)     # record 0 is never read
+    want = np.concatenate([steer[[1, 3, 4], 2]])                          # car 3 skipped tick 2: its records are ticks 0,1,3,4
+    assert np.allclose(labels[4:, 0], want)
+    _, feats, labels = load_records(str(tmp_path / "records_2"), "full_house")
+    assert feats.shape == (4, 2) and np.allclose(feats[:, 0], speed[1:5, 1] / 20) and np.allclose(feats[:, 1], 2.5)
+    _, feats, labels = load_records(str(tmp_path / "records_2"), "default")
+    assert np.allclose(labels[:, 1], 0.5)
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        load_records(str(tmp_path / "nope"))

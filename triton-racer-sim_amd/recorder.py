@@ -92,3 +92,77 @@ class DataStorage(Component):
 
     def getName(self):
         return "Data Storage"
+
+
+class BatchedDataStorage(Component):
+    """N cars per tick -> N tubs ``<root>/records_{i}/`` (``i`` from 1 like the reference's folder numbering,
+    ``datastorage.py:60-65``), each with the single-car layout above, so every tub loads with the reference's
+    ``DataLoader`` classes.  Ports carry arrays of length N (``cam/img``: ``uint8[N,H,W,3]``; ``None`` allowed);
+    ``usr/del_record`` / ``usr/toggle_record`` are scalars or per-car arrays."""
+
+    def __init__(self, n_cars, to_store=None, storage_root=None):
+        Component.__init__(self, inputs=list(DEFAULT_TO_STORE if to_store is None else to_store), threaded=False)
+        self.step_inputs += ["usr/del_record", "usr/toggle_record"]
+        if storage_root is None:
+            raise ValueError("storage_root is required")
+        os.makedirs(storage_root, exist_ok=True)
+        self.n = int(n_cars)
+        self.tubs = [DataStorage(to_store=self.step_inputs[:-2], storage_path=os.path.join(storage_root, f"records_{i + 1}")) for i in range(self.n)]
+
+    def step(self, *args):
+        def car(v, i):
+            if v is None or np.isscalar(v) or isinstance(v, (bool, str)):
+                return v
+            return v[i]
+        for i, tub in enumerate(self.tubs):
+            tub.step(*[car(a, i) for a in args])
+
+    def onShutdown(self):
+        for tub in self.tubs:
+            tub.onShutdown()
+
+    def getName(self):
+        return "Batched Data Storage"
+
+
+# ---- readers: the file walk and label / feature choices of the reference's loaders ------------------------------
+# (components/keras_train.py:33-57 DataLoader.load; :107-119 default names / labels / features; :264-299 variants)
+LOADERS = {
+    # name: (labels(record), features(record) or None)
+    "default": (lambda r: (r["mux/steering"], r["mux/throttle"]), None),                                     # :113-119
+    "speed_feature": (lambda r: (r["mux/steering"], r["mux/throttle"]), lambda r: (r["gym/speed"] / 20,)),   # :263-268
+    "speed_ctl": (lambda r: (r["mux/steering"], r["gym/speed"] / 20), None),                                 # :270-275
+    "full_house": (lambda r: (r["mux/steering"], r["gym/speed"] / 20),
+                   lambda r: (r["gym/speed"] / 20, r["loc/segment"])),                                       # :288-297
+}
+
+
+def load_records(paths, loader="speed_ctl"):
+    """What ``DataLoader.load`` collects before its train/validation split (``keras_train.py:33-57``): for every tub,
+    records ``i = 1, 2, ...`` until ``img_{i}.jpg`` or ``record_{i}.json`` is missing — the walk starts at 1, so the
+    writer's record 0 is never read (reference quirk, kept).  Returns ``(images float32[n,H,W,3] in [0,1],
+    features float32[n,F] (F = 0 without features), labels float32[n,L])``."""
+    from PIL import Image
+    labels_of, features_of = LOADERS[loader]
+    paths = [paths] if isinstance(paths, (str, os.PathLike)) else list(paths)
+    for p in paths:
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"Folder does not exists: {p}")                    # keras_train.py:26-28
+    imgs, feats, labels = [], [], []
+    for p in paths:
+        i = 1
+        while True:
+            try:
+                img = np.asarray(Image.open(os.path.join(p, f"img_{i}.jpg")), dtype=np.float32)
+                img /= 255
+                with open(os.path.join(p, f"record_{i}.json")) as f:
+                    record = json.load(f)
+            except FileNotFoundError:
+                break
+            imgs.append(img)
+            labels.append(np.asarray(labels_of(record), dtype=np.float32))
+            feats.append(np.asarray(features_of(record) if features_of else (), dtype=np.float32))
+            i += 1
+    if not imgs:
+        return np.zeros((0, 0, 0, 3), np.float32), np.zeros((0, 0), np.float32), np.zeros((0, 2), np.float32)
+    return np.stack(imgs), np.stack(feats), np.stack(labels)
