@@ -59,6 +59,7 @@ struct trs_env {
     uint8_t *done, *pending, *was_reset;
     uint8_t* img;
     uint8_t* pre;              /* processed-image buffer (trso_preprocess with dst == NULL) */
+    trs_pre_config frame_filter; int has_frame_filter;   /* trso_set_frame_filter */
     struct mux_car* mux;       /* ControlMultiplexer state per car (trso_control_mux) */
     int mux_tick;
     uint64_t step_count;
@@ -431,6 +432,9 @@ EXPORT int trso_reset(trs_env* e, const uint8_t* mask)
     return TRS_OK;
 }
 
+static void preprocess_image(const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int H, int W);
+static void hsv_tables(void);
+
 static int do_steps(struct trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n_steps, int synth)
 {
     if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
@@ -451,7 +455,18 @@ static int do_steps(struct trs_env* e, const float* st, const float* th, const f
                 steer = st[i]; thr = th[i]; brk = br ? br[i] : 0.0f; reset_in = (rs && k == 0) ? rs[i] != 0 : 0;
             }
             step_env(e, i, steer, thr, brk, reset_in, &s, &c);
-            if (e->img) render_env(e, i, s, c);
+            if (e->img) {
+                render_env(e, i, s, c);
+                if (e->has_frame_filter) {
+                    /* the oracle takes the long way on purpose: render the raw frame, then run the full per-pixel filter
+                     * over it -- the product filters the palette instead (trs_set_frame_filter) */
+                    size_t fb = (size_t)e->H * e->W * 3;
+                    uint8_t* tmp = malloc(fb);
+                    preprocess_image(&e->frame_filter, e->img + (size_t)i * fb, tmp, e->H, e->W);
+                    memcpy(e->img + (size_t)i * fb, tmp, fb);
+                    free(tmp);
+                }
+            }
         }
         for (int i = 0; i < e->n; ++i) { e->stats[0] += e->done[i]; e->stats[1] += e->was_reset[i]; }
         e->step_count++;
@@ -705,6 +720,20 @@ EXPORT void trso_default_pre_config(trs_pre_config* c)
     memcpy(c->hsv_lo, lo, sizeof lo); memcpy(c->hsv_hi, hi, sizeof hi);
     c->dst_channel[0] = 0; c->dst_channel[1] = 1;
     c->edge_threshold_a = 60; c->edge_threshold_b = 100; c->edge_dst_channel = 2;
+}
+
+EXPORT int trso_set_frame_filter(trs_env* e, const trs_pre_config* c)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    if (!e->cfg.render) return fail(TRS_ERR_STATE, "the env has no camera (cfg.render == 0)");
+    if (!c) { e->has_frame_filter = 0; return TRS_OK; }
+    int rc = check_pre(c);
+    if (rc) return rc;
+    if (c->dynamic_brightness) return fail(TRS_ERR_ARG, "dynamic brightness needs the frame's own mean: not a palette filter, use trs_preprocess");
+    if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
+    hsv_tables();
+    e->frame_filter = *c; e->has_frame_filter = 1;
+    return TRS_OK;
 }
 
 EXPORT int trso_preprocess_host(trs_env* e, const trs_pre_config* c, const uint8_t* src, uint8_t* dst, int n)

@@ -188,3 +188,53 @@ def test_gpu_preprocess_latest_frames_on_device(make_env):
     g.sync()
     dev = torch.as_tensor(handle, device="cuda").cpu().numpy()
     assert np.array_equal(dev, want)
+
+
+FUSED = [
+    {"preprocessing_contrast_enhancement_ratio": 1.37, "preprocessing_contrast_enhancement_offset": 110},
+    {"preprocessing_color_filter_enabled": True},
+    {"preprocessing_color_filter_enabled": True, "preprocessing_contrast_enhancement_ratio": 0.8,
+     "preprocessing_color_filter_hsvs": [((0, 0, 100), (90, 255, 255)), ((35, 30, 0), (180, 255, 200)), ((10, 10, 10), (170, 200, 240))],
+     "preprocessing_color_filter_destination_channels": [2, 0, 2]},
+]
+
+
+@pytest.mark.parametrize("cfg", FUSED)
+def test_oracle_frame_filter_is_render_then_filter(make_env, cfg):
+    """Definition of the fused mode: frames equal the raw frames pushed through ImgPreprocessing.__process."""
+    raw = make_env("oracle", n_envs=24, auto_reset=True)
+    fil = make_env("oracle", n_envs=24, auto_reset=True)
+    fil.set_frame_filter(cfg)
+    for env in (raw, fil):
+        env.step_synthetic(9, 1)
+    want = raw.preprocess_host(raw.fetch("img"), cfg)
+    assert np.array_equal(fil.fetch("img"), want) and not np.array_equal(want, raw.fetch("img"))
+    assert np.array_equal(fil.fetch("pos_x"), raw.fetch("pos_x"))           # the filter touches pixels only
+    fil.set_frame_filter(enabled=False)
+    for env in (raw, fil):
+        env.step_synthetic(1, 1)
+    assert np.array_equal(fil.fetch("img"), raw.fetch("img"))
+    for bad in ({"preprocessing_dynamic_brightness_enabled": True}, {"preprocessing_edge_detection_enabled": True}):
+        with pytest.raises(RuntimeError, match="not a palette filter"):
+            fil.set_frame_filter(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", FUSED)
+def test_gpu_fused_frame_filter_equals_oracle(make_env, cfg):
+    """The product filters the PALETTE (no extra pass); the oracle renders and then filters every pixel."""
+    g = make_env("hip", n_envs=96, auto_reset=True)
+    o = make_env("oracle", n_envs=96, auto_reset=True)
+    for env in (g, o):
+        env.set_frame_filter(cfg)
+        env.step_synthetic(7, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):                                                     # multi-step launches and a reload keep the filter
+        env.step_synthetic(8, 4)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.set_frame_filter(enabled=False)
+        env.step_synthetic(2, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    with pytest.raises(RuntimeError, match="not a palette filter"):
+        g.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True})

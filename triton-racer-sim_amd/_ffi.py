@@ -72,7 +72,7 @@ SYMBOLS = [
     "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic",
     "get_state", "copy_to_host", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
-    "default_pre_config", "preprocess", "preprocess_host", "normalize", "normalize_host",
+    "default_pre_config", "preprocess", "preprocess_host", "set_frame_filter", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
     "default_mux_config", "control_mux", "control_mux_host", "control_mux_reset",
 ]
@@ -126,6 +126,7 @@ class Api:
             "default_pre_config": (None, [C.POINTER(TrsPreConfig)]),
             "preprocess": (i32, [vp, C.POINTER(TrsPreConfig), vp, vp, i32, C.POINTER(vp)]),
             "preprocess_host": (i32, [vp, C.POINTER(TrsPreConfig), vp, vp, i32]),
+            "set_frame_filter": (i32, [vp, C.POINTER(TrsPreConfig)]),
             "normalize": (i32, [vp, vp, vp, i32]),
             "normalize_host": (i32, [vp, vp, vp, i32]),
             "driver_assist": (i32, [vp, i32, C.c_double, vp, vp, vp, vp, i32]),

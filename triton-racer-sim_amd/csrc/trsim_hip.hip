@@ -1002,6 +1002,7 @@ struct trs_env {
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
+    trs_pre_config frame_filter{}; bool has_frame_filter = false;   // trs_set_frame_filter
     int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
     int* hsv_tab = nullptr;
@@ -1207,6 +1208,8 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     return TRS_OK;
 }
 
+namespace { int upload_palette(trs_env* e); }
+
 TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
@@ -1318,7 +1321,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(e->stats, 0, 64 * sizeof(unsigned long long)));
     e->step_count = 0;
     e->track_loaded = true;
-    return TRS_OK;
+    return e->has_frame_filter ? upload_palette(e) : TRS_OK;
 }
 
 TRS_EXPORT int trs_reset(trs_env* e, const uint8_t* h_mask)
@@ -1499,6 +1502,51 @@ int ensure_hsv_table(trs_env* e)
     return TRS_OK;
 }
 
+// ImgPreprocessing.__process of ONE colour (img_preprocessing.py:37-74,92-99 without dynamic brightness and Canny):
+// the host twin of trs_preprocess_kernel's per-pixel arithmetic, used to filter the rasteriser's palette.
+uint32_t filter_colour(const trs_pre_config& c, uint32_t bgr)
+{
+    int t[3];
+    for (int ch = 0; ch < 3; ++ch) {
+        float x = (float)((bgr >> (8 * ch)) & 255u);
+        x = x - c.contrast_offset;
+        x = x * c.contrast_ratio;
+        x = x + c.contrast_offset;
+        x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+        t[ch] = (int)x;
+    }
+    int o[3] = {t[0], t[1], t[2]};
+    if (c.color_filter_enabled) {
+        const int r = t[0], g = t[1], b = t[2];
+        const int v = std::max(r, std::max(g, b)), vmin = std::min(r, std::min(g, b)), diff = v - vmin;
+        const int sdiv = v ? (int)std::lrint((255 << 12) / (1.0 * v)) : 0;
+        const int hdiv = diff ? (int)std::lrint((180 << 12) / (6.0 * diff)) : 0;
+        const int sat = (diff * sdiv + (1 << 11)) >> 12;
+        int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+        h = (h * hdiv + (1 << 11)) >> 12;
+        if (h < 0) h += 180;
+        const int hh = std::min(h, 255), ss = std::min(sat, 255);
+        for (int f = 0; f < c.n_filters; ++f) {
+            const bool in = hh >= c.hsv_lo[f][0] && hh <= c.hsv_hi[f][0] && ss >= c.hsv_lo[f][1] && ss <= c.hsv_hi[f][1] &&
+                            v >= c.hsv_lo[f][2] && v <= c.hsv_hi[f][2];
+            o[c.dst_channel[f]] = in ? 255 : 0;
+        }
+    }
+    return (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16);
+}
+
+// (re)write the palette of the raster LDS image: raw, or filtered when a frame filter is set
+int upload_palette(trs_env* e)
+{
+    if (!e->track_loaded || !e->cfg.render) return TRS_OK;
+    std::vector<uint32_t> pal(e->tab.palette);
+    if (e->has_frame_filter)
+        for (auto& c : pal) c = filter_colour(e->frame_filter, c);
+    HIPCHK(hipStreamSynchronize(e->sP));                       // frames in flight keep the palette they were launched with
+    HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
+    return TRS_OK;
+}
+
 int ensure_tmp(trs_env* e, size_t frames)
 {
     if (frames <= e->tmp_cap) return TRS_OK;
@@ -1528,6 +1576,23 @@ TRS_EXPORT void trs_default_pre_config(trs_pre_config* c)
     std::memcpy(c->hsv_lo, lo, sizeof lo); std::memcpy(c->hsv_hi, hi, sizeof hi);
     c->dst_channel[0] = 0; c->dst_channel[1] = 1;
     c->edge_threshold_a = 60; c->edge_threshold_b = 100; c->edge_dst_channel = 2;
+}
+
+TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    if (!e->cfg.render) return fail(TRS_ERR_STATE, "the env has no camera (cfg.render == 0)");
+    if (c) {
+        int rc = check_pre(c);
+        if (rc) return rc;
+        if (c->dynamic_brightness) return fail(TRS_ERR_ARG, "dynamic brightness needs the frame's own mean: not a palette filter, use trs_preprocess");
+        if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
+        e->frame_filter = *c; e->has_frame_filter = true;
+    } else {
+        e->has_frame_filter = false;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    return upload_palette(e);
 }
 
 TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t* d_src, uint8_t* d_dst, int n_images, const uint8_t** d_out)

@@ -224,6 +224,16 @@ class BatchedEnv:
         self.api.check(self.api.preprocess(self._h, C.byref(pc), None, None, self.n, C.byref(out)), "preprocess")
         return _DevicePtr(out.value, (self.n, self.H, self.W, 3), np.uint8, self)
 
+    def set_frame_filter(self, cfg=None, enabled=True):
+        """``ImgPreprocessing`` fused behind the rasteriser (``trs_set_frame_filter``): from the next frame on, the
+        env's ``img`` IS ``cam/processed_img`` at no extra cost (the palette is filtered, not the pixels).  Trim and
+        HSV masks only; dynamic brightness and Canny are refused.  ``enabled=False`` returns to raw frames."""
+        if not enabled:
+            self.api.check(self.api.set_frame_filter(self._h, None), "set_frame_filter")
+            return
+        pc = cfg if isinstance(cfg, _ffi.TrsPreConfig) else self.pre_config(cfg)
+        self.api.check(self.api.set_frame_filter(self._h, C.byref(pc)), "set_frame_filter")
+
     def normalize_host(self, frames):
         """Pilot-side ``float32(img) / 255`` (``keras_pilot.py:49-55``) -> ``float32[n,H,W,3]``."""
         src = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.H, self.W, 3)
