@@ -1,25 +1,33 @@
 #!/bin/bash
-# per-layer conv kernel times: persistent LDS-band kernels on (default) vs off (TRS_PILOT_NO_PERSIST=1)
+# per-layer kernel times of the pilot loop (rocprofv3 kernel trace); extra args go to bench.py; env TRS_PILOT_WAVES tunes waves/CU
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-for mode in persist generic; do
-  rm -rf gpurun_out/prof_pl_$mode
-  if [ $mode = generic ]; then export TRS_PILOT_NO_PERSIST=1; else unset TRS_PILOT_NO_PERSIST; fi
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_pl_$mode -o p -- python3 bench.py --no-cpu-baseline --pilot --envs-per-gpu 1024 --steps 30 --warmup 5 "$@" > /dev/null 2>&1
-  echo "== $mode"
-  python3 - <<PY
+tag=${PL_TAG:-run}
+rm -rf gpurun_out/prof_pl_$tag
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_pl_$tag -o p -- python3 bench.py --no-cpu-baseline --pilot --envs-per-gpu 1024 --steps 30 --warmup 5 "$@" > gpurun_out/prof_pl_$tag.json 2>/dev/null
+echo "== $tag $*"
+python3 - <<PY
 import csv,glob,collections
-f=glob.glob("gpurun_out/prof_pl_$mode/**/*kernel_trace.csv",recursive=True)[0]
+f=glob.glob("gpurun_out/prof_pl_$tag/**/*kernel_trace.csv",recursive=True)[0]
 rows=[r for r in csv.DictReader(open(f)) if "conv_" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
-by=collections.OrderedDict()
-for r in rows:
-    k=(("persist" if "persist" in r["Kernel_Name"] else "generic" if "conv_mfma" in r["Kernel_Name"] else "other"), r["Grid_Size_X"], r["Grid_Size_Y"])
-    by.setdefault(k,[]).append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 steps=len([r for r in rows if "tail" in r["Kernel_Name"]])
+# position of a launch inside its step identifies the layer
+seq=[]; cur=[]
+for r in rows:
+    cur.append(r)
+    if "tail" in r["Kernel_Name"]:
+        seq.append(cur); cur=[]
+seq=[s for s in seq if len(s)==len(seq[-1])]
+names=["env step","conv1","conv2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
 tot=0
-for k,v in by.items():
-    tot+=sum(v)
-    print(f"  {k[0]:8s} grid={k[1]:>8s}x{k[2]}  launches/step={len(v)/steps:4.1f}  mean {sum(v)/len(v)/1e3:8.1f} us  per step {sum(v)/steps/1e3:8.1f} us")
-print(f"  all kernels per step: {tot/steps/1e3:.1f} us")
+for j in range(len(seq[-1])):
+    d=[int(s[j]["End_Timestamp"])-int(s[j]["Start_Timestamp"]) for s in seq]
+    r=seq[-1][j]
+    kind="resident" if "resident" in r["Kernel_Name"] else "chunked" if "conv_mfma" in r["Kernel_Name"] else "-"
+    nm=names[j] if len(seq[-1])==len(names) else str(j)
+    tot+=sum(d)/len(d)
+    print(f"  {nm:9s} {kind:8s} grid={r['Grid_Size_X']:>8s}x{r['Grid_Size_Y']} wg={r['Workgroup_Size_X']:>4s} lds={r.get('LDS_Block_Size','?'):>7s}  mean {sum(d)/len(d)/1e3:8.1f} us")
+print(f"  all kernels per step: {tot/1e3:.1f} us   (steps seen: {len(seq)})")
 PY
-done
+cat gpurun_out/prof_pl_$tag.json | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  bench:', d['value'], d['unit'], d['roofline']['achieved'], d['roofline']['unit'])"

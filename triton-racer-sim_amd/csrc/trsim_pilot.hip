@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,6 +44,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int kConvBlock = 256;           // 4 waves x 32 output pixels = 128 GEMM rows per workgroup
 constexpr int kRowsPerWg = 128;
 constexpr int kLayers = 11;               // conv1..7, dense1..3, output
+#ifndef TRS_CONV_ABLATE
+#define TRS_CONV_ABLATE 0   /* diagnostic builds of trs_conv_lt_kernel, never shipped: 1 = no steady-state global loads, 2 = no LDS transpose, 3 = no MFMA, 4 = no stores */
+#endif
+constexpr int kConvPrefetch = 4;           // trips (pairs of k-steps) of pixel fragments in flight per wave
 constexpr int kLdsWeightBytes = 32 * 1024;   // per weight stage; 32 KB measured best of 8/16/32/64 (more workgroups per CU hide the A-load latency)
 
 struct ConvParams {
@@ -68,6 +73,15 @@ __device__ __forceinline__ unsigned short f2bf(float f)
     return (unsigned short)(u >> 16);
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{   // round to nearest even, two values per dword: v_cvt_pk_bf16_f32 on gfx950
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
 template <int NB, bool U8IN>
 __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvParams p)
 {
@@ -77,7 +91,8 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
     int* lgoff = reinterpret_cast<int*>(psmem + (size_t)p.gchunk * p.COUT_PAD * 16);   // [G_pad]
     for (int i = tid; i < p.G_pad; i += kConvBlock) lgoff[i] = p.goff[i];
 
-    // GEMM row of this lane for the A operand: one output pixel
+    // GEMM row of this lane for the A operand: one output pixel (this chunked kernel serves dense1's split-K, whose
+    // fp32 atomics want consecutive lanes on consecutive channels: D[pixel][cout], column = lane & 31)
     const int m = blockIdx.x * kRowsPerWg + wave * 32 + r;
     const int mm = min(m, p.M - 1);
     const int ohw = p.OH * p.OW;
@@ -97,49 +112,74 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = b;
     }
+    __syncthreads();                                                        // lgoff visible
+    if (gs >= ge) return;                                                   // empty K slice (uniform per workgroup)
 
+    auto load_a = [&](int g) -> bf16x8 {
+        if constexpr (U8IN) {
+            // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, byte-align, exact u8 -> bf16
+            // (0..255 is exact in bf16, so the upper half of the float IS the bf16)
+            const int addr = pixbase + lgoff[g];
+            const int al = addr & ~3;
+            const unsigned sh = (unsigned)addr & 3u;
+            const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
+            const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
+            const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
+            const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            auto pair = [](unsigned w, int j) -> unsigned {
+                const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
+                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // (f0 >> 16) | (f1 & 0xffff0000)
+            };
+            const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
+            return __builtin_bit_cast(bf16x8, packed);
+        } else {
+            const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
+            return __builtin_bit_cast(bf16x8, raw);
+        }
+    };
+
+    // A trip = two k-steps (4 granules).  The pixel fragments of kPf trips are in flight: slot t of the register ring is
+    // refilled for trip i + kPf right after trip i's MFMAs have read it (fragments do not depend on the weight stage, so
+    // the prefetch runs across chunk boundaries).  gchunk is a multiple of 4 * kPf, so a trip's slot is a compile-time
+    // index.  Every group of kPf trips but the last reloads UNCONDITIONALLY (clamped granule index): a load inside a
+    // branch makes hipcc drain the whole queue (vmcnt(0)) at the loop head; the last group has no loads and may be ragged.
+    constexpr int kPf = kConvPrefetch;
+    bf16x8 ring[2 * kPf];
+#pragma unroll
+    for (int t = 0; t < kPf; ++t) {
+        if (gs + 4 * t < ge) { ring[2 * t] = load_a(gs + 4 * t + h); ring[2 * t + 1] = load_a(gs + 4 * t + 2 + h); }
+    }
+    auto trip_mfma = [&](int gt, int t) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + h) * p.COUT_PAD + nb * 32 + r]);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[2 * t], w, acc[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + 2 + h) * p.COUT_PAD + nb * 32 + r]);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[2 * t + 1], w, acc[nb], 0, 0, 0);
+        }
+    };
     for (int c0 = gs; c0 < ge; c0 += p.gchunk) {
         const int gc = min(p.gchunk, ge - c0);
-        __syncthreads();                                                    // previous chunk fully consumed (and lgoff written)
+        __syncthreads();                                                    // previous chunk fully consumed
         for (int i = tid; i < gc * p.COUT_PAD; i += kConvBlock) lw[i] = p.w[(size_t)c0 * p.COUT_PAD + i];
         __syncthreads();
-        // two k-steps per trip, both A fragments requested before the first MFMA (G_pad and gchunk are multiples of 4)
-        auto load_a = [&](int g) -> bf16x8 {
-            if constexpr (U8IN) {
-                // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, funnel shift
-                const int addr = pixbase + lgoff[g];
-                const int al = addr & ~3, sh = addr & 3;
-                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
-                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
-                const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
-                const unsigned lo = sh ? ((w0 >> (8 * sh)) | (w1 << (32 - 8 * sh))) : w0;
-                const unsigned hi = sh ? ((w1 >> (8 * sh)) | (w2 << (32 - 8 * sh))) : w1;
-                unsigned short e[8];
+        for (int g2 = 0; g2 < gc; g2 += 4 * kPf) {
+            if (c0 + g2 + 4 * kPf < ge) {                                   // a full group with at least one trip behind it
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    e[j] = (unsigned short)(__float_as_uint((float)((lo >> (8 * j)) & 255u)) >> 16);       // 0..255 is exact in bf16
-                    e[4 + j] = (unsigned short)(__float_as_uint((float)((hi >> (8 * j)) & 255u)) >> 16);
+                for (int t = 0; t < kPf; ++t) {
+                    trip_mfma(g2 + 4 * t, t);
+                    const int gn = min(c0 + g2 + 4 * t + 4 * kPf, ge - 4);
+                    ring[2 * t] = load_a(gn + h); ring[2 * t + 1] = load_a(gn + 2 + h);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                const u4v packed = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                                    (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16)};
-                return __builtin_bit_cast(bf16x8, packed);
-            } else {
-                const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
-                return __builtin_bit_cast(bf16x8, raw);
-            }
-        };
-        for (int g2 = 0; g2 < gc; g2 += 4) {
-            const bf16x8 a0 = load_a(c0 + g2 + h);                           // this lane's granule of k-step 0
-            const bf16x8 a1 = load_a(c0 + g2 + 2 + h);                       // ... and of k-step 1
+            } else {                                                        // the last group: 1..kPf trips, nothing to fetch
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, lw[(g2 + h) * p.COUT_PAD + nb * 32 + r]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[nb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, lw[(g2 + 2 + h) * p.COUT_PAD + nb * 32 + r]);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[nb], 0, 0, 0);
+                for (int t = 0; t < kPf; ++t)
+                    if (g2 + 4 * t < gc) trip_mfma(g2 + 4 * t, t);
             }
         }
     }
@@ -160,6 +200,275 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
             if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
             else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2bf(v);
         }
+    }
+}
+
+// pixel index -> byte offset of its input window.  The tile's first pixel is wave-uniform, so its frame / remainder split
+// runs on the scalar unit; a lane adds its own offset (at most a few wraps) and divides the in-frame remainder by OW with a
+// float reciprocal + correction (remainders are far below 2^22).
+__device__ __forceinline__ int window_base(const ConvParams& p, int n0, int rem0, int add, float inv_ow)
+{
+    const int ohw = p.OH * p.OW;
+    int n = n0, rem = rem0 + add;
+    while (rem >= ohw) { rem -= ohw; ++n; }
+    int oy = (int)(((float)rem + 0.5f) * inv_ow);
+    int ox = rem - oy * p.OW;
+    if (ox < 0) { --oy; ox += p.OW; } else if (ox >= p.OW) { ++oy; ox -= p.OW; }
+    return ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
+}
+
+// Epilogue of a 32-pixel tile: bias + ReLU + bf16, transposed through the wave's 2 KB LDS stage so that the global stores
+// are 16 bytes per lane and contiguous across lanes (the direct 8-byte stores of the C/D layout cost the addresser one
+// lookup per lane: 31 us of conv2's 131).  Stage layout: [pixel][16-B chunk ^ f(pixel)], f spreads the 16 lanes of a
+// ds_write_b64 / ds_read_b128 group over the bank row.  NB = 2 (128 B per pixel) goes in two passes of 16 pixels.
+template <int NB>
+__device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int tile, int cbase, int lane)
+{
+    constexpr int CR = NB * 4;                                              // 16-B chunks per pixel row of this slice
+    constexpr int PP = 128 / CR;                                            // pixels per pass (2 KB stage)
+    const int r = lane & 31, h = lane >> 5;
+    const int crv = min(CR, (p.COUT - cbase) >> 3);                         // valid chunks (conv1: 3 of 4)
+    const unsigned magic = (65536u + (unsigned)crv - 1u) / (unsigned)crv;   // g / crv for g < 256
+    uint2* st2 = reinterpret_cast<uint2*>(stage);
+#pragma unroll
+    for (int pass = 0; pass < 32 / PP; ++pass) {
+        const int pr = r - pass * PP;                                       // pixel of this lane within the pass
+        if (pr >= 0 && pr < PP) {
+            const int f = NB == 1 ? (pr >> 1) & 3 : pr & 7;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = lbias[nb * 8 + 2 * q + h];
+                    float v0 = acc[nb][4 * q] + b.x, v1 = acc[nb][4 * q + 1] + b.y, v2 = acc[nb][4 * q + 2] + b.z, v3 = acc[nb][4 * q + 3] + b.w;
+                    if (p.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f; }
+                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+        }
+        const int total = PP * crv;                                         // 16-B chunks to write out in this pass
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = i * 64 + lane;
+            if (g < total) {
+                const int pix = (int)(((unsigned)g * magic) >> 16), c = g - pix * crv;
+                const int m = tile * 32 + pass * PP + pix;
+                const int f = NB == 1 ? (pix >> 1) & 3 : pix & 7;
+                if (m < p.M) {
+                    const u4v v = stage[pix * CR + (c ^ f)];
+                    *reinterpret_cast<u4v*>(static_cast<unsigned short*>(p.out) + (size_t)m * p.COUT + cbase + 8 * c) = v;
+                }
+            }
+        }
+    }
+}
+
+// conv1 (uint8 frame in, kPf = 3 trips = the whole K of 5 kernel rows x 16 bytes): resident weights, persistent workgroups,
+// independent waves, no barrier after the weight stage.  A wave walks 32-pixel tiles; the raw dwords of the NEXT tile are
+// requested before the current tile's MFMAs and epilogue, so their latency hides behind them.
+__global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NBW = 32, kGr = 6;                                        // granules per lane: 3 trips x 2 k-steps
+    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
+    int* lgoff = reinterpret_cast<int*>(psmem + (size_t)p.G_pad * NBW * 16);
+    const size_t off_bias = (size_t)p.G_pad * NBW * 16 + (((size_t)p.G_pad * 4 + 15) & ~(size_t)15);
+    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);           // [NBW / 4]
+    u4v* stage = reinterpret_cast<u4v*>(psmem + off_bias + NBW * 4) + wave * 128;   // 2 KB per wave: output transpose
+    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + 4 * i);
+    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
+        const int g = i / NBW, c = i - g * NBW;
+        lw[i] = p.w[(size_t)g * p.COUT_PAD + c];
+    }
+    for (int i = tid; i < p.G_pad; i += blockDim.x) lgoff[i] = p.goff[i];
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const int ohw = p.OH * p.OW;
+    const int ntiles = (p.M + 31) >> 5, stride = gridDim.x * nwaves;
+    const float inv_ow = 1.0f / (float)p.OW;
+    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
+    if (tile >= ntiles) return;
+    int goffs[kGr];                                                         // this lane's granules: k-step s, half h -> granule 2s + h
+#pragma unroll
+    for (int s = 0; s < kGr; ++s) goffs[s] = lgoff[min(2 * s + h, p.G_pad - 1)];
+    auto base_of = [&](int t) {                                             // t is wave-uniform: the frame split runs on the scalar unit
+        const int n0 = (t * 32) / ohw, rem0 = t * 32 - n0 * ohw;
+        return window_base(p, n0, rem0, min(r, p.M - 1 - t * 32), inv_ow);
+    };
+    unsigned raw[kGr][3];
+    int pixbase = base_of(tile);
+    auto request = [&](int pb) {
+#pragma unroll
+        for (int s = 0; s < kGr; ++s) {
+            const int al = (pb + goffs[s]) & ~3;
+            raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
+            raw[s][1] = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
+            raw[s][2] = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
+        }
+    };
+    request(pixbase);
+    while (true) {
+        // 8 of the 16 bytes of a kernel row at any byte alignment: byte-align, then exact u8 -> bf16 (0..255 is exact in
+        // bf16, so the upper half of the float IS the bf16)
+        bf16x8 x[kGr];
+#pragma unroll
+        for (int s = 0; s < kGr; ++s) {
+            const unsigned sh = (unsigned)(pixbase + goffs[s]) & 3u;
+            const unsigned lo = __builtin_amdgcn_alignbyte(raw[s][1], raw[s][0], sh);
+            const unsigned hi = __builtin_amdgcn_alignbyte(raw[s][2], raw[s][1], sh);
+            auto pair = [](unsigned w, int j) -> unsigned {
+                const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
+                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // (f0 >> 16) | (f1 & 0xffff0000)
+            };
+            const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
+            x[s] = __builtin_bit_cast(bf16x8, packed);
+        }
+        const int next = tile + stride;                                     // uniform
+        const int nbase = base_of(min(next, ntiles - 1));
+        request(nbase);                                                     // unconditional: the last tile re-requests itself
+        f32x16 acc[1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < kGr; ++s) {
+            if (2 * s < p.G_pad) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(2 * s + h) * NBW + r]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x[s], acc[0], 0, 0, 0);
+            }
+        }
+        store_tile<1>(stage, acc, lbias, p, tile, 0, lane);
+        if (next >= ntiles) break;
+        tile = next; pixbase = nbase;
+    }
+}
+
+// conv2..conv7 (bf16 input): resident weights + QUAD-COALESCED pixel loads.  Counters showed the per-lane 16-byte loads of
+// the kernel above cost the texture addresser one tag lookup per lane (56-88 per instruction: every lane another line) and
+// bound every layer.  Here the four lanes of a quad fetch the four consecutive granules (64 contiguous bytes) of ONE pixel,
+// so an instruction is 16 pixels x 64 B; the fragments reach the MFMA layout through a 2 KB wave-private LDS stage:
+//   load  (trip T, instruction i): lane l = 4q + jj holds granule 4T + j of pixel 16i + q, j = (jj - (q >> 2)) & 3
+//   write : lane l -> stage[i][l]                                  (linear, conflict-free)
+//   read  (k-step s): lane (r, h) wants granule j = 2s + h of pixel r  ->  stage[r >> 4][4q + ((j + (q >> 2)) & 3)], q = r & 15
+// The rotation by q >> 2 spreads the 16 lanes of every ds_read_b128 group over all 16 slots of the 256-B bank row.
+// Granules of a trip are contiguous in memory: k is ordered (kh, [kw, cin]) and a kernel row is one contiguous run of
+// KW * CIN / 8 granules in NHWC, padded to a multiple of 4 (only conv2: 15 -> 16, zero weights).
+template <int NB>
+__global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NBW = NB * 32;
+    const int cbase = blockIdx.y * NBW;
+    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
+    const size_t off_goff = (size_t)p.G_pad * NBW * 16;
+    const size_t off_bias = off_goff + (((size_t)p.G_pad * 4 + 15) & ~(size_t)15);
+    const size_t off_stage = off_bias + NBW * 4;
+    int* lgoff = reinterpret_cast<int*>(psmem + off_goff);
+    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);
+    u4v* stage = reinterpret_cast<u4v*>(psmem + off_stage) + wave * 128;   // [2][64] granules of this wave
+    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * i);
+    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
+        const int g = i / NBW, c = i - g * NBW;
+        lw[i] = p.w[(size_t)g * p.COUT_PAD + cbase + c];
+    }
+    for (int i = tid; i < p.G_pad; i += blockDim.x) lgoff[i] = p.goff[i];
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const int ohw = p.OH * p.OW;
+    const int ntiles = (p.M + 31) >> 5;
+    constexpr int kPf = kConvPrefetch;
+    // loader role of this lane: pixel 16 i + lq of the tile, granule lj of every trip
+    const int lq = lane >> 2, lj = ((lane & 3) - (lq >> 2)) & 3;
+    // reader role: slots of k-step 0 and 1 for pixel r, half h
+    const int rq = r & 15;
+    const int rd0 = (r >> 4) * 64 + 4 * rq + ((h + (rq >> 2)) & 3);
+    const int rd1 = (r >> 4) * 64 + 4 * rq + ((2 + h + (rq >> 2)) & 3);
+    const float inv_ow = 1.0f / (float)p.OW;
+    const int stride = gridDim.x * nwaves;
+    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
+    if (tile >= ntiles) return;
+    int lbase[2];
+    auto bases_of = [&](int t, int (&out)[2]) {                             // t is wave-uniform: the frame split runs on the scalar unit
+        const int n0 = (t * 32) / ohw, rem0 = t * 32 - n0 * ohw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) out[i] = window_base(p, n0, rem0, min(16 * i + lq, p.M - 1 - t * 32), inv_ow);
+    };
+    auto load_q = [&](int g4, int i) -> u4v {                               // g4 = first granule of the trip
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, lbase[i] + lgoff[g4 + lj], 0, 0);
+    };
+    u4v ring[2 * kPf];
+    auto preload = [&]() {
+#pragma unroll
+        for (int t = 0; t < kPf; ++t) {
+            const int g = min(4 * t, p.G_pad - 4);
+            ring[2 * t] = load_q(g, 0); ring[2 * t + 1] = load_q(g, 1);
+        }
+    };
+    bases_of(tile, lbase);
+    preload();
+    while (true) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+        auto trip_mfma = [&](int gt, int t) {
+#if TRS_CONV_ABLATE == 2
+            const bf16x8 x0 = __builtin_bit_cast(bf16x8, ring[2 * t]);
+            const bf16x8 x1 = __builtin_bit_cast(bf16x8, ring[2 * t + 1]);
+#else
+            stage[lane] = ring[2 * t];                                      // transpose through the wave's LDS stage (in-order per wave)
+            stage[64 + lane] = ring[2 * t + 1];
+            const bf16x8 x0 = __builtin_bit_cast(bf16x8, stage[rd0]);
+            const bf16x8 x1 = __builtin_bit_cast(bf16x8, stage[rd1]);
+#endif
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + h) * NBW + nb * 32 + r]);
+#if TRS_CONV_ABLATE == 3
+                acc[nb][0] += (float)w[0] * (float)x0[0];
+#else
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[nb], 0, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + 2 + h) * NBW + nb * 32 + r]);
+#if TRS_CONV_ABLATE == 3
+                acc[nb][1] += (float)w[0] * (float)x1[0];
+#else
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[nb], 0, 0, 0);
+#endif
+            }
+        };
+        int g2 = 0;
+        for (; g2 + 4 * kPf < p.G_pad; g2 += 4 * kPf) {
+#pragma unroll
+            for (int t = 0; t < kPf; ++t) {
+                trip_mfma(g2 + 4 * t, t);
+#if TRS_CONV_ABLATE != 1
+                const int gn = min(g2 + 4 * t + 4 * kPf, p.G_pad - 4);
+                ring[2 * t] = load_q(gn, 0); ring[2 * t + 1] = load_q(gn, 1);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kPf; ++t)
+            if (g2 + 4 * t < p.G_pad) trip_mfma(g2 + 4 * t, t);
+
+        // the next tile's first trips are requested before this tile's epilogue (unconditional: the last tile re-requests itself)
+        const int next = tile + stride;
+        bases_of(min(next, ntiles - 1), lbase);
+        preload();
+#if TRS_CONV_ABLATE != 4
+        store_tile<NB>(stage, acc, lbias, p, tile, cbase, lane);
+#endif
+        if (next >= ntiles) break;
+        tile = next;
     }
 }
 
@@ -231,11 +540,14 @@ __global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
 struct ConvLayer {
     int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad, gchunk, lds, ksplit = 1;
     bool u8in, out_f32, relu;
+    bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
+    int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
+    bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads) instead of trs_conv_resident_kernel
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
 
 struct PilotCtx {
-    int n_cap = 0, H = 0, W = 0;
+    int n_cap = 0, H = 0, W = 0, cu_count = 256;
     ConvLayer L[8];                       // conv1..7 + dense1 (1x1 "conv" over frames)
     void* act[8] = {};                    // outputs of L[i] for n_cap frames (bf16; act[7] float)
     size_t act_elems[8] = {};             // per frame
@@ -270,7 +582,7 @@ int upload(T** dst, const std::vector<T>& v)
     return TRS_OK;
 }
 
-int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s)
+int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count)
 {
     ConvParams p{};
     p.in = in; p.w = l.w; p.bias = l.bias; p.goff = l.goff; p.out = out;
@@ -280,6 +592,27 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
     p.ksplit = l.ksplit;
+    if (l.resident) {
+        const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
+        const int grid_x = std::max(1, std::min((ntiles + waves - 1) / waves, cu_count * l.res_wg_per_cu));
+#define LAUNCH_RES(NB, U8)                                                                                                   \
+    do {                                                                                                                     \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
+        hipLaunchKernelGGL((trs_conv_u8_kernel), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p); \
+    } while (0)
+#define LAUNCH_LT(NB)                                                                                                        \
+    do {                                                                                                                     \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_lt_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
+        hipLaunchKernelGGL((trs_conv_lt_kernel<NB>), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);        \
+    } while (0)
+        if (l.u8in) LAUNCH_RES(1, true);   // conv1
+        else if (l.res_lt && l.res_nb == 1) LAUNCH_LT(1);
+        else LAUNCH_LT(2);
+#undef LAUNCH_LT
+#undef LAUNCH_RES
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
+    }
     if (l.ksplit > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)p.M * l.COUT * sizeof(float), s));   // partial sums are added atomically
     const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
     const int nb = l.COUT_PAD / 32;
@@ -298,7 +631,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
     const void* in = d_frames;
     size_t in_bytes = (size_t)n * c->H * c->W * 3;
     for (int i = 0; i < 8; ++i) {
-        int rc = launch_conv(c->L[i], in, in_bytes, c->act[i], i == 7 ? n : n, v.stream);
+        int rc = launch_conv(c->L[i], in, in_bytes, c->act[i], n, v.stream, c->cu_count);
         if (rc) return rc;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
@@ -347,6 +680,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     if (*slot) { HIPCHK(hipStreamSynchronize(v.stream)); free_ctx(static_cast<PilotCtx*>(*slot)); *slot = nullptr; }
     PilotCtx* c = new PilotCtx();
     c->n_cap = v.n; c->H = v.H; c->W = v.W;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, v.device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     static const int spec[7][4] = {{5, 2, 3, 24}, {5, 2, 24, 32}, {5, 2, 32, 64}, {3, 1, 64, 64}, {3, 1, 64, 64}, {3, 1, 64, 128}, {3, 1, 128, 128}};
     int ih = v.H, iw = v.W;
     for (int i = 0; i < 8; ++i) {
@@ -357,7 +691,10 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         if (l.OH < 1 || l.OW < 1) { free_ctx(c); return trs_internal_fail(TRS_ERR_LIMIT, "image too small for Keras_2D_CNN"); }
         l.COUT_PAD = (l.COUT + 31) / 32 * 32;
         l.u8in = (i == 0); l.relu = true; l.out_f32 = (i == 7);
-        l.G = l.u8in ? 2 * l.KH : l.KH * l.KW * l.CIN / 8;
+        // granules: a kernel row is one contiguous run of KW * CIN / 8 granules in NHWC; runs are padded to whole trips of 4
+        // (zero weights) so that a trip is always 64 contiguous bytes (trs_conv_lt_kernel); dense1 is one long run
+        const int run = l.u8in ? 2 : l.KW * l.CIN / 8, run_pad = l.u8in ? 2 : (run + 3) & ~3;
+        l.G = l.KH * run_pad;
         l.G_pad = (l.G + 3) & ~3;
         l.gchunk = std::max(4, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~3));
         l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
@@ -365,6 +702,32 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             l.gchunk = std::min(l.gchunk, 16);
             l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
             l.ksplit = (l.G_pad + l.gchunk - 1) / l.gchunk;
+        }
+        if (i < 7) {       // conv layers: resident weights, at most 64 output channels per slice (NB <= 2 keeps 16 waves per CU in registers)
+            l.resident = true;
+            l.res_nb = std::min(2, l.COUT_PAD / 32);
+            l.res_ysplit = l.COUT_PAD / (32 * l.res_nb);
+            l.res_lt = !l.u8in;                                               // bf16 inputs: quad-coalesced loads + LDS transpose
+            const int stage_per_wave = 2048;                                  // input transpose (lt) / output transpose (both kernels)
+            auto lds_for = [&](int nb, int waves) { return l.G_pad * nb * 32 * 16 + ((l.G_pad * 4 + 15) & ~15) + nb * 32 * 4 + waves * stage_per_wave; };
+            if (lds_for(l.res_nb, 8) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // conv7: 32-channel slices
+            const int base = lds_for(l.res_nb, 0);
+            if (base + 4 * stage_per_wave > 160 * 1024) l.resident = false;    // does not happen for Keras_2D_CNN; the chunked kernel takes over
+            // workgroups per CU and waves per workgroup: about 16 waves per CU when LDS allows
+            l.res_wg_per_cu = 1;
+            for (int wg = 4; wg >= 1; --wg) {
+                const int waves = std::max(4, 16 / wg);
+                if (wg * (lds_for(l.res_nb, waves) + 512) <= 160 * 1024) { l.res_wg_per_cu = wg; break; }
+            }
+            int waves = std::max(4, 16 / l.res_wg_per_cu);
+            while (waves > 4 && l.res_wg_per_cu * (lds_for(l.res_nb, waves) + 512) > 160 * 1024) --waves;
+            l.res_block = 64 * waves;
+            l.res_lds = lds_for(l.res_nb, waves);
+            if (const char* e = std::getenv("TRS_PILOT_WAVES")) {            // tuning hook: waves per CU
+                const int wv = std::max(4, std::min(32, std::atoi(e)));
+                const int w2 = std::max(1, std::min(16, wv / l.res_wg_per_cu));
+                if (l.res_wg_per_cu * (lds_for(l.res_nb, w2) + 512) <= 160 * 1024) { l.res_block = 64 * w2; l.res_lds = lds_for(l.res_nb, w2); }
+            }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
         const float* K = arr[2 * i];
@@ -383,8 +746,10 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + ch) * l.COUT + co] / 255.0f);
                 }
             } else {
-                const int c8n = l.CIN / 8, kk = g / c8n, c8 = g % c8n, kh = kk / l.KW, kw = kk % l.KW;
-                goff[g] = ((kh * l.IW + kw) * l.CIN + c8 * 8) * 2;
+                const int kh = g / run_pad, gi = g % run_pad;                 // granule gi of kernel row kh
+                goff[g] = (kh * l.IW * l.CIN + gi * 8) * 2;
+                if (gi >= run) continue;                                      // run padding: next pixel's bytes x zero weights
+                const int c8n = l.CIN / 8, kw = gi / c8n, c8 = gi % c8n;
                 for (int j = 0; j < 8; ++j)
                     for (int co = 0; co < l.COUT; ++co)
                         wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + c8 * 8 + j) * l.COUT + co]);
