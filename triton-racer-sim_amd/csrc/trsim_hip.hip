@@ -79,6 +79,7 @@ struct RParams {                        // raster side of the step kernel
     int map_w, map_h, map_pitch_b;
     int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
     int depth;                          // 1 = also write the binary32 z-depth frame
+    int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -414,6 +415,15 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
+// Barrier among the waves of ONE team (the other team never arrives): every wave's LDS writes are complete before its
+// arrival is published; all lanes poll the counter (uniform address).
+__device__ __forceinline__ void team_barrier(int* counter, int n_waves, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_waves) __builtin_amdgcn_s_sleep(1);
+}
+
 template <bool DEPTH>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
@@ -428,50 +438,80 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         return;
     }
     STAMP(0);
-    // ---- prologue: each team stages the tables it reads (register-staged, all loads before the LDS writes) ----
-    if (raster_team) {
-        if (sp.r_last >= sp.r_first) {
-            const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-            u4v* dst = reinterpret_cast<u4v*>(smem);
-            const int n16 = p.blob_bytes >> 4;
-            u4v reg[kStageRegs];
-#pragma unroll
-            for (int r = 0; r < kStageRegs; ++r) { const int i = tid + r * kRasterThreads; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
-#pragma unroll
-            for (int r = 0; r < kStageRegs; ++r) { const int i = tid + r * kRasterThreads; if (i < n16) dst[i] = reg[r]; }
-        }
-    } else if (sp.n_phys > 0) {
-        const int st = tid - kRasterThreads;
-        constexpr int kT = kBlock - kRasterThreads;
-        const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
-        u4v* dst = reinterpret_cast<u4v*>(smem + sp.lds_off_phys);
-        const int n16 = sp.ph.blob_bytes >> 4;
-        for (int base = 0; base < n16; base += 8 * kT) {
-            u4v reg[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; if (i < n16) dst[i] = reg[r]; }
-        }
-    }
     const int e_begin = blockIdx.x * p.envs_per_wg;
     const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
     float4* const lcam = reinterpret_cast<float4*>(smem + sp.lds_off_cam);     // [n_phys][cam_stride]
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
-    for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
+    int* const tbar = pprog + sp.cam_stride;                                   // [0] class map staged (physics waves arrive), [1] physics team barrier
+    const bool rendering = sp.r_last >= sp.r_first;
+    for (int j = tid; j < sp.cam_stride + 2; j += kBlock) pprog[j] = 0;
+    // ---- prologue.  The raster team stages only its small tables (row table, palette, row depth: a few KB) and, for the
+    // frame of the step before this launch, the camera poses the previous launch left in the global ring; the ~90 KB class
+    // map is staged by the PHYSICS team while the raster team already writes the rows that do not need it. ----
+    const int map16 = p.off_rowtab >> 4;
+    float4* const lcam_prev = lcam + max(sp.n_phys, 1) * sp.cam_stride;       // [cam_stride] poses of step_base - 1
+    if (raster_team && rendering) {
+        const u4v* src = reinterpret_cast<const u4v*>(p.blob);
+        u4v* dst = reinterpret_cast<u4v*>(smem);
+        const int n16 = p.blob_bytes >> 4;
+        // both loads are requested before either is waited for (one global round trip, not two)
+        const float4* const cam_prev = sp.ph.cam + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
+        const bool has_t = map16 + tid < n16, has_c = sp.r_first < 0 && tid < e_end - e_begin;
+        u4v tv = (u4v)(0u);
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_t) tv = src[map16 + tid];
+        if (has_c) cv = cam_prev[e_begin + tid];
+        if (has_t) dst[map16 + tid] = tv;
+        if (has_c) lcam_prev[tid] = cv;
+        for (int i = map16 + tid + kRasterThreads; i < n16; i += kRasterThreads) dst[i] = src[i];                 // tall images
+        if (sp.r_first < 0)
+            for (int j = tid + kRasterThreads; j < e_end - e_begin; j += kRasterThreads) lcam_prev[j] = cam_prev[e_begin + j];
+    }
     STAMP(1);
-    __syncthreads();
+    __syncthreads();                                                          // tables, poses and zeroed counters visible
     STAMP(2);
 
-    // ---- physics team: one wave per env, no workgroup synchronisation; runs up to n_phys steps ahead of the raster ----
+    // ---- physics team: stages its own track image, then one wave per env, no workgroup synchronisation; runs up to
+    // n_phys steps ahead of the raster ----
     if (!raster_team) {
+        const int st = tid - kRasterThreads;
+        constexpr int kT = kBlock - kRasterThreads;
+        if (rendering) {
+            // the raster team's class map goes global -> LDS directly (LDS-DMA, no registers, no ds_write pass: five waves
+            // writing 90 KB with ds_write_b128 took 6,000 cycles, the DMA form is bound by the loads alone); one
+            // instruction = 64 lanes x 16 B = 1 KB, lane-linear, which is exactly the map's linear image at LDS offset 0
+            const u4v* src = reinterpret_cast<const u4v*>(p.blob);
+            const int pw0 = wave - kRasterThreads / 64;
+            for (int g0 = pw0 * 64; g0 < map16; g0 += kPhysWaves * 64) {
+                const int g = g0 + lane;
+                if (g < map16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
+                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(g0 * 16), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&tbar[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // map ready: 5 arrivals
+        }
+        if (sp.n_phys <= 0) return;
+        {
+            const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
+            u4v* dst = reinterpret_cast<u4v*>(smem + sp.lds_off_phys);
+            const int n16 = sp.ph.blob_bytes >> 4;
+            for (int base = 0; base < n16; base += 8 * kT) {
+                u4v preg[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; preg[r] = (i < n16) ? src[i] : (u4v)(0u); }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; if (i < n16) dst[i] = preg[r]; }
+            }
+            team_barrier(&tbar[1], kPhysWaves, lane);
+        }
         float4* const ring = sp.ph.cam;
         const unsigned char* const lphys = smem + sp.lds_off_phys;
         const int pw = wave - kRasterThreads / 64;
         if (p.envs_per_wg <= kPhysWaves) {
             // at most one env per physics wave: its state lives in registers for all the steps of this launch
             const int e = e_begin + pw;
-            if (e < e_end && sp.n_phys > 0) {
+            if (e < e_end) {
                 const int j = e - e_begin;
                 EnvRegs st;
                 env_load(sp.ph, e, st);
@@ -499,12 +539,15 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         STAMP(3);
         return;
     }
-    if (sp.r_last < sp.r_first) return;
+    if (!rendering) return;
 
     // ---- raster team ----
     // A thread owns one 4-pixel column group (u0 fixed) and walks image rows, so the pixel-centre offsets uf are
-    // loop constants.  Per pixel: 1 packed fma (gx,gz), 2 saturating converts + 2 min (= floor + clamp), 3 address
-    // ops, 1 LDS map read, shift + bit-field extract, 1 palette address op, 1 LDS palette read.
+    // loop constants.  The first `uni_rows` rows (sky, ground beyond the far plane) have four equal class colours: they
+    // need neither the class map nor the camera pose and are written FIRST, while the map is still on its way and (in a
+    // single-step call) while the physics team integrates.  Per pixel of the other rows: 1 packed fma (gx,gz), 2
+    // saturating converts + 2 min (= floor + clamp), 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette
+    // address op, 1 LDS palette read.
     const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
     const float* lrowdepth = reinterpret_cast<const float*>(smem + p.off_depth);
     const float half_w = (float)(p.W / 2);
@@ -514,32 +557,60 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
     const unsigned pitch = (unsigned)p.map_pitch_b;
     const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
+    int vground = vstart;                                // this thread's first row that needs the map
+    while (vground < p.uni_rows) vground += p.rows_per_pass;
     const size_t row_bytes = (size_t)p.gpr * 12;
+    const int col_off = cg * 12;
+    bool map_ready = false;
     for (int sidx = sp.r_first; sidx <= sp.r_last; ++sidx) {
     const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
     uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
-    const float4* const cam_prev = sp.ph.cam + (size_t)(abs_step & (kRing - 1)) * sp.ph.n_envs;
+    float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
+    // rows with four equal class colours need no map and no pose: each wave writes them for its NEXT envs for as long as
+    // the class map is still on its way (the stores keep HBM busy during the wait), at the latest right before an env's
+    // other rows
+    int e_u = e_begin;                                                        // first env whose uniform rows this wave has not written yet
+    auto uniform_rows = [&](int e) {
+        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
+            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+        __amdgpu_buffer_rsrc_t udrs = ursrc;
+        if constexpr (DEPTH) udrs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+        for (int v = vstart; v < p.uni_rows; v += p.rows_per_pass) {
+            const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)v << 4));
+            const u3v px3 = {__builtin_amdgcn_perm(c, c, 0x04020100u), __builtin_amdgcn_perm(c, c, 0x05040201u), __builtin_amdgcn_perm(c, c, 0x06050402u)};
+            __builtin_amdgcn_raw_buffer_store_b96(px3, ursrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
+            if constexpr (DEPTH) {
+                const unsigned dz = __float_as_uint(lrowdepth[v]);
+                const u4v d4 = {dz, dz, dz, dz};
+                __builtin_amdgcn_raw_buffer_store_b128(d4, udrs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+            }
+        }
+    };
     for (int e = e_begin; e < e_end; ++e) {
+        if (e_u <= e) { uniform_rows(e_u); ++e_u; }
+        if (!map_ready) {                                                     // once per launch: the physics team stages the class map
+            while (e_u < e_end && __hip_atomic_load(&tbar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPhysWaves) { uniform_rows(e_u); ++e_u; }
+            while (__hip_atomic_load(&tbar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPhysWaves) __builtin_amdgcn_s_sleep(1);
+            map_ready = true;
+            STAMP(4);
+        }
+        // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+        __amdgpu_buffer_rsrc_t drs = rsrc;
+        if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+        // -- rows that see the track
         float4 cam;
+        const int j = e - e_begin;
         if (sidx < 0) {
-            cam = cam_prev[e];                                                // written by the previous launch
-        } else {
-            const int j = e - e_begin;                                        // wait until the physics team has finished this step of env j
+            cam = lcam_prev[j];                                               // written by the previous launch, staged in the prologue
+        } else {                                                              // wait until the physics team has finished this step of env j
             while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
             cam = lcam[sidx * sp.cam_stride + j];
         }
         const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-        // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
-        const int col_off = cg * 12;
-        __amdgpu_buffer_rsrc_t drs = rsrc;
-        if constexpr (DEPTH) {
-            float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
-            drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
-        }
-        f2v rt = lrow[vstart < p.H ? vstart : 0];
-        for (int v = vstart; v < p.H; v += p.rows_per_pass) {
+        f2v rt = lrow[vground < p.H ? vground : 0];
+        for (int v = vground; v < p.H; v += p.rows_per_pass) {
             const int vn = v + p.rows_per_pass;
             const f2v rtn = lrow[vn < p.H ? vn : v];                            // prefetch the next row's table entry
             const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
@@ -1046,8 +1117,8 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.lds_off_phys = e->lds_off_phys;
     sp.cam_stride = e->pp.envs_per_wg;
     sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
-    sp.lds_off_prog = sp.lds_off_cam + std::max(n_phys, 1) * sp.cam_stride * 16;
-    const int lds = sp.lds_off_prog + sp.cam_stride * 4;
+    sp.lds_off_prog = sp.lds_off_cam + (std::max(n_phys, 1) + 1) * sp.cam_stride * 16;   // + one row: poses of the step before the launch
+    const int lds = sp.lds_off_prog + sp.cam_stride * 4 + 16;                      // + the two team-barrier counters
 #ifndef TRS_SINGLE_VARIANT   /* A/B switch: build without the depth instantiation (HIP guide rule 19: co-compiled variants perturb each other) */
     if (e->rp.depth) hipLaunchKernelGGL(trs_step_kernel<true>, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
     else
@@ -1291,7 +1362,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
-        const int free_b = 160 * 1024 - e->lds_step - epw * 4;
+        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16;
         e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
@@ -1321,7 +1392,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(e->stats, 0, 64 * sizeof(unsigned long long)));
     e->step_count = 0;
     e->track_loaded = true;
-    return e->has_frame_filter ? upload_palette(e) : TRS_OK;
+    return upload_palette(e);                 // also sets rp.uni_rows (and applies a frame filter that was set earlier)
 }
 
 TRS_EXPORT int trs_reset(trs_env* e, const uint8_t* h_mask)
@@ -1535,6 +1606,13 @@ uint32_t filter_colour(const trs_pre_config& c, uint32_t bgr)
     return (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16);
 }
 
+int leading_uniform_rows(const std::vector<uint32_t>& pal, int H)
+{
+    int u = 0;
+    while (u < H && pal[4 * u] == pal[4 * u + 1] && pal[4 * u] == pal[4 * u + 2] && pal[4 * u] == pal[4 * u + 3]) ++u;
+    return u;
+}
+
 // (re)write the palette of the raster LDS image: raw, or filtered when a frame filter is set
 int upload_palette(trs_env* e)
 {
@@ -1542,6 +1620,7 @@ int upload_palette(trs_env* e)
     std::vector<uint32_t> pal(e->tab.palette);
     if (e->has_frame_filter)
         for (auto& c : pal) c = filter_colour(e->frame_filter, c);
+    e->rp.uni_rows = leading_uniform_rows(pal, e->H);
     HIPCHK(hipStreamSynchronize(e->sP));                       // frames in flight keep the palette they were launched with
     HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
     return TRS_OK;
