@@ -1,7 +1,14 @@
 #!/bin/bash
-# A/B of the step kernel: library built from git HEAD (committed) vs the working tree, alternating runs in one session
+# A/B of the step kernel: library built from an older git ref vs the working tree, alternating runs in one session.
+#   here (has .git):    scripts/step_ab.sh prepare <ref>      -> copies that ref's csrc into scripts/ab_old/ (git-ignored)
+#   on the GPU box:     gpurun -- 'bash scripts/step_ab.sh'
 set -e
 cd "$(dirname "$0")/.."
+if [ "$1" = prepare ]; then
+  mkdir -p scripts/ab_old
+  for f in trsim_hip.hip trsim_pilot.hip trsim_tables.cpp trsim_tables.hpp trsim_internal.hpp; do git show "${2:-HEAD}:triton-racer-sim_amd/csrc/$f" > scripts/ab_old/$f; done
+  exit 0
+fi
 C=triton-racer-sim_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ffp-contract=off -fno-fast-math"
 /opt/rocm/bin/hipcc $FLAGS -I. -o /tmp/libtrsim_new.so $C/trsim_hip.hip $C/trsim_pilot.hip $C/trsim_tables.cpp 2>/dev/null &
