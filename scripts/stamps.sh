@@ -11,7 +11,7 @@ from triton_racer_sim_amd.env import BatchedEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 env = BatchedEnv(n_envs=n, auto_reset=True)
 env.step_synthetic(50, 1)
-names = ["entry", "tables staged", "barrier passed", "physics done (phys wave)", "uniform rows done + map ready", "raster done"]
+names = ["entry", "DMA + poses requested", "barrier passed (all staged)", "physics done (phys wave)", "(unused)", "raster done"]
 acc = []
 for _ in range(10):
     env.step_synthetic(6, 1)          # pipelined: last full launch before the raster-only flush is what remains in the slots

@@ -415,15 +415,6 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
-// Barrier among the waves of ONE team (the other team never arrives): every wave's LDS writes are complete before its
-// arrival is published; all lanes poll the counter (uniform address).
-__device__ __forceinline__ void team_barrier(int* counter, int n_waves, int lane)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_waves) __builtin_amdgcn_s_sleep(1);
-}
-
 template <bool DEPTH>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
@@ -442,72 +433,54 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const int e_end = min(e_begin + p.envs_per_wg, p.n_envs);
     float4* const lcam = reinterpret_cast<float4*>(smem + sp.lds_off_cam);     // [n_phys][cam_stride]
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
-    int* const tbar = pprog + sp.cam_stride;                                   // [0] class map staged (physics waves arrive), [1] physics team barrier
     const bool rendering = sp.r_last >= sp.r_first;
-    for (int j = tid; j < sp.cam_stride + 2; j += kBlock) pprog[j] = 0;
-    // ---- prologue.  The raster team stages only its small tables (row table, palette, row depth: a few KB) and, for the
-    // frame of the step before this launch, the camera poses the previous launch left in the global ring; the ~90 KB class
-    // map is staged by the PHYSICS team while the raster team already writes the rows that do not need it. ----
-    const int map16 = p.off_rowtab >> 4;
+    for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
+    // ---- prologue: everything is staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves
+    // 64 lanes x 16 B = 1 KB, lane-linear, no registers and no ds_write pass), all requests are in flight together and
+    // one workgroup barrier closes the stage.  Raster waves: the class map + row tables (one linear image at LDS offset
+    // 0); physics waves: the track image.  The previous step's poses ride along through a register. ----
+    const int pw = wave - kRasterThreads / 64;                                // physics wave index (< 0 for the raster team)
     float4* const lcam_prev = lcam + max(sp.n_phys, 1) * sp.cam_stride;       // [cam_stride] poses of step_base - 1
-    if (raster_team && rendering) {
-        const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-        u4v* dst = reinterpret_cast<u4v*>(smem);
-        const int n16 = p.blob_bytes >> 4;
-        // both loads are requested before either is waited for (one global round trip, not two)
-        const float4* const cam_prev = sp.ph.cam + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
-        const bool has_t = map16 + tid < n16, has_c = sp.r_first < 0 && tid < e_end - e_begin;
-        u4v tv = (u4v)(0u);
+    {
+        const bool has_c = raster_team && rendering && sp.r_first < 0 && tid < e_end - e_begin;
         float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_t) tv = src[map16 + tid];
+        const float4* const cam_prev = sp.ph.cam + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
         if (has_c) cv = cam_prev[e_begin + tid];
-        if (has_t) dst[map16 + tid] = tv;
+        if (raster_team) {
+            if (rendering) {
+                const u4v* src = reinterpret_cast<const u4v*>(p.blob);
+                const int n16 = p.blob_bytes >> 4;
+                for (int g0 = wave * 64; g0 < n16; g0 += (kRasterThreads / 64) * 64) {
+                    const int g = g0 + lane;
+                    if (g < n16)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
+                                                         (__attribute__((address_space(3))) void*)(uintptr_t)(g0 * 16), 16, 0, 0);
+                }
+            }
+        } else if (sp.n_phys > 0) {
+            const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
+            const int n16 = sp.ph.blob_bytes >> 4;
+            for (int g0 = pw * 64; g0 < n16; g0 += kPhysWaves * 64) {
+                const int g = g0 + lane;
+                if (g < n16)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
+                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(sp.lds_off_phys + g0 * 16), 16, 0, 0);
+            }
+        }
         if (has_c) lcam_prev[tid] = cv;
-        for (int i = map16 + tid + kRasterThreads; i < n16; i += kRasterThreads) dst[i] = src[i];                 // tall images
-        if (sp.r_first < 0)
+        if (raster_team && rendering && sp.r_first < 0)
             for (int j = tid + kRasterThreads; j < e_end - e_begin; j += kRasterThreads) lcam_prev[j] = cam_prev[e_begin + j];
     }
     STAMP(1);
-    __syncthreads();                                                          // tables, poses and zeroed counters visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's DMA pieces have landed
+    __syncthreads();
     STAMP(2);
 
-    // ---- physics team: stages its own track image, then one wave per env, no workgroup synchronisation; runs up to
-    // n_phys steps ahead of the raster ----
+    // ---- physics team: one wave per env, no workgroup synchronisation; runs up to n_phys steps ahead of the raster ----
     if (!raster_team) {
-        const int st = tid - kRasterThreads;
-        constexpr int kT = kBlock - kRasterThreads;
-        if (rendering) {
-            // the raster team's class map goes global -> LDS directly (LDS-DMA, no registers, no ds_write pass: five waves
-            // writing 90 KB with ds_write_b128 took 6,000 cycles, the DMA form is bound by the loads alone); one
-            // instruction = 64 lanes x 16 B = 1 KB, lane-linear, which is exactly the map's linear image at LDS offset 0
-            const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-            const int pw0 = wave - kRasterThreads / 64;
-            for (int g0 = pw0 * 64; g0 < map16; g0 += kPhysWaves * 64) {
-                const int g = g0 + lane;
-                if (g < map16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
-                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(g0 * 16), 16, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&tbar[0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // map ready: 5 arrivals
-        }
         if (sp.n_phys <= 0) return;
-        {
-            const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
-            u4v* dst = reinterpret_cast<u4v*>(smem + sp.lds_off_phys);
-            const int n16 = sp.ph.blob_bytes >> 4;
-            for (int base = 0; base < n16; base += 8 * kT) {
-                u4v preg[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; preg[r] = (i < n16) ? src[i] : (u4v)(0u); }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { const int i = base + st + r * kT; if (i < n16) dst[i] = preg[r]; }
-            }
-            team_barrier(&tbar[1], kPhysWaves, lane);
-        }
         float4* const ring = sp.ph.cam;
         const unsigned char* const lphys = smem + sp.lds_off_phys;
-        const int pw = wave - kRasterThreads / 64;
         if (p.envs_per_wg <= kPhysWaves) {
             // at most one env per physics wave: its state lives in registers for all the steps of this launch
             const int e = e_begin + pw;
@@ -561,15 +534,12 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     while (vground < p.uni_rows) vground += p.rows_per_pass;
     const size_t row_bytes = (size_t)p.gpr * 12;
     const int col_off = cg * 12;
-    bool map_ready = false;
     for (int sidx = sp.r_first; sidx <= sp.r_last; ++sidx) {
     const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
     uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
     float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
-    // rows with four equal class colours need no map and no pose: each wave writes them for its NEXT envs for as long as
-    // the class map is still on its way (the stores keep HBM busy during the wait), at the latest right before an env's
-    // other rows
-    int e_u = e_begin;                                                        // first env whose uniform rows this wave has not written yet
+    // rows with four equal class colours need no map lookup and no pose: one palette read per 4 pixels, and in a
+    // single-step call they are written while the physics team still integrates
     auto uniform_rows = [&](int e) {
         const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
             img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
@@ -587,13 +557,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         }
     };
     for (int e = e_begin; e < e_end; ++e) {
-        if (e_u <= e) { uniform_rows(e_u); ++e_u; }
-        if (!map_ready) {                                                     // once per launch: the physics team stages the class map
-            while (e_u < e_end && __hip_atomic_load(&tbar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPhysWaves) { uniform_rows(e_u); ++e_u; }
-            while (__hip_atomic_load(&tbar[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kPhysWaves) __builtin_amdgcn_s_sleep(1);
-            map_ready = true;
-            STAMP(4);
-        }
+        uniform_rows(e);
         // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
