@@ -391,17 +391,17 @@ constexpr int kPhysBlock = 256;
 __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {
+    {   // the track image goes global -> LDS by LDS-DMA (1 KB per wave instruction, no registers, no ds_write pass)
         const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-        u4v* dst = reinterpret_cast<u4v*>(smem);
         const int n16 = p.blob_bytes >> 4;
-        for (int base = 0; base < n16; base += 8 * kPhysBlock) {
-            u4v reg[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { const int i = base + tid + r * kPhysBlock; reg[r] = (i < n16) ? src[i] : (u4v)(0u); }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { const int i = base + tid + r * kPhysBlock; if (i < n16) dst[i] = reg[r]; }
+        const unsigned lds_base = (unsigned)(uintptr_t)smem;                  // LDS byte address of the dynamic segment
+        for (int g0 = wave * 64; g0 < n16; g0 += (kPhysBlock / 64) * 64) {
+            const int g = g0 + lane;
+            if (g < n16)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + g0 * 16), 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float4* const lsink = reinterpret_cast<float4*>(smem + p.off_scratch);          // per-wave sinks for the camera hand-off slots
     int* const psink = reinterpret_cast<int*>(smem + p.off_scratch + (kPhysBlock / 64) * 16);
