@@ -62,6 +62,7 @@ struct ConvParams {
     int gchunk;                // granules per LDS stage (even)
     int relu, out_f32, in_px_bytes;   // in_px_bytes: bytes per input pixel (CIN*2, conv1: 3)
     int ksplit;                // > 1: blockIdx.y owns a slice of the granules and adds its partial sums atomically (fp32 out, no ReLU)
+    int KH, KW, run_pad, cg, span_nl;   // span kernel: kernel rows, granules per kernel row (padded), granules per pixel, load instructions per kernel row
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
@@ -472,6 +473,111 @@ __global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
     }
 }
 
+// conv2 / conv3 (stride-2 5x5): overlapping windows make the kernel above fetch every input byte ~2.5x, and the texture
+// addresser (about one lookup per clock) is what bounds these layers.  Here a wave stages, per kernel row, the CONTIGUOUS
+// input span its 32-pixel tile needs (a tile crosses output rows, so the span is 1..4 segments, one per output row touched)
+// with fully coalesced 1 KB loads, writes it to a wave-private LDS stage, and reads the im2col fragments from there:
+//   virtual granule v of the stage = segment start c_s + (input granule within the segment's span)
+//   loader lane l, instruction k: v = 64 k + l  ->  global address base_s + kh * row_bytes + 16 (v - c_s)
+//   reader lane (pixel r = segment s, position q; half h), k-step t: v = c_s + q * S * cg + 2 t + h
+// The next kernel row's span is requested (registers) before the current row's MFMAs; SWZ (pixel stride of 8 granules,
+// conv3) XOR-swizzles the stage so a ds_read_b128 group covers all 16 slots of the bank row.
+template <int NB, bool SWZ>
+__global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
+{
+    constexpr int kMaxNl = 5, kMaxSeg = 4;                                  // 12 waves per workgroup at most: the segment bookkeeping wants ~150 VGPRs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    constexpr int NBW = NB * 32;
+    const int cbase = blockIdx.y * NBW;
+    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
+    const size_t off_bias = (size_t)p.G_pad * NBW * 16;
+    const size_t off_stage = off_bias + NBW * 4;
+    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);
+    u4v* stage = reinterpret_cast<u4v*>(psmem + off_stage) + wave * (p.span_nl * 64);   // span_nl KB per wave
+    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * i);
+    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
+        const int g = i / NBW, c = i - g * NBW;
+        lw[i] = p.w[(size_t)g * p.COUT_PAD + cbase + c];
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const int ohw = p.OH * p.OW;
+    const int ntiles = (p.M + 31) >> 5, stride = gridDim.x * nwaves;
+    const int row_bytes = p.IW * p.in_px_bytes;
+    const int pix_gran = p.S * p.cg;                                        // granules between neighbouring output pixels
+    const int tail = p.run_pad;                                             // granules a segment's last pixel needs (window + run padding)
+    auto swz = [](int v) { return SWZ ? v ^ ((v >> 4) & 7) : v; };
+
+    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
+    if (tile >= ntiles) return;
+    int laddr[kMaxNl];                                                      // loader: byte address of this lane's granule of instruction k, kernel row 0
+    auto setup = [&](int t, int& roff) {                                    // roff: virtual granule of this lane's pixel, k-step 0, half h
+        // t is wave-uniform: the segment list is scalar work
+        const int m0 = t * 32;
+        const int n0 = m0 / ohw, rem0 = m0 - n0 * ohw;
+        int n = n0, oy = rem0 / p.OW, ox = rem0 - oy * p.OW;
+        int left = 32, cum = 0, c = 0;
+        roff = 0;
+#pragma unroll
+        for (int k = 0; k < kMaxNl; ++k) laddr[k] = p.in_bytes;             // out of range: the buffer load returns zeros
+#pragma unroll
+        for (int sgi = 0; sgi < kMaxSeg; ++sgi) {
+            if (left > 0) {
+                const int len = min(left, p.OW - ox);
+                const int sg = (len - 1) * pix_gran + tail;                 // granules of this segment's span
+                const int base = ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
+                if (r >= cum && r < cum + len) roff = c + (r - cum) * pix_gran + h;
+#pragma unroll
+                for (int k = 0; k < kMaxNl; ++k) {
+                    const int v = 64 * k + lane;
+                    if (k < p.span_nl && v >= c && v < c + sg) laddr[k] = base + (v - c) * 16;
+                }
+                left -= len; cum += len; c += sg;
+                ox = 0; ++oy;
+                if (oy == p.OH) { oy = 0; ++n; }
+            }
+        }
+    };
+    u4v regs[kMaxNl];
+    auto request = [&](int kh) {
+#pragma unroll
+        for (int k = 0; k < kMaxNl; ++k)
+            if (k < p.span_nl) regs[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, laddr[k] == p.in_bytes ? p.in_bytes : laddr[k] + kh * row_bytes, 0, 0);
+    };
+    int roff_cur = 0, roff_next = 0;
+    setup(tile, roff_cur);
+    request(0);
+    while (true) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+        const int next = tile + stride;                                     // uniform
+        for (int kh = 0; kh < p.KH; ++kh) {
+#pragma unroll
+            for (int k = 0; k < kMaxNl; ++k)
+                if (k < p.span_nl) stage[swz(64 * k + lane)] = regs[k];     // this kernel row's span -> LDS (in-order per wave)
+            if (kh + 1 < p.KH) request(kh + 1);                             // uniform branch; next row's span flies during the MFMAs
+            else { setup(min(next, ntiles - 1), roff_next); request(0); }   // ... or the next tile's first row (the last tile re-requests itself)
+            const int gbase = kh * p.run_pad;
+            for (int t = 0; t < p.run_pad; t += 2) {                        // (fetching step t + 1's fragments by hand before step t's MFMAs measured 5-10 % slower)
+                const bf16x8 x = __builtin_bit_cast(bf16x8, stage[swz(roff_cur + t)]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gbase + t + h) * NBW + nb * 32 + r]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+        store_tile<NB>(stage, acc, lbias, p, tile, cbase, lane);
+        if (next >= ntiles) break;
+        tile = next; roff_cur = roff_next;
+    }
+}
+
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
 struct TailParams {
     const float* h1;           // [n][100] dense1 output (after ReLU), fp32
@@ -542,7 +648,8 @@ struct ConvLayer {
     bool u8in, out_f32, relu;
     bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
-    bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads) instead of trs_conv_resident_kernel
+    bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
+    bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
 
@@ -592,6 +699,7 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
     p.ksplit = l.ksplit;
+    p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
     if (l.resident) {
         const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
         const int grid_x = std::max(1, std::min((ntiles + waves - 1) / waves, cu_count * l.res_wg_per_cu));
@@ -605,10 +713,21 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_lt_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
         hipLaunchKernelGGL((trs_conv_lt_kernel<NB>), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);        \
     } while (0)
+#define LAUNCH_SPAN(NB, SW)                                                                                                  \
+    do {                                                                                                                     \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_span_kernel<NB, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
+        hipLaunchKernelGGL((trs_conv_span_kernel<NB, SW>), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);  \
+    } while (0)
+        const bool swz = (l.S * (l.CIN / 8)) % 8 == 0;
         if (l.u8in) LAUNCH_RES(1, true);   // conv1
+        else if (l.res_span && l.res_nb == 1 && swz) LAUNCH_SPAN(1, true);
+        else if (l.res_span && l.res_nb == 1) LAUNCH_SPAN(1, false);
+        else if (l.res_span && swz) LAUNCH_SPAN(2, true);
+        else if (l.res_span) LAUNCH_SPAN(2, false);
         else if (l.res_lt && l.res_nb == 1) LAUNCH_LT(1);
         else LAUNCH_LT(2);
 #undef LAUNCH_LT
+#undef LAUNCH_SPAN
 #undef LAUNCH_RES
         HIPCHK(hipGetLastError());
         return TRS_OK;
@@ -708,9 +827,22 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             l.res_nb = std::min(2, l.COUT_PAD / 32);
             l.res_ysplit = l.COUT_PAD / (32 * l.res_nb);
             l.res_lt = !l.u8in;                                               // bf16 inputs: quad-coalesced loads + LDS transpose
-            const int stage_per_wave = 2048;                                  // input transpose (lt) / output transpose (both kernels)
+            l.run_pad = run_pad;
+            // stride-2 layers with wide kernels re-fetch every byte ~2.5x through overlapping windows: span staging instead
+            const int cgr = l.CIN / 8, pix_gran = l.S * cgr;
+            const int nseg_max = 30 / l.OW + 2;
+            int span_mask = 0x6;                                              // bit i = conv(i+1) uses the span kernel: conv2 and conv3
+            if (const char* e = std::getenv("TRS_PILOT_SPAN_LAYERS")) span_mask = std::atoi(e);
+            l.res_span = !l.u8in && l.S == 2 && l.KW >= 5 && nseg_max <= 4 && ((span_mask >> i) & 1);
+            if (l.res_span) {
+                l.span_nl = ((32 - nseg_max) * pix_gran + nseg_max * run_pad + 63) / 64;
+                if (l.span_nl > 5) l.res_span = false;
+            }
+            const int stage_per_wave = l.res_span ? l.span_nl * 1024 : 2048;  // input transpose / span stage; output transpose (all kernels)
             auto lds_for = [&](int nb, int waves) { return l.G_pad * nb * 32 * 16 + ((l.G_pad * 4 + 15) & ~15) + nb * 32 * 4 + waves * stage_per_wave; };
-            if (lds_for(l.res_nb, 8) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // conv7: 32-channel slices
+            int min_waves = 8;
+            if (const char* e = std::getenv("TRS_PILOT_MIN_WAVES")) min_waves = std::atoi(e);
+            if (lds_for(l.res_nb, min_waves) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // conv7: 32-channel slices
             const int base = lds_for(l.res_nb, 0);
             if (base + 4 * stage_per_wave > 160 * 1024) l.resident = false;    // does not happen for Keras_2D_CNN; the chunked kernel takes over
             // workgroups per CU and waves per workgroup: about 16 waves per CU when LDS allows
@@ -720,6 +852,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 if (wg * (lds_for(l.res_nb, waves) + 512) <= 160 * 1024) { l.res_wg_per_cu = wg; break; }
             }
             int waves = std::max(4, 16 / l.res_wg_per_cu);
+            if (l.res_span) waves = std::min(waves, 12);                      // trs_conv_span_kernel is built for <= 768 threads
             while (waves > 4 && l.res_wg_per_cu * (lds_for(l.res_nb, waves) + 512) > 160 * 1024) --waves;
             l.res_block = 64 * waves;
             l.res_lds = lds_for(l.res_nb, waves);
