@@ -139,6 +139,12 @@ int trs_get_state(trs_env* env, trs_state_view* out);
 /* Synchronising copy of one field to host memory (`which` = TRS_F_*). `bytes` must match. */
 int trs_copy_to_host(trs_env* env, int which, void* h_dst, size_t bytes);
 
+/* What GymInterface.step returns (components/gyminterface.py:76), all fields of all envs in ONE synchronisation: the
+ * copies are queued behind the last step on the handle's stream into a pinned staging buffer, followed by a single
+ * stream wait.  Any pointer may be NULL.  h_img: uint8[n_envs][H][W][3]; the others n_envs elements each. */
+int trs_fetch_outputs(trs_env* env, uint8_t* h_img, float* h_x, float* h_y, float* h_z, float* h_speed, float* h_cte,
+                      int32_t* h_seg_idx, uint8_t* h_done);
+
 /* Overwrite env pose (x, y, z, yaw, v) from host arrays of n_envs floats — test hook. */
 int trs_set_pose(trs_env* env, const float* h_x, const float* h_y, const float* h_z,
                  const float* h_yaw, const float* h_v);

@@ -525,6 +525,22 @@ EXPORT int trso_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     return TRS_OK;
 }
 
+EXPORT int trso_fetch_outputs(trs_env* e, uint8_t* img, float* x, float* y, float* z, float* speed, float* cte, int32_t* seg, uint8_t* done)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    if (img && !e->img) return fail(TRS_ERR_STATE, "the env has no camera (cfg.render == 0)");
+    size_t n = (size_t)e->n;
+    if (img) memcpy(img, e->img, n * e->H * e->W * 3);
+    if (x) memcpy(x, e->x, n * 4);
+    if (y) memcpy(y, e->y, n * 4);
+    if (z) memcpy(z, e->z, n * 4);
+    if (speed) memcpy(speed, e->speed, n * 4);
+    if (cte) memcpy(cte, e->cte, n * 4);
+    if (seg) memcpy(seg, e->seg_idx, n * 4);
+    if (done) memcpy(done, e->done, n);
+    return TRS_OK;
+}
+
 EXPORT int trso_set_pose(trs_env* e, const float* x, const float* y, const float* z, const float* yaw, const float* v)
 {
     if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");

@@ -244,3 +244,21 @@ def test_device_pointer_controls_from_torch(make_env):
     assert np.array_equal(frames.cpu().numpy(), o.fetch("img"))
     ret = torch.as_tensor(g.device_array("ep_return"), device="cuda")
     assert np.array_equal(ret.cpu().numpy(), o.fetch("ep_return"))
+
+
+@pytest.mark.gpu
+def test_fetch_outputs_equals_field_copies(make_env):
+    """trs_fetch_outputs: the whole GymInterface tuple in one synchronisation == the per-field copies, HIP == oracle."""
+    g = make_env("hip", n_envs=33, auto_reset=True)
+    o = make_env("oracle", n_envs=33, auto_reset=True)
+    for env in (g, o):
+        env.step_synthetic(9, 1)
+    got, want = g.fetch_outputs(), o.fetch_outputs()
+    names = ["img", "pos_x", "pos_y", "pos_z", "speed", "cte", "seg_idx", "done"]
+    for name, a, b in zip(names, got, want):
+        assert np.array_equal(a, g.fetch(name)), name
+        if a.dtype == np.float32:
+            assert np.max(np.abs(a - b)) <= 1e-5, name
+        else:
+            assert np.array_equal(a, b), name
+    assert g.fetch_outputs(image=False)[0] is None

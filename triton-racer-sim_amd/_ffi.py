@@ -70,7 +70,7 @@ FIELDS = {
 # every symbol include/trsim.h declares (suffix after the prefix)
 SYMBOLS = [
     "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic",
-    "get_state", "copy_to_host", "set_pose", "locate", "map_info_get", "sync", "event_record",
+    "get_state", "copy_to_host", "fetch_outputs", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
     "default_pre_config", "preprocess", "preprocess_host", "set_frame_filter", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
@@ -115,6 +115,7 @@ class Api:
             "step_synthetic": (i32, [vp, i32, i32]),
             "get_state": (i32, [vp, C.POINTER(TrsStateView)]),
             "copy_to_host": (i32, [vp, i32, vp, C.c_size_t]),
+            "fetch_outputs": (i32, [vp] + [vp] * 8),
             "set_pose": (i32, [vp, fp, fp, fp, fp, fp]),
             "locate": (i32, [vp, dp, i32, vp]),
             "map_info_get": (i32, [vp, C.POINTER(TrsMapInfo)]),

@@ -55,14 +55,12 @@ class HipGymInterface(Component):
         if steering is None or throttle is None:              # first tick: the mux has not produced anything yet
             steering, throttle = 0.0, 0.0
         self.env.step(float(steering), float(throttle), float(breaking), reset=bool(reset))
-        # a fresh ndarray per frame, never overwritten by later steps (ownership rule of gyminterface.py:99)
-        self.last_image = self.env.fetch("img")[0]
-        self.pos_x = float(self.env.fetch("pos_x")[0])        # Python floats: json.dump needs them (gyminterface.py:100-104)
-        self.pos_y = float(self.env.fetch("pos_y")[0])
-        self.pos_z = float(self.env.fetch("pos_z")[0])
-        self.speed = float(self.env.fetch("speed")[0])
-        self.cte = float(self.env.fetch("cte")[0])
-        self.seg_idx = int(self.env.fetch("seg_idx")[0])
+        # a fresh ndarray per frame, never overwritten by later steps (ownership rule of gyminterface.py:99); Python floats
+        # because json.dump needs them (gyminterface.py:100-104); one synchronisation for the whole tuple
+        img, x, y, z, speed, cte, seg, _ = self.env.fetch_outputs()
+        self.last_image = img[0]
+        self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte = float(x[0]), float(y[0]), float(z[0]), float(speed[0]), float(cte[0])
+        self.seg_idx = int(seg[0])
         return self.last_image, self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte
 
     def onStart(self):
@@ -95,7 +93,7 @@ class BatchedGymInterface(Component):
         self.env.step(steering, throttle, breaking, reset=None if reset is None else reset)
         names = ["img", "pos_x", "pos_y", "pos_z", "speed", "cte", "seg_idx", "done"]
         if self.to_host:
-            return tuple(self.env.fetch(n) for n in names)
+            return self.env.fetch_outputs()
         return tuple(self.env.device_array(n) for n in names)
 
     def onShutdown(self):

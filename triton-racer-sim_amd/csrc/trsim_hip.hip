@@ -1038,6 +1038,7 @@ struct trs_env {
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
     trs_pre_config frame_filter{}; bool has_frame_filter = false;   // trs_set_frame_filter
+    unsigned char* pinned = nullptr; size_t pinned_bytes = 0;   // trs_fetch_outputs staging (hipHostMalloc)
     int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
     int* hsv_tab = nullptr;
@@ -1236,6 +1237,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->mux_state);
+    if (e->pinned) (void)hipHostFree(e->pinned);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->sP) (void)hipStreamDestroy(e->sP);
@@ -1460,6 +1462,42 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
     if (which == TRS_F_STATS && static_cast<unsigned long long*>(dst)[2] != 0)
         return fail(TRS_ERR_DEVICE, "raster kernel found its dynamic LDS segment at a non-zero offset");
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_fetch_outputs(trs_env* e, uint8_t* h_img, float* h_x, float* h_y, float* h_z, float* h_speed, float* h_cte,
+                                 int32_t* h_seg, uint8_t* h_done)
+{
+    if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
+    if (h_img && !e->cfg.render) return fail(TRS_ERR_STATE, "the env has no camera (cfg.render == 0)");
+    HIPCHK(hipSetDevice(e->device));
+    const PParams& k = e->pp;
+    const size_t n = (size_t)e->n, img_b = h_img ? e->img_bytes : 0;
+    const size_t need = ((img_b + 15) & ~(size_t)15) + 7 * ((n * 4 + 15) & ~(size_t)15) + 16;   // every item starts 16-B aligned
+    if (e->pinned_bytes < need) {
+        if (e->pinned) { HIPCHK(hipStreamSynchronize(e->sP)); (void)hipHostFree(e->pinned); e->pinned = nullptr; e->pinned_bytes = 0; }
+        HIPCHK(hipHostMalloc((void**)&e->pinned, need, hipHostMallocDefault));
+        e->pinned_bytes = need;
+    }
+    struct Item { const void* src; void* dst; size_t bytes; };
+    const Item items[8] = {
+        {h_img ? e->img[(e->step_count + 1) & 1] : nullptr, h_img, img_b},
+        {k.x, h_x, n * 4}, {k.y, h_y, n * 4}, {k.z, h_z, n * 4}, {k.speed, h_speed, n * 4}, {k.cte, h_cte, n * 4},
+        {k.seg_idx, h_seg, n * 4}, {k.done, h_done, n},
+    };
+    size_t off = 0;
+    for (const Item& it : items) {
+        if (!it.dst || !it.bytes) continue;
+        HIPCHK(hipMemcpyAsync(e->pinned + off, it.src, it.bytes, hipMemcpyDeviceToHost, e->sP));
+        off += (it.bytes + 15) & ~(size_t)15;
+    }
+    HIPCHK(hipStreamSynchronize(e->sP));
+    off = 0;
+    for (const Item& it : items) {
+        if (!it.dst || !it.bytes) continue;
+        std::memcpy(it.dst, e->pinned + off, it.bytes);
+        off += (it.bytes + 15) & ~(size_t)15;
+    }
     return TRS_OK;
 }
 

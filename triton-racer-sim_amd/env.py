@@ -153,6 +153,17 @@ class BatchedEnv:
         self.api.check(self.api.copy_to_host(self._h, _ffi.FIELDS[name], out.ctypes.data, out.nbytes), f"copy_to_host({name})")
         return out
 
+    def fetch_outputs(self, image=True):
+        """``(img, x, y, z, speed, cte, seg_idx, done)`` of all envs as fresh numpy arrays in one synchronisation
+        (``trs_fetch_outputs``): what ``GymInterface.step`` returns plus the tracker index and the done flag."""
+        n = self.n
+        img = np.empty((n, self.H, self.W, 3), np.uint8) if image else None
+        f = [np.empty(n, np.float32) for _ in range(5)]
+        seg, done = np.empty(n, np.int32), np.empty(n, np.uint8)
+        self.api.check(self.api.fetch_outputs(self._h, img.ctypes.data if image else None, *[a.ctypes.data for a in f],
+                                              seg.ctypes.data, done.ctypes.data), "fetch_outputs")
+        return (img, *f, seg, done)
+
     def state_view(self):
         sv = _ffi.TrsStateView()
         self.api.check(self.api.get_state(self._h, C.byref(sv)), "get_state")
