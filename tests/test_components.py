@@ -99,3 +99,21 @@ def test_car_loop_on_gpu_equals_oracle(oracle_api, tmp_path):
     for a, b in zip(probe.rows, ref.rows):
         assert np.array_equal(a[0], b[0])                              # frame, byte for byte
         assert a[6] == b[6] and max(abs(p - q) for p, q in zip(a[1:6], b[1:6])) <= 1e-5
+
+
+def test_sim_latency_is_a_delay_line(oracle_api):
+    """sim_latency ms (gyminterface.py:96) -> ceil(ms * loop_hz / 1000) ticks of delay on the returned tuple."""
+    from triton_racer_sim_amd.components import HipGymInterface
+    now = HipGymInterface(gym_config={"sim_latency": 0}, _api=oracle_api)
+    late = HipGymInterface(gym_config={"sim_latency": 120, "loop_hz": 20}, _api=oracle_api)      # 2.4 -> 3 ticks
+    assert late.latency_ticks == 3
+    seen_now, seen_late = [], []
+    for k in range(8):
+        args = (0.1 * ((k % 3) - 1), 0.6, None, False)
+        seen_now.append(now.step(*args))
+        seen_late.append(late.step(*args))
+    for k in range(3):
+        assert seen_late[k][0] is None and seen_late[k][1:] == (0.0, 0.0, 0.0, 0.0, 0.0)
+    for k in range(3, 8):
+        assert np.array_equal(seen_late[k][0], seen_now[k - 3][0]) and seen_late[k][1:] == seen_now[k - 3][1:]
+    now.onShutdown(); late.onShutdown()

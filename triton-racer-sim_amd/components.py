@@ -41,7 +41,12 @@ class HipGymInterface(Component):
         self.gym_config = dict(DEFAULT_GYM_CONFIG)          # a private copy: the reference mutates its module-level
         self.gym_config.update(gym_config or {})            # default in place (gyminterface.py:50-51) — not kept
         Component.__init__(self, inputs=list(GYM_INPUTS), outputs=list(GYM_OUTPUTS), threaded=False)
+        # sim_latency (gyminterface.py:96 sleeps that many ms before a telemetry frame is accepted): with the env's fixed tick
+        # this is a delay line of ceil(latency_ms * loop_hz / 1000) ticks on the returned tuple (deterministic)
         self.latency = self.gym_config["sim_latency"]
+        import collections, math
+        self.latency_ticks = int(math.ceil(float(self.latency) * float(self.gym_config.get("loop_hz", 20)) / 1000.0)) if self.latency else 0
+        self._delay = collections.deque()
         self.env = BatchedEnv(n_envs=1, track=_track_for(self.gym_config), device=self.gym_config.get("hip_device", 0),
                               img_h=int(self.gym_config["img_h"]), img_w=int(self.gym_config["img_w"]), render=True, _api=_api)
         self.last_image = None
@@ -61,10 +66,16 @@ class HipGymInterface(Component):
         self.last_image = img[0]
         self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte = float(x[0]), float(y[0]), float(z[0]), float(speed[0]), float(cte[0])
         self.seg_idx = int(seg[0])
-        return self.last_image, self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte
+        out = (self.last_image, self.pos_x, self.pos_y, self.pos_z, self.speed, self.cte)
+        if self.latency_ticks:
+            self._delay.append(out)
+            if len(self._delay) <= self.latency_ticks:                # nothing has "arrived" yet: the constructor's state
+                return None, 0.0, 0.0, 0.0, 0.0, 0.0                  # (gyminterface.py:56,60-64)
+            out = self._delay.popleft()
+        return out
 
     def onStart(self):
-        print(f"HipGymInterface: in-process env on GPU {self.env.device}; artificial latency setting ignored ({self.latency}ms).")
+        print(f"HipGymInterface: in-process env on GPU {self.env.device}; artificial latency {self.latency} ms = {self.latency_ticks} tick(s).")
 
     def onShutdown(self):
         self.env.close()
