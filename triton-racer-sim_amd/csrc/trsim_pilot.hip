@@ -62,6 +62,7 @@ struct ConvParams {
     int gchunk;                // granules per LDS stage (even)
     int relu, out_f32, in_px_bytes;   // in_px_bytes: bytes per input pixel (CIN*2, conv1: 3)
     int ksplit;                // > 1: blockIdx.y owns a slice of the granules and adds its partial sums atomically (fp32 out, no ReLU)
+    int nt_out;                // non-temporal activation stores (outputs far larger than L2; measured: conv1 86 -> 80 us, small layers lose)
     int KH, KW, run_pad, cg, span_nl;   // span kernel: kernel rows, granules per kernel row (padded), granules per pixel, load instructions per kernel row
 };
 
@@ -248,6 +249,8 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
             }
         }
         const int total = PP * crv;                                         // 16-B chunks to write out in this pass
+        const size_t pass_byte0 = (size_t)(tile * 32 + pass * PP) * p.COUT * 2;
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out) + pass_byte0, 0, PP * p.COUT * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int g = i * 64 + lane;
@@ -257,7 +260,12 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
                 const int f = NB == 1 ? (pix >> 1) & 3 : pix & 7;
                 if (m < p.M) {
                     const u4v v = stage[pix * CR + (c ^ f)];
-                    *reinterpret_cast<u4v*>(static_cast<unsigned short*>(p.out) + (size_t)m * p.COUT + cbase + 8 * c) = v;
+                    // a buffer store so that the cache policy can be chosen per layer (immediate aux bits): activations far
+                    // larger than L2 leave non-temporally and do not displace what the next layer is about to read
+                    const int off = (pix * p.COUT + cbase + 8 * c) * 2;
+                    if (p.nt_out == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 2);         // nt
+                    else if (p.nt_out == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 17);   // sc0 sc1 (write-through)
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 0);
                 }
             }
         }
@@ -699,6 +707,13 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
     p.ksplit = l.ksplit;
+    {
+        size_t nt_mb = 128;                                                // outputs above this many MB leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
+        if (const char* e = std::getenv("TRS_PILOT_NT_MB")) nt_mb = (size_t)std::atoi(e);
+        int nt_kind = 1;
+        if (const char* e = std::getenv("TRS_PILOT_NT_KIND")) nt_kind = std::atoi(e);
+        p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > (nt_mb << 20)) ? nt_kind : 0;
+    }
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
     if (l.resident) {
         const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
