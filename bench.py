@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--pilot", action="store_true", help="closed loop with cnn_2d_speed_control inference on the device frame each step (BASELINE configs[4] shape)")
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the informational 8-steps-per-launch leg (profiling runs: only the timed kernel in the trace)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
     args = ap.parse_args()
 
@@ -191,7 +192,7 @@ def main():
 
     # informational only (never part of `value`): the same workload with 8 steps per launch, timed separately
     also = None
-    if render and not args.pilot and spl == 1 and world == 1:
+    if render and not args.pilot and spl == 1 and world == 1 and not args.no_also:
         env.sync()
         env.event_record(2)
         env.step_synthetic(args.steps, 8)

@@ -3,7 +3,7 @@
 # usage: bash scripts/profile.sh <tag> [bench args...]
 set -e
 TAG=${1:-r01}; shift || true
-ARGS="--steps 300 --warmup 30 --no-cpu-baseline $@"
+ARGS="--steps 300 --warmup 30 --no-cpu-baseline --no-also $@"
 cd "$(dirname "$0")/.."
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
