@@ -190,10 +190,12 @@ int trs_preprocess_host(trs_env* env, const trs_pre_config* cfg, const uint8_t* 
 /* ImgPreprocessing fused behind the rasteriser: with a filter set, every frame the env renders IS
  * 'cam/processed_img' — no extra pass over HBM and no extra kernel.  Possible because the trim (:92-99) and the HSV
  * in-range masks (:65-74) are functions of a pixel's colour alone and a rendered pixel's colour comes from the
- * per-row palette: the library filters the palette (4 classes x img_h rows) on the host with the same binary32 /
- * fixed-point arithmetic and the kernel is unchanged.  Not expressible this way, hence refused (use trs_preprocess):
- * dynamic brightness (needs the frame's own mean first, :88-91) and the Canny layer (a neighbourhood operator).
- * cfg NULL = back to raw frames.  Takes effect from the next rendered frame; survives trs_load_track. */
+ * per-row palette.  Without dynamic brightness the library filters the palette (4 classes x img_h rows) once on the
+ * host and the kernel is unchanged.  With dynamic brightness (:88-91: the frame's own mean over rows 40..118) the step
+ * kernel classifies those rows first, reduces the three channel sums per env, filters a per-env palette in LDS with
+ * that frame's delta and shades from it; every pixel is still classified once.  Refused: the Canny layer, a
+ * neighbourhood operator (use trs_preprocess).  cfg NULL = back to raw frames.  Takes effect from the next rendered
+ * frame; survives trs_load_track. */
 int trs_set_frame_filter(trs_env* env, const trs_pre_config* cfg_or_null);
 
 /* Pilot-side normalisation (components/keras_pilot.py:49-55, keras_train.py:41-42): float32(img) / 255.

@@ -745,7 +745,6 @@ EXPORT int trso_set_frame_filter(trs_env* e, const trs_pre_config* c)
     if (!c) { e->has_frame_filter = 0; return TRS_OK; }
     int rc = check_pre(c);
     if (rc) return rc;
-    if (c->dynamic_brightness) return fail(TRS_ERR_ARG, "dynamic brightness needs the frame's own mean: not a palette filter, use trs_preprocess");
     if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
     hsv_tables();
     e->frame_filter = *c; e->has_frame_filter = 1;

@@ -190,6 +190,12 @@ def test_gpu_preprocess_latest_frames_on_device(make_env):
     assert np.array_equal(dev, want)
 
 
+DYNAMIC = [
+    {"preprocessing_dynamic_brightness_enabled": True},
+    {"preprocessing_dynamic_brightness_enabled": True, "preprocessing_brightness_baseline": 420, "preprocessing_contrast_enhancement_ratio": 1.25,
+     "preprocessing_color_filter_enabled": True},
+]
+
 FUSED = [
     {"preprocessing_contrast_enhancement_ratio": 1.37, "preprocessing_contrast_enhancement_offset": 110},
     {"preprocessing_color_filter_enabled": True},
@@ -199,7 +205,7 @@ FUSED = [
 ]
 
 
-@pytest.mark.parametrize("cfg", FUSED)
+@pytest.mark.parametrize("cfg", FUSED + DYNAMIC)
 def test_oracle_frame_filter_is_render_then_filter(make_env, cfg):
     """Definition of the fused mode: frames equal the raw frames pushed through ImgPreprocessing.__process."""
     raw = make_env("oracle", n_envs=24, auto_reset=True)
@@ -214,9 +220,8 @@ def test_oracle_frame_filter_is_render_then_filter(make_env, cfg):
     for env in (raw, fil):
         env.step_synthetic(1, 1)
     assert np.array_equal(fil.fetch("img"), raw.fetch("img"))
-    for bad in ({"preprocessing_dynamic_brightness_enabled": True}, {"preprocessing_edge_detection_enabled": True}):
-        with pytest.raises(RuntimeError, match="not a palette filter"):
-            fil.set_frame_filter(bad)
+    with pytest.raises(RuntimeError, match="not a palette filter"):
+        fil.set_frame_filter({"preprocessing_edge_detection_enabled": True})
 
 
 @pytest.mark.gpu
@@ -237,4 +242,35 @@ def test_gpu_fused_frame_filter_equals_oracle(make_env, cfg):
         env.step_synthetic(2, 1)
     assert np.array_equal(g.fetch("img"), o.fetch("img"))
     with pytest.raises(RuntimeError, match="not a palette filter"):
-        g.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True})
+        g.set_frame_filter({"preprocessing_edge_detection_enabled": True})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", DYNAMIC)
+@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (64, 64, 300, False)])
+def test_gpu_fused_dynamic_brightness_equals_oracle(make_env, cfg, shape):
+    """Dynamic brightness inside the step kernel (class histogram of rows 40..118 -> per-env palette) against the
+    oracle's render-then-filter, bit for bit; env counts that leave the last workgroup partly filled; single-step calls,
+    pipelined calls and multi-step launches."""
+    h, w, n, depth = shape
+    g = make_env("hip", n_envs=n, auto_reset=True, img_h=h, img_w=w, depth=depth)
+    o = make_env("oracle", n_envs=n, auto_reset=True, img_h=h, img_w=w, depth=depth)
+    for env in (g, o):
+        env.set_frame_filter(cfg)
+        env.step_synthetic(1, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.step_synthetic(5, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.step_synthetic(6, 3)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    if depth:
+        assert np.array_equal(g.fetch("depth"), o.fetch("depth"))
+    assert np.array_equal(g.fetch("seg_idx"), o.fetch("seg_idx"))
+    for env in (g, o):                                                     # and back to a static palette filter, then raw
+        env.set_frame_filter(FUSED[1]); env.step_synthetic(2, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.set_frame_filter(enabled=False); env.step_synthetic(2, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))

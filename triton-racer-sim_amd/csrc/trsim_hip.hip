@@ -194,6 +194,15 @@ constexpr int kRasterThreads = 640;
 constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;   // 5
 constexpr int kStageRegs = 10;                               // 10 x 640 x 16 B = 100 KB per pass of the raster team
 
+struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernel (DYN instantiation)
+    double baseline;
+    float contrast, offset;
+    int color, n_filters;
+    int lo[4], hi[4], dst_ch[4];
+    int w0, w1;                         // brightness window: image rows [w0, w1) = img[40:119] (img_preprocessing.py:88)
+    int lds_off;                        // LDS: uint32 penv[H][4] | int esum[2][3] | int dbar
+};
+
 struct SParams {
     PParams ph;                         // physics side (blob = px|py|pz|tan image; cam = ring base)
     RParams ra;                         // raster side
@@ -204,7 +213,45 @@ struct SParams {
                                         // launch (camera parameters from the global ring, written by the previous launch)
     unsigned step_base;                 // absolute index of this launch's physics step 0
     int lds_off_phys, lds_off_cam, lds_off_prog, cam_stride;   // LDS: physics image, float4 lcam[n_phys][cam_stride], int pprog[cam_stride]
+    FParams fp;
 };
+
+// ImgPreprocessing.__process of ONE colour with this frame's brightness delta (img_preprocessing.py:37-74,92-99): the
+// per-pixel arithmetic of trs_preprocess_kernel, with OpenCV's fixed-point reciprocals computed instead of tabulated
+__device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t bgr, float deltaf)
+{
+    int t[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float x = (float)((bgr >> (8 * ch)) & 255u);
+        x = x + deltaf;
+        x = x - f.offset;
+        x = x * f.contrast;
+        x = x + f.offset;
+        x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+        t[ch] = (int)x;
+    }
+    int o0 = t[0], o1 = t[1], o2 = t[2];
+    if (f.color) {
+        const int r = t[0], g = t[1], b = t[2];
+        const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+        const int sdiv = v ? __double2int_rn((double)(255 << 12) / (1.0 * (double)v)) : 0;
+        const int hdiv = diff ? __double2int_rn((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+        const int sat = (diff * sdiv + (1 << 11)) >> 12;
+        int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+        h = (h * hdiv + (1 << 11)) >> 12;
+        if (h < 0) h += 180;
+        const int hh = min(h, 255), ss = min(sat, 255);
+        for (int k = 0; k < f.n_filters; ++k) {
+            const int lh = f.lo[k] & 255, ls = (f.lo[k] >> 8) & 255, lv = (f.lo[k] >> 16) & 255;
+            const int uh = f.hi[k] & 255, us = (f.hi[k] >> 8) & 255, uv = (f.hi[k] >> 16) & 255;
+            const int m = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
+            const int dc = f.dst_ch[k];
+            o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
+        }
+    }
+    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+}
 
 // one wave advances one env (all lanes compute the same scalars; the track scan is lane-parallel)
 template <typename T>
@@ -415,7 +462,7 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
-template <bool DEPTH>
+template <bool DEPTH, bool DYN>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
     const int tid = threadIdx.x;
@@ -435,6 +482,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
+    if constexpr (DYN) { if (tid < 8) reinterpret_cast<int*>(smem + sp.fp.lds_off + p.H * 16)[tid] = 0; }   // esum[2][3], dbar
     // ---- prologue: everything is staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves
     // 64 lanes x 16 B = 1 KB, lane-linear, no registers and no ds_write pass), all requests are in flight together and
     // one workgroup barrier closes the stage.  Raster waves: the class map + row tables (one linear image at LDS offset
@@ -557,6 +605,112 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         }
     };
     for (int e = e_begin; e < e_end; ++e) {
+        if constexpr (DYN) {
+            // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
+            // every pixel there, so: (A) classify those rows once (classes kept in registers), sum the RAW colours per
+            // channel, reduce over the team; (B) every thread filters one entry of a per-env palette with this frame's
+            // delta; (C) shade all rows from that palette.  No extra pass over HBM, each pixel classified once.
+            const FParams& f = sp.fp;
+            uint32_t* const penv = reinterpret_cast<uint32_t*>(smem + f.lds_off);
+            int* const esum = reinterpret_cast<int*>(smem + f.lds_off + p.H * 16);     // [2][3]
+            int* const dbar = esum + 6;
+            const int it = (sidx - sp.r_first) * (e_end - e_begin) + (e - e_begin);    // env iterations so far (same in every wave)
+            const int par = it & 1;
+            const int j = e - e_begin;
+            float4 cam;
+            if (sidx < 0) cam = lcam_prev[j];
+            else {
+                while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
+                cam = lcam[sidx * sp.cam_stride + j];
+            }
+            const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
+            auto classify4 = [&](int v) -> unsigned {                         // classes of this thread's 4 pixels of row v, 2 bits each
+                const f2v rt = lrow[v];
+                const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+                const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
+                const f2v d = kk2 * cns;
+                auto cls_of = [&](f2v uf) -> unsigned {
+                    const f2v g = __builtin_elementwise_fma(uf, d, a);
+                    const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
+                    const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
+                    const uint32_t w = *(lds_u32p)(uintptr_t)(iz * pitch + ((ix >> 2) & ~3u));
+                    return __builtin_amdgcn_ubfe(w, ix << 1, 2);
+                };
+                return cls_of(ufa) | (cls_of(ufb) << 2) | (cls_of(ufc) << 4) | (cls_of(ufd) << 6);
+            };
+            // (A)
+            unsigned sr = 0, sg = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0;
+            int slot = 0;
+            for (int v = vstart; v < f.w1; v += p.rows_per_pass) {
+                if (v < f.w0) continue;
+                const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+                unsigned pack = 0;
+                if (v >= p.uni_rows) {
+                    pack = classify4(v);
+                    const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
+                    cb0 |= word == 0 ? pack << sh : 0u; cb1 |= word == 1 ? pack << sh : 0u; cb2 |= word == 2 ? pack << sh : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = *(lds_u32p)(uintptr_t)(pal_a + (((pack >> (2 * k)) & 3u) << 2));
+                    sr += c & 255u; sg += (c >> 8) & 255u; sb += (c >> 16) & 255u;
+                }
+                ++slot;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+            if (lane == 0) { atomicAdd(&esum[par * 3], (int)sr); atomicAdd(&esum[par * 3 + 1], (int)sg); atomicAdd(&esum[par * 3 + 2], (int)sb); }
+            const int nrw = kRasterThreads / 64;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 1)) __builtin_amdgcn_s_sleep(1);
+            // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then one palette entry per thread
+            {
+                const double cnt = (double)(f.w1 - f.w0) * (double)p.W;
+                double cur = 0.0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) cur = cur + (cnt > 0 ? (double)esum[par * 3 + ch] / cnt : 0.0);
+                cur = cur + 0.0;
+                const float deltaf = (float)((f.baseline - cur) / 3);
+                for (int t = tid; t < p.H * 4; t += kRasterThreads)
+                    penv[t] = filter_colour_dev(f, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)t << 2)), deltaf);
+                if (tid < 3) esum[(par ^ 1) * 3 + tid] = 0;                     // the next env's sums start from zero (nobody reads that half now)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 2)) __builtin_amdgcn_s_sleep(1);
+            // (C)
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+            __amdgpu_buffer_rsrc_t drs = rsrc;
+            if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+            slot = 0;
+            const unsigned penv_a = (unsigned)f.lds_off;
+            for (int v = vstart; v < p.H; v += p.rows_per_pass) {
+                const bool in_win = v >= f.w0 && v < f.w1;
+                unsigned pack = 0;
+                if (v >= p.uni_rows) {
+                    if (in_win) {
+                        const unsigned word = (unsigned)slot >> 2, wv = word == 0 ? cb0 : (word == 1 ? cb1 : cb2);
+                        pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
+                    } else {
+                        pack = classify4(v);
+                    }
+                }
+                if (in_win) ++slot;
+                const unsigned row_a = penv_a + ((unsigned)v << 4);
+                const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
+                const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
+                const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
+                __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
+                if constexpr (DEPTH) {
+                    const unsigned dz = __float_as_uint(lrowdepth[v]);
+                    const u4v d4 = {dz, dz, dz, dz};
+                    __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+                }
+            }
+            continue;
+        }
         uniform_rows(e);
         // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -1037,7 +1191,7 @@ struct trs_env {
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
-    trs_pre_config frame_filter{}; bool has_frame_filter = false;   // trs_set_frame_filter
+    trs_pre_config frame_filter{}; bool has_frame_filter = false, filter_dynamic = false;   // trs_set_frame_filter
     unsigned char* pinned = nullptr; size_t pinned_bytes = 0;   // trs_fetch_outputs staging (hipHostMalloc)
     int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
@@ -1083,12 +1237,33 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.cam_stride = e->pp.envs_per_wg;
     sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
     sp.lds_off_prog = sp.lds_off_cam + (std::max(n_phys, 1) + 1) * sp.cam_stride * 16;   // + one row: poses of the step before the launch
-    const int lds = sp.lds_off_prog + sp.cam_stride * 4 + 16;                      // + the two team-barrier counters
+    int lds = sp.lds_off_prog + sp.cam_stride * 4 + 16;                            // + spare counters
+    const bool dyn = e->has_frame_filter && e->filter_dynamic;
+    std::memset(&sp.fp, 0, sizeof sp.fp);
+    if (dyn) {
+        const trs_pre_config& c = e->frame_filter;
+        sp.fp.baseline = c.brightness_baseline; sp.fp.contrast = c.contrast_ratio; sp.fp.offset = c.contrast_offset;
+        sp.fp.color = c.color_filter_enabled; sp.fp.n_filters = c.n_filters;
+        for (int k = 0; k < 4; ++k) {
+            sp.fp.lo[k] = c.hsv_lo[k][0] | (c.hsv_lo[k][1] << 8) | (c.hsv_lo[k][2] << 16);
+            sp.fp.hi[k] = c.hsv_hi[k][0] | (c.hsv_hi[k][1] << 8) | (c.hsv_hi[k][2] << 16);
+            sp.fp.dst_ch[k] = c.dst_channel[k];
+        }
+        sp.fp.w0 = std::min(40, e->H); sp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
+        sp.fp.lds_off = (lds + 15) & ~15;
+        lds = sp.fp.lds_off + e->H * 16 + 64;                              // per-env palette + channel sums + barrier counter
+    }
+    const dim3 grid(grid_of(e)), block(kBlock);
+    if (dyn) {
+        if (e->rp.depth) hipLaunchKernelGGL((trs_step_kernel<true, true>), grid, block, lds, e->sP, sp);
+        else hipLaunchKernelGGL((trs_step_kernel<false, true>), grid, block, lds, e->sP, sp);
+    } else {
 #ifndef TRS_SINGLE_VARIANT   /* A/B switch: build without the depth instantiation (HIP guide rule 19: co-compiled variants perturb each other) */
-    if (e->rp.depth) hipLaunchKernelGGL(trs_step_kernel<true>, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
-    else
+        if (e->rp.depth) hipLaunchKernelGGL((trs_step_kernel<true, false>), grid, block, lds, e->sP, sp);
+        else
 #endif
-    hipLaunchKernelGGL(trs_step_kernel<false>, dim3(grid_of(e)), dim3(kBlock), lds, e->sP, sp);
+        hipLaunchKernelGGL((trs_step_kernel<false, false>), grid, block, lds, e->sP, sp);
+    }
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
@@ -1328,13 +1503,15 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
-        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16;
+        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16 - (e->H * 16 + 96);   // ... and the per-env palette of the dynamic-brightness filter
         e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifndef TRS_SINGLE_VARIANT
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, k.blob_bytes));
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
@@ -1620,7 +1797,7 @@ int upload_palette(trs_env* e)
 {
     if (!e->track_loaded || !e->cfg.render) return TRS_OK;
     std::vector<uint32_t> pal(e->tab.palette);
-    if (e->has_frame_filter)
+    if (e->has_frame_filter && !e->filter_dynamic)             // dynamic brightness: the kernel filters a per-env palette itself
         for (auto& c : pal) c = filter_colour(e->frame_filter, c);
     e->rp.uni_rows = leading_uniform_rows(pal, e->H);
     HIPCHK(hipStreamSynchronize(e->sP));                       // frames in flight keep the palette they were launched with
@@ -1666,9 +1843,12 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
     if (c) {
         int rc = check_pre(c);
         if (rc) return rc;
-        if (c->dynamic_brightness) return fail(TRS_ERR_ARG, "dynamic brightness needs the frame's own mean: not a palette filter, use trs_preprocess");
         if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
-        e->frame_filter = *c; e->has_frame_filter = true;
+        if (c->dynamic_brightness) {
+            const int rpp = kRasterThreads / (e->W / 4);
+            if (rpp < 1 || (79 + rpp - 1) / rpp > 12) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 3 registers), use trs_preprocess");
+        }
+        e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
     } else {
         e->has_frame_filter = false;
     }
