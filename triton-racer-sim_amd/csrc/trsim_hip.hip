@@ -1206,6 +1206,7 @@ struct trs_env {
     uint8_t* ctl_reset = nullptr;
     size_t img_bytes = 0;
     int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
+    int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
 };
 
@@ -1275,7 +1276,8 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
 int run_camera_steps(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, int per_launch)
 {
     const uint64_t s0 = e->step_count;
-    const int kmax = std::max(1, std::min(per_launch, e->max_steps_per_launch));
+    const bool dyn_filter = e->has_frame_filter && e->filter_dynamic;
+    const int kmax = std::max(1, std::min(per_launch, dyn_filter ? e->max_steps_dyn : e->max_steps_per_launch));
     int rc = TRS_OK;
     if (n == 1) {
         rc = launch_step(e, st, th, br, rs, synth, 1, 0, 0, s0);
@@ -1503,8 +1505,10 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
-        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16 - (e->H * 16 + 96);   // ... and the per-env palette of the dynamic-brightness filter
+        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16;
         e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
+        const int free_dyn = free_b - (e->H * 16 + 96);
+        e->max_steps_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1535,6 +1539,11 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(e->stats, 0, 64 * sizeof(unsigned long long)));
     e->step_count = 0;
     e->track_loaded = true;
+    if (e->has_frame_filter && e->filter_dynamic && e->max_steps_dyn < 1) {
+        e->has_frame_filter = false; e->filter_dynamic = false;
+        (void)upload_palette(e);
+        return fail(TRS_ERR_LIMIT, "this track leaves no LDS for the dynamic-brightness frame filter that was set: the filter has been removed");
+    }
     return upload_palette(e);                 // also sets rp.uni_rows (and applies a frame filter that was set earlier)
 }
 
@@ -1847,6 +1856,7 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
         if (c->dynamic_brightness) {
             const int rpp = kRasterThreads / (e->W / 4);
             if (rpp < 1 || (79 + rpp - 1) / rpp > 12) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 3 registers), use trs_preprocess");
+            if (e->track_loaded && e->max_steps_dyn < 1) return fail(TRS_ERR_LIMIT, "no LDS left beside this track's tables for the in-kernel dynamic-brightness palette, use trs_preprocess");
         }
         e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
     } else {
