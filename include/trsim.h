@@ -178,7 +178,8 @@ void trs_default_pre_config(trs_pre_config* cfg);
 
 /* ImgPreprocessing.__process (img_preprocessing.py:37-102) for n_images frames of the env's image size: brightness /
  * contrast trim in binary32 exactly as numpy evaluates it (mean over rows 40..118, :88-99), the HSV in-range masks
- * (:65-74) and the Canny edge layer (:76-79; frames up to 26,000 pixels) written over their destination channels (:57-63).
+ * (:65-74) and the Canny edge layer (:76-79; work arrays in LDS up to ~26,000 pixels, in an L2-resident scratch beyond)
+ * written over their destination channels (:57-63).
  * d_src NULL = the env's latest frame (n_images must then be n_envs); d_dst NULL = the env's own processed-image
  * buffer (returned through *d_out).  Device pointers; asynchronous on the handle's stream. */
 int trs_preprocess(trs_env* env, const trs_pre_config* cfg, const uint8_t* d_src, uint8_t* d_dst, int n_images,

@@ -6,12 +6,16 @@ import ctypes as C
 from triton_racer_sim_amd.env import BatchedEnv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-env = BatchedEnv(n_envs=N, auto_reset=True)
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 160
+env = BatchedEnv(n_envs=N, auto_reset=True, img_h=H, img_w=W)
 env.step_synthetic(20, 1)
 CFGS = {
     "identity trim": {},
     "trim (contrast 1.2)": {"preprocessing_contrast_enhancement_ratio": 1.2},
     "trim + dynamic brightness": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True},
+    "trim + dynamic + masks + Canny": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True, "preprocessing_color_filter_enabled": True,
+                                       "preprocessing_edge_detection_enabled": True},
     "trim + dynamic + HSV masks": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True, "preprocessing_color_filter_enabled": True},
 }
 frame = env.H * env.W * 3

@@ -793,7 +793,9 @@ struct PreParams {
     unsigned lo[4], hi[4];              // packed h | s<<8 | v<<16
     int dst_ch[4];
     int edge, edge_low, edge_high, edge_ch;   // Canny layer (edge kernel only)
-    int off_mag, off_map, off_tab;      // edge kernel: LDS offsets behind the trimmed frame
+    int off_mag, off_map, off_tab;      // edge kernel: offsets of the gradient magnitudes / edge map behind the trimmed frame; LDS offset of the tables
+    unsigned char* scratch;             // edge kernel, frames too large for LDS: per-workgroup work arrays in global memory (L2 resident)
+    size_t scratch_stride;
 };
 
 __device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
@@ -905,11 +907,16 @@ __device__ __forceinline__ void edge_sobel(const unsigned char* simg, int H, int
     dy = (g + 2 * h + i) - (a + 2 * b + d);
 }
 
+// SCRATCH = false: the three whole-frame work arrays live in LDS (frames up to ~26,000 pixels).  SCRATCH = true: they live in
+// a per-workgroup global scratch that stays in L2 (any frame size, e.g. config 5's 240x320); only the tables are in
+// LDS.  Same code, same results; __syncthreads() orders the workgroup's global accesses between the phases.
+template <bool SCRATCH>
 __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const PreParams p)
 {
-    unsigned char* const simg = smem;
-    short* const mag = reinterpret_cast<short*>(smem + p.off_mag);
-    unsigned char* const map = smem + p.off_map;
+    unsigned char* const work = SCRATCH ? p.scratch + (size_t)blockIdx.x * p.scratch_stride : smem;
+    unsigned char* const simg = work;
+    short* const mag = reinterpret_cast<short*>(work + p.off_mag);
+    unsigned char* const map = work + p.off_map;
     int* const s_tab = reinterpret_cast<int*>(smem + p.off_tab);
     unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [8][3]
     float* const s_delta = reinterpret_cast<float*>(s_part + 24);
@@ -1196,6 +1203,7 @@ struct trs_env {
     int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
     int* hsv_tab = nullptr;
+    unsigned char* edge_scratch = nullptr; size_t edge_scratch_bytes = 0;   // work arrays of the Canny layer for frames beyond LDS
     PParams pp{};
     RParams rp{};
     trsim::TrackTables tab;
@@ -1413,7 +1421,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
-    (void)hipFree(e->mux_state);
+    (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch);
     if (e->pinned) (void)hipHostFree(e->pinned);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1904,11 +1912,27 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
         const size_t npx = (size_t)e->H * e->W;
         p.off_mag = (int)align_up(npx * 3, 16);
         p.off_map = p.off_mag + (int)align_up((size_t)(e->H + 2) * (e->W + 2) * 2, 16);
-        p.off_tab = p.off_map + (int)align_up(npx, 16);
-        const int lds = p.off_tab + 512 * 4 + 24 * 4 + 16;
-        if (lds > 160 * 1024) return fail(TRS_ERR_LIMIT, "frame too large for the LDS-resident Canny layer (about 26,000 pixels)");
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_preprocess_edge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(trs_preprocess_edge_kernel, dim3(std::min(n_images, e->cu_count)), dim3(kEdgeBlock), lds, e->sP, p);
+        const size_t work = (size_t)p.off_map + align_up(npx, 16);
+        const int tables = 512 * 4 + 24 * 4 + 16;
+        const int grid = std::min(n_images, e->cu_count);
+        if (work + tables <= 160 * 1024) {                                    // whole frame in LDS
+            p.off_tab = (int)work;
+            const int lds = p.off_tab + tables;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_preprocess_edge_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(trs_preprocess_edge_kernel<false>, dim3(grid), dim3(kEdgeBlock), lds, e->sP, p);
+        } else {                                                              // work arrays in a global scratch (stays in L2), tables in LDS
+            p.off_tab = 0;
+            p.scratch_stride = align_up(work, 256);
+            const size_t need = p.scratch_stride * (size_t)grid;
+            if (e->edge_scratch_bytes < need) {
+                HIPCHK(hipStreamSynchronize(e->sP));
+                (void)hipFree(e->edge_scratch); e->edge_scratch = nullptr; e->edge_scratch_bytes = 0;
+                HIPCHK(hipMalloc((void**)&e->edge_scratch, need));
+                e->edge_scratch_bytes = need;
+            }
+            p.scratch = e->edge_scratch;
+            hipLaunchKernelGGL(trs_preprocess_edge_kernel<true>, dim3(grid), dim3(kEdgeBlock), tables, e->sP, p);
+        }
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
