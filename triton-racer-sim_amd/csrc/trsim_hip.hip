@@ -800,20 +800,20 @@ struct PreParams {
 
 __device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
 
-__global__ __launch_bounds__(256) void trs_preprocess_kernel(const PreParams p)
+__global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)   // 256 threads per frame at 120x160, 1024 for frames of 8,192+ pixel groups
 {
     __shared__ int s_tab[512];
-    __shared__ unsigned s_part[4][3];
+    __shared__ unsigned s_part[16][3];
     __shared__ float s_delta;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const size_t frame_bytes = (size_t)p.gpe * 12;
-    for (int i = tid; i < 512; i += 256) s_tab[i] = p.hsv_tab[i];
+    for (int i = tid; i < 512; i += nthreads) s_tab[i] = p.hsv_tab[i];
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         // ---- pass 1: channel sums over the brightness rows ----
         unsigned sr = 0, sg = 0, sb = 0;
-        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += 256) {
+        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += nthreads) {
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
             // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3
             sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
@@ -828,7 +828,8 @@ __global__ __launch_bounds__(256) void trs_preprocess_kernel(const PreParams p)
             const double cnt = (double)(p.r1 - p.r0) * (double)p.W;
             double cur = 0.0;
             for (int ch = 0; ch < 3; ++ch) {
-                const unsigned long long tot = (unsigned long long)s_part[0][ch] + s_part[1][ch] + s_part[2][ch] + s_part[3][ch];
+                unsigned long long tot = 0;
+                for (int w = 0; w < nwaves; ++w) tot += s_part[w][ch];
                 cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
             }
             cur = cur + 0.0;
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(256) void trs_preprocess_kernel(const PreParams p)
         __syncthreads();
         const float deltaf = s_delta, off = p.offset, con = p.contrast;
         // ---- pass 2: trim, masks, merge ----
-        for (int g = tid; g < p.gpe; g += 256) {
+        for (int g = tid; g < p.gpe; g += nthreads) {
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
             unsigned by[12];
 #pragma unroll
@@ -1936,8 +1937,9 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
-    const int grid = std::min(n_images, e->cu_count * 8);
-    hipLaunchKernelGGL(trs_preprocess_kernel, dim3(grid), dim3(256), 0, e->sP, p);
+    const int block = p.gpe >= 8192 ? 1024 : 256;                          // large frames: more waves per frame (one workgroup per frame cannot fill the chip otherwise)
+    const int grid = std::min(n_images, e->cu_count * (block == 256 ? 8 : 2));
+    hipLaunchKernelGGL(trs_preprocess_kernel, dim3(grid), dim3(block), 0, e->sP, p);
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
