@@ -29,3 +29,17 @@ for name, cfg in CFGS.items():
     env.event_record(1); env.sync()
     us = env.event_elapsed_ms(0, 1) * 1e3 / 50
     print(f"{name:32s} {us:8.2f} us per {N} frames   {2 * frame * N / us / 1e3:7.1f} GB/s (read + write once)")
+
+# pilot-side normalisation float32(img) / 255 (keras_pilot.py:49-55): 1 byte in, 4 bytes out per channel value
+hip = C.CDLL(None)                                      # hipMalloc of the runtime libtrsim.so already uses (global symbols; no torch import: slow on a fresh box)
+dst = C.c_void_p()
+assert hip.hipMalloc(C.byref(dst), C.c_size_t(4 * frame * N)) == 0
+for _ in range(5):
+    env.api.check(env.api.normalize(env._h, None, dst, N), "normalize")
+env.sync(); env.event_record(0)
+for _ in range(50):
+    env.api.check(env.api.normalize(env._h, None, dst, N), "normalize")
+env.event_record(1); env.sync()
+us = env.event_elapsed_ms(0, 1) * 1e3 / 50
+print(f"{'normalize (u8 -> f32 / 255)':32s} {us:8.2f} us per {N} frames   {5 * frame * N / us / 1e3:7.1f} GB/s (1 B read + 4 B written per value)")
+hip.hipFree(dst)
