@@ -747,10 +747,19 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
-    if (l.ksplit > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)p.M * l.COUT * sizeof(float), s));   // partial sums are added atomically
     const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
+    // split-K only as far as it takes to fill the chip about twice: every extra slice adds a full tile of fp32 atomics
+    // (dense1 at 240x320: 551 one-chunk slices x 4 row tiles spent 166 us mostly in atomics)
+    int ks = l.ksplit;
+    if (ks > 1) {
+        int want = std::max(1, (2 * cu_count + grid - 1) / grid);
+        if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
+        ks = std::min(ks, want);
+    }
+    p.ksplit = ks;
+    if (ks > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)p.M * l.COUT * sizeof(float), s));   // partial sums are added atomically
     const int nb = l.COUT_PAD / 32;
-#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, l.ksplit), dim3(kConvBlock), l.lds, s, p)
+#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, ks), dim3(kConvBlock), l.lds, s, p)
     if (l.u8in) LAUNCH(1, true);
     else if (nb == 1) LAUNCH(1, false);
     else if (nb == 2) LAUNCH(2, false);
