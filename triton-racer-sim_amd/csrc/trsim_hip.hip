@@ -1,19 +1,20 @@
 // trsim_hip.hip — libtrsim.so: the gfx950 (MI355X, CDNA4) kernels and the C ABI of include/trsim.h.
 //
-//   trs_step_kernel     camera on: ONE launch per env step on ONE stream.  960-thread workgroups (15 wave64) own a
+//   trs_step_kernel     camera on: ONE launch per env step on ONE stream.  768-thread workgroups (12 wave64) own a
 //     contiguous range of envs and are wave-specialised:
-//       physics team (waves 10..14, one wave per env, no workgroup barrier): SoA state load, bicycle-model step
+//       physics team (waves 8..11, one wave per env, no workgroup barrier): SoA state load, bicycle-model step
 //         (include/trsim_spec.h), binary64 L1 scan of the LDS-resident track with a wave64 DPP argmin
 //         (= reference LocationTracker.__find_closest, components/track_data_process.py:89-101), y / cte / done /
 //         reward, state store, one float4 of camera parameters per env into a small ring;
-//       raster team (waves 0..9): LDS holds the packed 2-bit surface-class map (LDS offset 0, odd row pitch), the
+//       raster team (waves 0..7): LDS holds the packed 2-bit surface-class map (LDS offset 0, odd row pitch), the
 //         per-row camera table and the per-row fogged palette; a thread owns a 4-pixel column group and walks rows:
 //         1 packed-fp32 fma per pixel, saturating convert + min (= floor + clamp), mad_u24 addressing, one LDS map
 //         read, bit-field extract, one LDS palette read; 4 pixels -> 12 bytes via v_perm, so one wave-instruction
 //         stores 768 contiguous bytes (6 full 128-B lines).  Bound: HBM writes (57,600 B per env-step at 120x160).
 //     Inside a multi-step call the raster team renders step t-1 while the physics team computes step t; the host
 //     opens the call with a physics-only launch and closes it with a raster-only launch (the lag never leaves the
-//     call).  A single-step call runs physics -> barrier -> raster in one launch.
+//     call).  A single-step call is one launch: the raster team writes the rows that need no pose (sky, far ground)
+//     and then waits per env for the physics team's progress counter.  All LDS staging is LDS-DMA before one barrier.
 //   trs_physics_kernel  camera off (BASELINE config 2): the same wave-per-env routine, 4 envs per 256-thread
 //     workgroup, K steps per launch, no synchronisation after the one-time staging of the track into LDS.
 //   trs_locate_kernel   batched LocationTracker for arbitrary binary64 query points.
@@ -43,10 +44,16 @@
 
 namespace {
 
-constexpr int kBlock = 960;            // 15 waves: 4800 four-pixel groups of a 120x160 image = 5 x 960
+#ifndef TRS_RASTER_WAVES
+#define TRS_RASTER_WAVES 8    /* raster waves per workgroup: 512 threads = 12 full rows of 40 groups per pass, 10 passes exactly at 120x160, and 12 waves balance over the 4 SIMDs (10 + 5 waves: 72.5 M env-steps/s, 8 + 4: 77.0 M; profiles/r01_step_kernel_waves_ab.txt) */
+#endif
+#ifndef TRS_PHYS_WAVES
+#define TRS_PHYS_WAVES 4      /* physics waves per workgroup: one env per wave at 1024 envs */
+#endif
+constexpr int kBlock = 64 * (TRS_RASTER_WAVES + TRS_PHYS_WAVES);   // 12 waves
 constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
 constexpr int kRing = 4;               // global camera-parameter ring: the last step of launch i is the first frame of launch i+1
-[[maybe_unused]] constexpr int kRasterStampThread = 640;  // diagnostic stamps: wave 0 and the first physics wave
+[[maybe_unused]] constexpr int kRasterStampThread = 64 * TRS_RASTER_WAVES;  // diagnostic stamps: wave 0 and the first physics wave
 
 struct PParams {                        // physics kernel
     float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
@@ -183,16 +190,15 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 #define STAMP_STATS sp.ra.stats
 // ---------------------------------------------------------------------------------------------
 // Fused, wave-specialised step kernel (camera on).  One launch per env step, one stream.
-//   raster team  = waves 0..9  (640 threads): rasterises the frame of camera-ring slot `r_slot`
-//   physics team = waves 10..14 (one wave per env, no workgroup barriers): advances the envs one step and
+//   raster team  = waves 0..7  (512 threads): rasterises the frame of camera-ring slot `r_slot`
+//   physics team = waves 8..11 (one wave per env, no workgroup barriers): advances the envs one step and
 //                  writes their camera parameters to ring slot `p_slot`
 //   seq = 1  (single-step call): raster waits for this launch's physics and renders the SAME step
 //   seq = 0  (inside a multi-step call): raster renders the PREVIOUS step while physics computes the next one;
 //            the host issues a physics-only first launch and a raster-only last launch, so the lag never
 //            leaves the call.
-constexpr int kRasterThreads = 640;
-constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;   // 5
-constexpr int kStageRegs = 10;                               // 10 x 640 x 16 B = 100 KB per pass of the raster team
+constexpr int kRasterThreads = 64 * TRS_RASTER_WAVES;
+constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;
 
 struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernel (DYN instantiation)
     double baseline;
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const float* lrowdepth = reinterpret_cast<const float*>(smem + p.off_depth);
     const float half_w = (float)(p.W / 2);
     const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
-    const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (none at W = 160: 16 x 40 = 640)
+    const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (32 of 512 at W = 160: 12 x 40 = 480)
     const float uf0 = (float)(cg << 2) + 0.5f - half_w;
     const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
     const unsigned pitch = (unsigned)p.map_pitch_b;
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 return cls_of(ufa) | (cls_of(ufb) << 2) | (cls_of(ufc) << 4) | (cls_of(ufd) << 6);
             };
             // (A)
-            unsigned sr = 0, sg = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0;
+            unsigned sr = 0, sg = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
             int slot = 0;
             for (int v = vstart; v < f.w1; v += p.rows_per_pass) {
                 if (v < f.w0) continue;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 if (v >= p.uni_rows) {
                     pack = classify4(v);
                     const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
-                    cb0 |= word == 0 ? pack << sh : 0u; cb1 |= word == 1 ? pack << sh : 0u; cb2 |= word == 2 ? pack << sh : 0u;
+                    cb0 |= word == 0 ? pack << sh : 0u; cb1 |= word == 1 ? pack << sh : 0u; cb2 |= word == 2 ? pack << sh : 0u; cb3 |= word == 3 ? pack << sh : 0u;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 unsigned pack = 0;
                 if (v >= p.uni_rows) {
                     if (in_win) {
-                        const unsigned word = (unsigned)slot >> 2, wv = word == 0 ? cb0 : (word == 1 ? cb1 : cb2);
+                        const unsigned word = (unsigned)slot >> 2, wv = word == 0 ? cb0 : (word == 1 ? cb1 : (word == 2 ? cb2 : cb3));
                         pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
                     } else {
                         pack = classify4(v);
@@ -1407,7 +1413,7 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     k.cam_fwd = cfg->cam_fwd; k.auto_reset = cfg->auto_reset; k.seed = cfg->seed;
     if (r.gpr > kBlock) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup"); }
     if (r.gpr > kRasterThreads) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than raster threads"); }
-    r.rows_per_pass = kRasterThreads / r.gpr;   // raster threads beyond rows_per_pass * gpr idle (none at W = 160: 16 x 40 = 640)
+    r.rows_per_pass = kRasterThreads / r.gpr;   // raster threads beyond rows_per_pass * gpr idle (32 of 512 at W = 160)
     HIPCHK(hipStreamSynchronize(e->sP));
     *out = e;
     return TRS_OK;
@@ -1465,7 +1471,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     r.off_depth = (int)roff; roff += align_up((size_t)e->H * 4, 16);
     r.blob_bytes = (int)roff;
     e->lds_r = (int)align_up(roff, 16);
-    if ((size_t)r.blob_bytes > (size_t)kStageRegs * kRasterThreads * 16)
+    if ((size_t)r.blob_bytes > (size_t)100 * 1024)
         return fail(TRS_ERR_LIMIT, "map + camera tables exceed the step kernel's LDS staging capacity");
     // tangents ride in LDS when the fused kernel's image (raster tables + points + tangents) still fits a CU's 160 KiB
     e->lds_off_phys = e->lds_r;
@@ -1864,7 +1870,7 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
         if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
         if (c->dynamic_brightness) {
             const int rpp = kRasterThreads / (e->W / 4);
-            if (rpp < 1 || (79 + rpp - 1) / rpp > 12) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 3 registers), use trs_preprocess");
+            if (rpp < 1 || (79 + rpp - 1) / rpp > 16) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 4 registers), use trs_preprocess");
             if (e->track_loaded && e->max_steps_dyn < 1) return fail(TRS_ERR_LIMIT, "no LDS left beside this track's tables for the in-kernel dynamic-brightness palette, use trs_preprocess");
         }
         e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
