@@ -811,9 +811,23 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
     __shared__ int s_tab[512];
     __shared__ unsigned s_part[16][3];
     __shared__ float s_delta;
+    // per-value tables replace per-pixel arithmetic (the masks variant was VALU bound at ~80 integer ops per pixel):
+    // s_trim[x] = the trim of byte value x for this frame's delta; s_rng[c][x] = bit f set when value x of component c
+    // (h, s, v) lies inside filter f's range -> one AND of three lookups answers all (<= 4) in-range tests of a pixel
+    __shared__ unsigned s_trim[256];
+    __shared__ unsigned s_rng[3][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const size_t frame_bytes = (size_t)p.gpe * 12;
     for (int i = tid; i < 512; i += nthreads) s_tab[i] = p.hsv_tab[i];
+    for (int i = tid; i < 768; i += nthreads) {
+        const int c = i >> 8, x = i & 255;
+        unsigned bits = 0;
+        for (int f = 0; f < p.n_filters; ++f) {
+            const int lo = (p.lo[f] >> (8 * c)) & 255, hi = (p.hi[f] >> (8 * c)) & 255;
+            bits |= (x >= lo && x <= hi) ? 1u << f : 0u;
+        }
+        s_rng[c][x] = bits;
+    }
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
@@ -843,29 +857,28 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         }
         __syncthreads();
         const float deltaf = s_delta, off = p.offset, con = p.contrast;
+        if (tid < 256) {                                                    // this frame's trim of every byte value, in numpy's operation order (:92-99)
+            float x = (float)tid;
+            if (p.dynamic) x = x + deltaf;
+            x = x - off;
+            x = x * con;
+            x = x + off;
+            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+            s_trim[tid] = (unsigned)(int)x;
+        }
+        __syncthreads();
         // ---- pass 2: trim, masks, merge ----
         for (int g = tid; g < p.gpe; g += nthreads) {
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
-            unsigned by[12];
+            unsigned t[12];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { by[k] = (w.x >> (8 * k)) & 255u; by[4 + k] = (w.y >> (8 * k)) & 255u; by[8 + k] = (w.z >> (8 * k)) & 255u; }
+            for (int k = 0; k < 4; ++k) { t[k] = s_trim[(w.x >> (8 * k)) & 255u]; t[4 + k] = s_trim[(w.y >> (8 * k)) & 255u]; t[8 + k] = s_trim[(w.z >> (8 * k)) & 255u]; }
             unsigned ob[12];
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
-                int t[3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    float x = (float)by[3 * px + ch];
-                    if (p.dynamic) x = x + deltaf;
-                    x = x - off;
-                    x = x * con;
-                    x = x + off;
-                    x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
-                    t[ch] = (int)x;
-                }
-                int o0 = t[0], o1 = t[1], o2 = t[2];
+                unsigned o0 = t[3 * px], o1 = t[3 * px + 1], o2 = t[3 * px + 2];
                 if (p.color) {
-                    const int r = t[0], gg = t[1], b = t[2];
+                    const int r = (int)o0, gg = (int)o1, b = (int)o2;
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
                     const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
                     const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
@@ -873,15 +886,14 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                     h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
-                    for (int f = 0; f < p.n_filters; ++f) {
-                        const int lh = p.lo[f] & 255, ls = (p.lo[f] >> 8) & 255, lv = (p.lo[f] >> 16) & 255;
-                        const int uh = p.hi[f] & 255, us = (p.hi[f] >> 8) & 255, uv = (p.hi[f] >> 16) & 255;
-                        const int m = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
+                    const unsigned inr = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
+                    for (int f = 0; f < p.n_filters; ++f) {                 // later filters overwrite earlier ones (:57-63)
+                        const unsigned m = (inr >> f) & 1u ? 255u : 0u;
                         const int dc = p.dst_ch[f];
                         o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
                     }
                 }
-                ob[3 * px] = (unsigned)o0; ob[3 * px + 1] = (unsigned)o1; ob[3 * px + 2] = (unsigned)o2;
+                ob[3 * px] = o0; ob[3 * px + 1] = o1; ob[3 * px + 2] = o2;
             }
             const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
                              ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
