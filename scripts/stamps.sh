@@ -10,13 +10,16 @@ sys.path.insert(0, '.')
 from triton_racer_sim_amd.env import BatchedEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 env = BatchedEnv(n_envs=n, auto_reset=True)
+import os
+if os.environ.get("STAMPS_DYN"):
+    env.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True, "preprocessing_color_filter_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2})
 env.step_synthetic(50, 1)
-names = ["entry", "DMA + poses requested", "barrier passed (all staged)", "physics done (phys wave)", "(unused)", "raster done"]
+names = ["entry", "DMA + poses requested", "barrier passed (all staged)", "physics done (phys wave)", "(unused)", "raster done", "dyn: rows classified + sums (A)", "dyn: barrier A passed", "dyn: palettes built + barrier B"]
 acc = []
 for _ in range(10):
     env.step_synthetic(6, 1)          # pipelined: last full launch before the raster-only flush is what remains in the slots
     st = env.fetch("stats").astype(np.int64)
-    acc.append(np.stack([st[8:14], st[32:38]]))
+    acc.append(np.stack([st[8:17], st[32:41]]))
 a = np.median(np.array(acc), axis=0)
 base = a[0, 0]
 print(f"n_envs={n} (ticks from wave 0 entry; NOTE the final launch of a call is raster-only, so physics slots are from the launch before)")

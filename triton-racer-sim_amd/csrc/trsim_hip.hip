@@ -206,7 +206,8 @@ struct FParams {                        // ImgPreprocessing with dynamic brightn
     int color, n_filters;
     int lo[4], hi[4], dst_ch[4];
     int w0, w1;                         // brightness window: image rows [w0, w1) = img[40:119] (img_preprocessing.py:88)
-    int lds_off;                        // LDS: uint32 penv[H][4] | int esum[2][3] | int dbar
+    int lds_off;                        // LDS: uint32 penv[4][H][4] | int esum[2][4][3] | int dbar | float edelta[4]
+    const int* hsv_tab;                 // [512] OpenCV's sdiv | hdiv fixed-point reciprocals (global, 2 KB, cache resident)
 };
 
 struct SParams {
@@ -223,7 +224,7 @@ struct SParams {
 };
 
 // ImgPreprocessing.__process of ONE colour with this frame's brightness delta (img_preprocessing.py:37-74,92-99): the
-// per-pixel arithmetic of trs_preprocess_kernel, with OpenCV's fixed-point reciprocals computed instead of tabulated
+// per-pixel arithmetic of trs_preprocess_kernel (OpenCV's fixed-point reciprocal tables are read from global memory)
 __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t bgr, float deltaf)
 {
     int t[3];
@@ -241,8 +242,7 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
     if (f.color) {
         const int r = t[0], g = t[1], b = t[2];
         const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
-        const int sdiv = v ? __double2int_rn((double)(255 << 12) / (1.0 * (double)v)) : 0;
-        const int hdiv = diff ? __double2int_rn((double)(180 << 12) / (6.0 * (double)diff)) : 0;
+        const int sdiv = f.hsv_tab[v], hdiv = f.hsv_tab[256 + diff];
         const int sat = (diff * sdiv + (1 << 11)) >> 12;
         int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
         h = (h * hdiv + (1 << 11)) >> 12;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
-    if constexpr (DYN) { if (tid < 8) reinterpret_cast<int*>(smem + sp.fp.lds_off + p.H * 16)[tid] = 0; }   // esum[2][3], dbar
+    if constexpr (DYN) { if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0; }   // esum[2][4][3], dbar
     // ---- prologue: everything is staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves
     // 64 lanes x 16 B = 1 KB, lane-linear, no registers and no ds_write pass), all requests are in flight together and
     // one workgroup barrier closes the stage.  Raster waves: the class map + row tables (one linear image at LDS offset
@@ -613,24 +613,39 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     for (int e = e_begin; e < e_end; ++e) {
         if constexpr (DYN) {
             // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
-            // every pixel there, so: (A) classify those rows once (classes kept in registers), sum the RAW colours per
-            // channel, reduce over the team; (B) every thread filters one entry of a per-env palette with this frame's
-            // delta; (C) shade all rows from that palette.  No extra pass over HBM, each pixel classified once.
+            // every pixel there, so, for up to kDynBatch envs at a time: (A) classify those rows once (classes kept in
+            // registers), sum the RAW colours per channel, reduce over the team; (B) every thread filters entries of the
+            // per-env palettes with each frame's delta; (C) shade all rows from those palettes.  No extra pass over HBM, each
+            // pixel classified once, two team barriers per batch.
+            constexpr int kDynBatch = 4;
+            if ((e - e_begin) % kDynBatch != 0) continue;                     // the batch leader does the work
             const FParams& f = sp.fp;
-            uint32_t* const penv = reinterpret_cast<uint32_t*>(smem + f.lds_off);
-            int* const esum = reinterpret_cast<int*>(smem + f.lds_off + p.H * 16);     // [2][3]
-            int* const dbar = esum + 6;
-            const int it = (sidx - sp.r_first) * (e_end - e_begin) + (e - e_begin);    // env iterations so far (same in every wave)
+            uint32_t* const penv = reinterpret_cast<uint32_t*>(smem + f.lds_off);                          // [kDynBatch][H][4]
+            int* const esum = reinterpret_cast<int*>(smem + f.lds_off + kDynBatch * p.H * 16);           // [2][kDynBatch][3]
+            int* const dbar = esum + 2 * kDynBatch * 3;
+            const int nbatch = (e_end - e_begin + kDynBatch - 1) / kDynBatch;
+            const int it = (sidx - sp.r_first) * nbatch + (e - e_begin) / kDynBatch;   // batches so far (same in every wave)
             const int par = it & 1;
-            const int j = e - e_begin;
-            float4 cam;
-            if (sidx < 0) cam = lcam_prev[j];
-            else {
-                while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
-                cam = lcam[sidx * sp.cam_stride + j];
+            const int nrw = kRasterThreads / 64;
+            unsigned cbits[kDynBatch][4];
+            float4 cams[kDynBatch];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                const int eb = e + bi;
+                cams[bi] = make_float4(0.f, 0.f, 0.f, 1.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cbits[bi][k] = 0u;
+                if (eb < e_end) {
+                    const int j = eb - e_begin;
+                    if (sidx < 0) cams[bi] = lcam_prev[j];
+                    else {
+                        while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
+                        cams[bi] = lcam[sidx * sp.cam_stride + j];
+                    }
+                }
             }
-            const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-            auto classify4 = [&](int v) -> unsigned {                         // classes of this thread's 4 pixels of row v, 2 bits each
+            auto classify4 = [&](int v, const float4& cam) -> unsigned {       // classes of this thread's 4 pixels of row v, 2 bits each
+                const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
                 const f2v rt = lrow[v];
                 const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
                 const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
@@ -639,80 +654,118 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                     const f2v g = __builtin_elementwise_fma(uf, d, a);
                     const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
                     const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
-                    const uint32_t w = *(lds_u32p)(uintptr_t)(iz * pitch + ((ix >> 2) & ~3u));
+                    unsigned waddr;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(pitch), "v"((ix >> 2) & ~3u));
+                    const uint32_t w = *(lds_u32p)(uintptr_t)waddr;
                     return __builtin_amdgcn_ubfe(w, ix << 1, 2);
                 };
                 return cls_of(ufa) | (cls_of(ufb) << 2) | (cls_of(ufc) << 4) | (cls_of(ufd) << 6);
             };
-            // (A)
-            unsigned sr = 0, sg = 0, sb = 0, cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
-            int slot = 0;
-            for (int v = vstart; v < f.w1; v += p.rows_per_pass) {
-                if (v < f.w0) continue;
-                const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
-                unsigned pack = 0;
-                if (v >= p.uni_rows) {
-                    pack = classify4(v);
-                    const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
-                    cb0 |= word == 0 ? pack << sh : 0u; cb1 |= word == 1 ? pack << sh : 0u; cb2 |= word == 2 ? pack << sh : 0u; cb3 |= word == 3 ? pack << sh : 0u;
-                }
+            // (A) rows outside, envs inside: the (up to) four envs' lookups of one row are independent chains (row table -> map
+            // -> palette are three dependent LDS round trips per row, and two waves per SIMD cannot hide them one env at a time)
+            unsigned srb[kDynBatch], sgs[kDynBatch];                          // R | B << 16 and G: <= 24 rows x 4 px x 255 per thread fits 16 bits
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t c = *(lds_u32p)(uintptr_t)(pal_a + (((pack >> (2 * k)) & 3u) << 2));
-                    sr += c & 255u; sg += (c >> 8) & 255u; sb += (c >> 16) & 255u;
+            for (int bi = 0; bi < kDynBatch; ++bi) { srb[bi] = 0u; sgs[bi] = 0u; }
+            {
+                int slot = 0;
+                for (int v = vstart; v < f.w1; v += p.rows_per_pass) {
+                    if (v < f.w0) continue;
+                    const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+                    const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
+                    unsigned packs[kDynBatch];
+#pragma unroll
+                    for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = (v >= p.uni_rows && e + bi < e_end) ? classify4(v, cams[bi]) : 0u;
+#pragma unroll
+                    for (int bi = 0; bi < kDynBatch; ++bi) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) cbits[bi][k] |= word == (unsigned)k ? packs[bi] << sh : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t c = *(lds_u32p)(uintptr_t)(pal_a + (((packs[bi] >> (2 * k)) & 3u) << 2));
+                            srb[bi] += c & 0x00FF00FFu; sgs[bi] += (c >> 8) & 255u;
+                        }
+                    }
+                    ++slot;
                 }
-                ++slot;
             }
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-            if (lane == 0) { atomicAdd(&esum[par * 3], (int)sr); atomicAdd(&esum[par * 3 + 1], (int)sg); atomicAdd(&esum[par * 3 + 2], (int)sb); }
-            const int nrw = kRasterThreads / 64;
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                if (e + bi >= e_end) continue;
+                unsigned sr = srb[bi] & 0xFFFFu, sb = srb[bi] >> 16, sg = sgs[bi];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+                if (lane == 0) {
+                    int* const es = esum + (par * kDynBatch + bi) * 3;
+                    atomicAdd(&es[0], (int)sr); atomicAdd(&es[1], (int)sg); atomicAdd(&es[2], (int)sb);
+                }
+            }
+            STAMP(6);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 1)) __builtin_amdgcn_s_sleep(1);
-            // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then one palette entry per thread
+            STAMP(7);
+            // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then the palette entries
             {
                 const double cnt = (double)(f.w1 - f.w0) * (double)p.W;
-                double cur = 0.0;
+                const int per_env = p.H * 4;
+                float dl = 0.0f;                                              // lane b of every wave computes env b's delta once (binary64 divisions)
+                if (lane < kDynBatch && e + lane < e_end) {
+                    const int* const es = esum + (par * kDynBatch + lane) * 3;
+                    double cur = 0.0;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) cur = cur + (cnt > 0 ? (double)esum[par * 3 + ch] / cnt : 0.0);
-                cur = cur + 0.0;
-                const float deltaf = (float)((f.baseline - cur) / 3);
-                for (int t = tid; t < p.H * 4; t += kRasterThreads)
-                    penv[t] = filter_colour_dev(f, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)t << 2)), deltaf);
-                if (tid < 3) esum[(par ^ 1) * 3 + tid] = 0;                     // the next env's sums start from zero (nobody reads that half now)
+                    for (int ch = 0; ch < 3; ++ch) cur = cur + (cnt > 0 ? (double)es[ch] / cnt : 0.0);
+                    cur = cur + 0.0;
+                    dl = (float)((f.baseline - cur) / 3);
+                }
+                float dlt[kDynBatch];
+#pragma unroll
+                for (int bi = 0; bi < kDynBatch; ++bi) dlt[bi] = __shfl(dl, bi, 64);
+                for (int t = tid; t < kDynBatch * per_env; t += kRasterThreads) {
+                    const int bi = t / per_env, ent = t - bi * per_env;
+                    if (e + bi >= e_end) break;
+                    const float deltaf = bi == 0 ? dlt[0] : (bi == 1 ? dlt[1] : (bi == 2 ? dlt[2] : dlt[3]));
+                    penv[t] = filter_colour_dev(f, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)), deltaf);
+                }
+                if (tid < kDynBatch * 3) esum[(par ^ 1) * kDynBatch * 3 + tid] = 0;   // the next batch's sums start from zero (nobody reads that half now)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 2)) __builtin_amdgcn_s_sleep(1);
+            STAMP(8);
             // (C)
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
-            __amdgpu_buffer_rsrc_t drs = rsrc;
-            if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
-            slot = 0;
-            const unsigned penv_a = (unsigned)f.lds_off;
-            for (int v = vstart; v < p.H; v += p.rows_per_pass) {
-                const bool in_win = v >= f.w0 && v < f.w1;
-                unsigned pack = 0;
-                if (v >= p.uni_rows) {
-                    if (in_win) {
-                        const unsigned word = (unsigned)slot >> 2, wv = word == 0 ? cb0 : (word == 1 ? cb1 : (word == 2 ? cb2 : cb3));
-                        pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
-                    } else {
-                        pack = classify4(v);
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                const int eb = e + bi;
+                if (eb >= e_end) continue;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    img + (size_t)eb * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+                __amdgpu_buffer_rsrc_t drs = rsrc;
+                if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)eb * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+                int slot = 0;
+                const unsigned penv_a = (unsigned)f.lds_off + (unsigned)(bi * p.H * 16);
+                for (int v = vstart; v < p.H; v += p.rows_per_pass) {
+                    const bool in_win = v >= f.w0 && v < f.w1;
+                    unsigned pack = 0;
+                    if (v >= p.uni_rows) {
+                        if (in_win) {
+                            const unsigned word = (unsigned)slot >> 2;
+                            const unsigned wv = word == 0 ? cbits[bi][0] : (word == 1 ? cbits[bi][1] : (word == 2 ? cbits[bi][2] : cbits[bi][3]));
+                            pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
+                        } else {
+                            pack = classify4(v, cams[bi]);
+                        }
                     }
-                }
-                if (in_win) ++slot;
-                const unsigned row_a = penv_a + ((unsigned)v << 4);
-                const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
-                const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
-                const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
-                __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
-                if constexpr (DEPTH) {
-                    const unsigned dz = __float_as_uint(lrowdepth[v]);
-                    const u4v d4 = {dz, dz, dz, dz};
-                    __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+                    if (in_win) ++slot;
+                    const unsigned row_a = penv_a + ((unsigned)v << 4);
+                    const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
+                    const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
+                    const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
+                    __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
+                    if constexpr (DEPTH) {
+                        const unsigned dz = __float_as_uint(lrowdepth[v]);
+                        const u4v d4 = {dz, dz, dz, dz};
+                        __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+                    }
                 }
             }
             continue;
@@ -1278,8 +1331,9 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
             sp.fp.dst_ch[k] = c.dst_channel[k];
         }
         sp.fp.w0 = std::min(40, e->H); sp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
+        sp.fp.hsv_tab = e->hsv_tab;
         sp.fp.lds_off = (lds + 15) & ~15;
-        lds = sp.fp.lds_off + e->H * 16 + 64;                              // per-env palette + channel sums + barrier counter
+        lds = sp.fp.lds_off + 4 * e->H * 16 + 128;                         // palettes of a batch of 4 envs + channel sums + barrier counter
     }
     const dim3 grid(grid_of(e)), block(kBlock);
     if (dyn) {
@@ -1534,7 +1588,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         const int epw = k.envs_per_wg;
         const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16;
         e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
-        const int free_dyn = free_b - (e->H * 16 + 96);
+        const int free_dyn = free_b - (4 * e->H * 16 + 160);
         e->max_steps_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
@@ -1885,6 +1939,7 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
             if (rpp < 1 || (79 + rpp - 1) / rpp > 16) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 4 registers), use trs_preprocess");
             if (e->track_loaded && e->max_steps_dyn < 1) return fail(TRS_ERR_LIMIT, "no LDS left beside this track's tables for the in-kernel dynamic-brightness palette, use trs_preprocess");
         }
+        if (c->dynamic_brightness) { HIPCHK(hipSetDevice(e->device)); rc = ensure_hsv_table(e); if (rc) return rc; }
         e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
     } else {
         e->has_frame_filter = false;
