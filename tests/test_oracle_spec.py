@@ -103,3 +103,42 @@ def test_image_sanity(make_env):
     assert (np.abs(near - road).sum(1) < 40).mean() > 0.5  # the car starts on the road: asphalt fills the near field
     pal = env.fetch("palette")
     assert (pal[:40] == pal[:40, :1]).all()                # sky rows: one colour for every class
+
+
+def test_render_matches_numpy_restatement(make_env):
+    """The oracle's camera loop restated independently with vectorised numpy from the oracle's own tables (class map, row
+    table, palette) and the env's pose: include/trsim_spec.h 'one frame'.  fma is emulated through binary64 (a double
+    rounding can differ from a true fma in the last bit), so the check allows a handful of boundary pixels."""
+    n, H, W = 6, 120, 160
+    env = make_env("oracle", n_envs=n, auto_reset=True)
+    env.step_synthetic(40, 1)
+    mi = env.map_info
+    gmap = env.fetch("map").reshape(mi.map_h, mi.map_words)
+    rowtab = env.fetch("rowtab").reshape(H, 2)
+    pal = env.fetch("palette").reshape(H, 4)
+    img = env.fetch("img")
+    x, z, yaw = env.fetch("pos_x"), env.fetch("pos_z"), env.fetch("yaw")
+    x0f, z0f, inv = F(mi.x0), F(mi.z0), F(1.0 / mi.cell)
+    fwd = F(env.cfg.cam_fwd)
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+    uf = (np.arange(W, dtype=F) + F(0.5) - F(W // 2))[None, :]
+    bad = 0
+    for i in range(n):
+        s, c = np_sincos(yaw[i])
+        camx = F(F(F(x[i] + F(fwd * s)) - x0f) * inv)
+        camz = F(F(F(z[i] + F(fwd * c)) - z0f) * inv)
+        lz, kk = rowtab[:, :1], rowtab[:, 1:]
+        ax, az = fma(lz, np.full_like(lz, s), np.full_like(lz, camx)), fma(lz, np.full_like(lz, c), np.full_like(lz, camz))
+        dx, dz = (kk * F(c)).astype(F), (-(kk * F(s))).astype(F)
+        gx = fma(np.broadcast_to(uf, (H, W)), np.broadcast_to(dx, (H, W)), np.broadcast_to(ax, (H, W)))
+        gz = fma(np.broadcast_to(uf, (H, W)), np.broadcast_to(dz, (H, W)), np.broadcast_to(az, (H, W)))
+        ix = np.clip(np.floor(gx).astype(np.int64), 0, mi.map_w - 1)
+        iz = np.clip(np.floor(gz).astype(np.int64), 0, mi.map_h - 1)
+        cls = (gmap[iz, ix >> 4] >> ((ix & 15) * 2).astype(np.uint32)) & 3
+        rgb = pal[np.arange(H)[:, None], cls]
+        want = np.stack([rgb & 255, (rgb >> 8) & 255, (rgb >> 16) & 255], -1).astype(np.uint8)
+        bad += int((want != img[i]).any(-1).sum())
+    assert bad <= 3 * n, bad                                                # double-rounded fma at a cell boundary, at most
