@@ -198,9 +198,20 @@ def main():
         env.step_synthetic(args.steps, 8)
         env.event_record(3)
         ms8 = env.event_elapsed_ms(2, 3)
-        also = {"steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms8 * 1e-3), 1),
+        # ... and with externally produced controls: a device-resident action sequence, one control set per step (trs_step_sequence)
+        seq_steer = (torch.rand((args.steps, n), device="cuda") * 2 - 1) * 0.3
+        seq_thr = torch.rand((args.steps, n), device="cuda") * 0.6 + 0.2
+        torch.cuda.synchronize()
+        env.event_record(4)
+        env.step_sequence_device(seq_steer.data_ptr(), seq_thr.data_ptr(), n_steps=args.steps, steps_per_launch=8)
+        env.event_record(5)
+        ms_seq = env.event_elapsed_ms(4, 5)
+        also = {"sequence_steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms_seq * 1e-3), 1),
+                                                "frac_of_hbm_peak": round(algorithmic_bytes(args.img_h, args.img_w, render, args.depth) * n * args.steps / (ms_seq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                                "note": "trs_step_sequence: a different device-resident control set per step (open-loop action sequences), 8 steps per launch"},
+                "steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms8 * 1e-3), 1),
                                        "frac_of_hbm_peak": round(algorithmic_bytes(args.img_h, args.img_w, render, args.depth) * n * args.steps / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                       "note": "physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
+                                       "note": "synthetic controls; physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -133,6 +133,16 @@ int trs_step_host(trs_env* env, const float* h_steering, const float* h_throttle
  * (SURVEY.md §8d), evaluated inside the step kernel.  steps_per_launch >= 1. */
 int trs_step_synthetic(trs_env* env, int n_steps, int steps_per_launch);
 
+/* n_steps env steps with a DIFFERENT control set per step (open-loop action sequences: action repeat, shooting-method
+ * planners): d_steering / d_throttle / d_brake are [n_steps][n_envs] device arrays (d_brake NULL = 0), d_reset
+ * [n_envs] applies to the first step.  Like trs_step_synthetic the call runs steps_per_launch steps per kernel launch
+ * (the physics team runs ahead of the raster team through the LDS ring), so a consumer that decides on whole sequences
+ * gets the multi-step throughput.  Every step's frame is rendered; the state and frame of the LAST step remain. */
+int trs_step_sequence(trs_env* env, const float* d_steering, const float* d_throttle, const float* d_brake,
+                      const uint8_t* d_reset, int n_steps, int steps_per_launch);
+int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h_throttle, const float* h_brake,
+                           const uint8_t* h_reset, int n_steps, int steps_per_launch);
+
 /* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
 int trs_get_state(trs_env* env, trs_state_view* out);
 

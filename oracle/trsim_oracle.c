@@ -478,6 +478,21 @@ EXPORT int trso_step(trs_env* e, const float* st, const float* th, const float* 
 { return do_steps(e, st, th, br, rs, n, 0); }
 EXPORT int trso_step_host(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n)
 { return do_steps(e, st, th, br, rs, n, 0); }
+EXPORT int trso_step_sequence(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n_steps, int steps_per_launch)
+{
+    if (!e || !e->np) return fail(TRS_ERR_STATE, "no track loaded");
+    if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
+    if (!st || !th) return fail(TRS_ERR_ARG, "null controls");
+    for (int k = 0; k < n_steps; ++k) {                     /* one plain step per control set */
+        size_t o = (size_t)k * (size_t)e->n;
+        int rc = do_steps(e, st + o, th + o, br ? br + o : NULL, k == 0 ? rs : NULL, 1, 0);
+        if (rc) return rc;
+    }
+    return TRS_OK;
+}
+EXPORT int trso_step_sequence_host(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n_steps, int steps_per_launch)
+{ return trso_step_sequence(e, st, th, br, rs, n_steps, steps_per_launch); }
+
 EXPORT int trso_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
 { (void)steps_per_launch; return do_steps(e, NULL, NULL, NULL, NULL, n_steps, 1); }
 

@@ -297,3 +297,31 @@ def test_non_default_parameters_match_oracle(make_env, kw):
     pal = o.fetch("palette").reshape(-1, 4)
     uni = int(np.argmin((pal[:, 0] == pal[:, 1]) & (pal[:, 1] == pal[:, 2]) & (pal[:, 2] == pal[:, 3]))) if not np.all(pal[:, :1] == pal) else len(pal)
     assert 0 <= uni <= 120
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("render", [True, False])
+def test_step_sequence_equals_single_steps(make_env, render):
+    """trs_step_sequence: a different control set per step inside multi-step launches == the same controls fed one
+    trs_step at a time (HIP) == the oracle."""
+    n, k = 70, 13
+    rng = np.random.default_rng(5)
+    st = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    th = rng.uniform(-0.2, 1, (k, n)).astype(np.float32)
+    br = (rng.uniform(0, 1, (k, n)) * (rng.uniform(0, 1, (k, n)) < 0.2)).astype(np.float32)
+    seq = make_env("hip", n_envs=n, render=render, auto_reset=True)
+    one = make_env("hip", n_envs=n, render=render, auto_reset=True)
+    ora = make_env("oracle", n_envs=n, render=render, auto_reset=True)
+    for env in (seq, one, ora):
+        env.step_synthetic(3, 1)
+    seq.step_sequence(st, th, br, steps_per_launch=5)
+    ora.step_sequence(st, th, br, steps_per_launch=5)
+    for t in range(k):
+        one.step(st[t], th[t], br[t])
+    names = ["seg_idx", "done", "ep_len"] + (["img"] if render else [])
+    for name in names:
+        assert np.array_equal(seq.fetch(name), one.fetch(name)), name
+        assert np.array_equal(seq.fetch(name), ora.fetch(name)), name
+    for name in ("pos_x", "pos_z", "speed", "cte", "yaw", "ep_return"):
+        assert np.array_equal(seq.fetch(name), one.fetch(name)), name
+        assert np.max(np.abs(seq.fetch(name) - ora.fetch(name))) <= 1e-5, name

@@ -61,6 +61,7 @@ struct PParams {                        // physics kernel
     uint8_t *done, *pending;
     const float *ctl_steer, *ctl_thr, *ctl_brk;
     const uint8_t* ctl_reset;
+    int ctl_stride;                     // elements between the control arrays of consecutive steps of a launch (0 = the same controls every step)
     float4* cam;                        // [kRing][n_envs] camx, camz, sin, cos (cell units) for the raster kernel
     const unsigned char* blob;          // physics LDS image: px | py | pz | tangent
     const float* start_yaw;             // [np]
@@ -368,7 +369,10 @@ __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* 
     const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
     float sf = s.sf;
     float steer = 0.f, thr = 0.f, brk = 0.f;
-    if (!p.synth) { steer = p.ctl_steer[e]; thr = p.ctl_thr[e]; brk = p.ctl_brk ? p.ctl_brk[e] : 0.0f; }
+    if (!p.synth) {
+        const size_t ci = (size_t)k * (size_t)p.ctl_stride + (size_t)e;
+        steer = p.ctl_steer[ci]; thr = p.ctl_thr[ci]; brk = p.ctl_brk ? p.ctl_brk[ci] : 0.0f;
+    }
     const int prev_idx = s.seg;
     float epr = s.epr;
     int epl = s.epl;
@@ -1286,6 +1290,8 @@ struct trs_env {
     uint8_t* ctl_reset = nullptr;
     size_t img_bytes = 0;
     int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
+    float* seq_buf = nullptr; size_t seq_cap = 0;   // device copy of host control sequences (trs_step_sequence_host)
+    int seq_stride = 0;                  // trs_step_sequence: n_envs while a sequence call is running, else 0
     int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
 };
@@ -1307,7 +1313,7 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
 {
     SParams sp;
     sp.ph = e->pp;
-    sp.ph.ctl_steer = st; sp.ph.ctl_thr = th; sp.ph.ctl_brk = br; sp.ph.ctl_reset = rs;
+    sp.ph.ctl_steer = st; sp.ph.ctl_thr = th; sp.ph.ctl_brk = br; sp.ph.ctl_reset = rs; sp.ph.ctl_stride = e->seq_stride;
     sp.ph.synth = synth; sp.ph.n_steps = n_phys; sp.ph.write_cam = 1; sp.ph.step_off = (uint32_t)step_base;
     sp.ra = e->rp;
     sp.img0 = e->img[0]; sp.img1 = e->img[1];
@@ -1365,7 +1371,8 @@ int run_camera_steps(trs_env* e, const float* st, const float* th, const float* 
     } else {
         for (int done = 0; done < n && !rc;) {
             const int k = std::min(kmax, n - done);
-            rc = launch_step(e, st, th, br, done == 0 ? rs : nullptr, synth, k, done == 0 ? 0 : -1, k - 2, s0 + done);
+            const size_t co = (size_t)done * (size_t)e->seq_stride;       // a sequence call hands each launch its own slice of controls
+            rc = launch_step(e, st ? st + co : st, th ? th + co : th, br ? br + co : br, done == 0 ? rs : nullptr, synth, k, done == 0 ? 0 : -1, k - 2, s0 + done);
             done += k;
         }
         if (!rc) rc = launch_step(e, st, th, br, nullptr, synth, 0, -1, -1, s0 + n);
@@ -1381,7 +1388,9 @@ int run_physics_steps(trs_env* e, const float* st, const float* th, const float*
     for (int done = 0; done < n;) {
         const int now = std::min(per_launch, n - done);
         PParams p = e->pp;
-        p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = done == 0 ? rs : nullptr;
+        const size_t co = (size_t)done * (size_t)e->seq_stride;
+        p.ctl_steer = st ? st + co : st; p.ctl_thr = th ? th + co : th; p.ctl_brk = br ? br + co : br; p.ctl_reset = done == 0 ? rs : nullptr;
+        p.ctl_stride = e->seq_stride;
         p.synth = synth; p.n_steps = now; p.write_cam = 0; p.step_off = (uint32_t)e->step_count;
         hipLaunchKernelGGL(trs_physics_kernel, dim3((e->n + kPhysBlock / 64 - 1) / (kPhysBlock / 64)), dim3(kPhysBlock), e->lds_p, e->sP, p);
         HIPCHK(hipGetLastError());
@@ -1494,7 +1503,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
-    (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch);
+    (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf);
     if (e->pinned) (void)hipHostFree(e->pinned);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1665,6 +1674,40 @@ TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, c
     if (h_br) HIPCHK(hipMemcpyAsync(e->ctl_brk, h_br, n * 4, hipMemcpyHostToDevice, e->sP));
     if (h_rs) HIPCHK(hipMemcpyAsync(e->ctl_reset, h_rs, n, hipMemcpyHostToDevice, e->sP));
     return trs_step(e, e->ctl_steer, e->ctl_thr, h_br ? e->ctl_brk : nullptr, h_rs ? e->ctl_reset : nullptr, n_steps);
+}
+
+TRS_EXPORT int trs_step_sequence(trs_env* e, const float* d_st, const float* d_th, const float* d_br, const uint8_t* d_rs, int n_steps, int steps_per_launch)
+{
+    if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
+    if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
+    if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
+    HIPCHK(hipSetDevice(e->device));
+    e->seq_stride = e->n;
+    const int rc = e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, steps_per_launch)
+                                 : run_physics_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, steps_per_launch);
+    e->seq_stride = 0;
+    return rc;
+}
+
+TRS_EXPORT int trs_step_sequence_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps, int steps_per_launch)
+{
+    if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
+    if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
+    if (!h_st || !h_th) return fail(TRS_ERR_ARG, "null controls");
+    HIPCHK(hipSetDevice(e->device));
+    const size_t cnt = (size_t)n_steps * (size_t)e->n;
+    if (e->seq_cap < cnt) {
+        HIPCHK(hipStreamSynchronize(e->sP));
+        (void)hipFree(e->seq_buf); e->seq_buf = nullptr; e->seq_cap = 0;
+        HIPCHK(hipMalloc((void**)&e->seq_buf, cnt * 3 * sizeof(float)));
+        e->seq_cap = cnt;
+    }
+    float *ds = e->seq_buf, *dt = ds + cnt, *db = dt + cnt;
+    HIPCHK(hipMemcpyAsync(ds, h_st, cnt * 4, hipMemcpyHostToDevice, e->sP));
+    HIPCHK(hipMemcpyAsync(dt, h_th, cnt * 4, hipMemcpyHostToDevice, e->sP));
+    if (h_br) HIPCHK(hipMemcpyAsync(db, h_br, cnt * 4, hipMemcpyHostToDevice, e->sP));
+    if (h_rs) HIPCHK(hipMemcpyAsync(e->ctl_reset, h_rs, (size_t)e->n, hipMemcpyHostToDevice, e->sP));
+    return trs_step_sequence(e, ds, dt, h_br ? db : nullptr, h_rs ? e->ctl_reset : nullptr, n_steps, steps_per_launch);
 }
 
 TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)

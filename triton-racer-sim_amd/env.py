@@ -132,6 +132,23 @@ class BatchedEnv:
         self.api.check(self.api.step(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
                                      int(n_steps)), "step")
 
+    def step_sequence(self, steering, throttle, brake=None, reset=None, steps_per_launch=8):
+        """Open-loop action sequences: ``steering`` / ``throttle`` / ``brake`` are ``[n_steps, n_envs]`` host arrays, one
+        control set per step (``trs_step_sequence_host``); the call runs ``steps_per_launch`` steps per kernel launch."""
+        st = np.ascontiguousarray(steering, dtype=np.float32)
+        k = st.shape[0]
+        f = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (k, self.n)))
+        st, th = f(st), f(throttle)
+        br = None if brake is None else f(brake)
+        rs = None if reset is None else np.ascontiguousarray(np.broadcast_to(np.asarray(reset, dtype=np.uint8), (self.n,)))
+        self.api.check(self.api.step_sequence_host(self._h, st.ctypes.data, th.ctypes.data, None if br is None else br.ctypes.data,
+                                                   None if rs is None else rs.ctypes.data, int(k), int(steps_per_launch)), "step_sequence_host")
+
+    def step_sequence_device(self, d_steering, d_throttle, d_brake=0, d_reset=0, n_steps=1, steps_per_launch=8):
+        """Same with raw device pointers to ``float32[n_steps, n_envs]`` arrays."""
+        self.api.check(self.api.step_sequence(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
+                                              int(n_steps), int(steps_per_launch)), "step_sequence")
+
     def step_synthetic(self, n_steps=1, steps_per_launch=1):
         self.api.check(self.api.step_synthetic(self._h, int(n_steps), int(steps_per_launch)), "step_synthetic")
 
