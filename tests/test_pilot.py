@@ -151,3 +151,37 @@ def test_break_mode_and_errors(make_env):
         phys = make_env("hip", n_envs=2, render=False)
         phys.pilot_load(make_weights(120, 160))
         phys.step_pilot(1)
+
+
+def test_keras_pilot_component_contract(tmp_path):
+    """HipKerasPilot: KerasPilot's ports / modes / post-processing (keras_pilot.py:17-153) around the GPU network."""
+    from triton_racer_sim_amd.components import HipKerasPilot, PILOT_INPUTS, PILOT_OUTPUTS
+    ws = make_weights(120, 160, seed=4)
+    path = str(tmp_path / "model.npz")
+    np.savez(path, *ws)
+    cfg = {"spd_ctl_threshold": 1.1, "smooth_steering_enabled": True, "smooth_steering_threshold": 0.02}
+    part = HipKerasPilot(cfg, model_path=path, model_type="cnn_2d_speed_control")
+    assert part.step_inputs == PILOT_INPUTS and part.step_outputs == PILOT_OUTPUTS and part.getName() == "Keras Pilot"
+    rng = np.random.default_rng(2)
+    frame = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    assert part.step(None, 3.0, 0.0, 0.0, "ai") == (0.0, 0.0, 0.0)                 # no frame yet (keras_pilot.py:46-47)
+    assert part.step(frame, 3.0, 0.0, 0.0, "human") == (0.0, 0.0, 0.0)             # not an AI mode (:139)
+    raw = part.env.pilot_forward_host(frame[None])[0]
+    got = part.step(frame, 3.0, 0.0, 0.0, "ai_steering")
+    st, thr, brk = pilot_postprocess(raw, 3.0, cfg)
+    st = 1.0 if st > 0.02 else (-1.0 if st < -0.02 else st)                        # smooth steering (:147-153)
+    assert all(isinstance(v, float) for v in got)
+    # dense1 sums its K slices with fp32 atomics: two forward passes agree to ~1e-7 relative, not bit for bit
+    assert abs(got[0] - st) < 1e-6 and abs(got[1] - thr) < 1e-5 and got[2] == brk == 0.0
+    part.onShutdown()
+    brake = HipKerasPilot(dict(cfg, spd_ctl_break=True, smooth_steering_enabled=False), weights=ws, n_cars=3)
+    frames = rng.integers(0, 256, (3, 120, 160, 3), dtype=np.uint8)
+    speeds = np.array([0.0, 6.0, 25.0])
+    s3, t3, b3 = brake.step(frames, speeds, None, None, "ai")
+    raws = brake.env.pilot_forward_host(frames)
+    for i in range(3):
+        want = pilot_postprocess(raws[i], float(speeds[i]), dict(cfg, spd_ctl_break=True))
+        assert abs(s3[i] - want[0]) < 1e-6 and abs(t3[i] - want[1]) < 1e-5 and abs(b3[i] - want[2]) < 1e-5
+    brake.onShutdown()
+    with pytest.raises(ValueError, match="CNN_2D_SPD_CTL"):
+        HipKerasPilot(cfg, weights=ws, model_type="cnn_2d")

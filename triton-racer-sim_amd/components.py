@@ -211,3 +211,76 @@ class BatchedControlMultiplexer(Component):
 
     def getName(self):
         return "Control Multiplexer"
+
+
+PILOT_INPUTS = ["cam/img", "gym/speed", "loc/segment", "gym/cte", "usr/mode"]          # keras_pilot.py:18
+PILOT_OUTPUTS = ["ai/steering", "ai/throttle", "ai/breaking"]
+
+
+class HipKerasPilot(Component):
+    """``KerasPilot`` for ``ModelType.CNN_2D_SPD_CTL`` (reference ``components/keras_pilot.py:17-153``): same ports, same
+    ``spd_ctl_*`` / ``smooth_steering_*`` config keys, same rule "``(0.0, 0.0, 0.0)`` without a frame or outside the two AI
+    modes".  The network (``Keras_2D_CNN.get_model``, ``keras_train.py:127-174``) runs on the GPU in bf16 MFMA
+    convolutions (``trs_pilot_forward_host``); the post-processing (cap, x20, ``calcThrottle`` / ``calcBreak``, smooth
+    steering; ``:78-95``) is the reference's scalar arithmetic on the host.
+
+    ``weights``: the 22 arrays of ``model.get_weights()`` (kernel, bias of conv1..conv7, dense1..dense3, output_layer), or
+    ``model_path``: an ``.npz`` with those arrays in that order (``np.savez(path, *model.get_weights())``) — reading a
+    Keras ``.h5`` needs h5py / TensorFlow, which this image does not have.  Ports may carry one frame (N = 1, the
+    reference's use) or a batch ``uint8[N,H,W,3]`` with per-car speeds; the outputs are then arrays."""
+
+    def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0):
+        mt = getattr(model_type, "value", model_type)
+        if mt != "cnn_2d_speed_control":
+            raise ValueError("HipKerasPilot implements ModelType.CNN_2D_SPD_CTL ('cnn_2d_speed_control') only")
+        Component.__init__(self, inputs=list(PILOT_INPUTS), outputs=list(PILOT_OUTPUTS), threaded=False)
+        self.cfg = dict(cfg or {})
+        if weights is None:
+            if model_path is None:
+                raise ValueError("weights or model_path (.npz of model.get_weights()) is required")
+            with np.load(model_path) as z:
+                weights = [z[k] for k in z.files]
+        self.env = BatchedEnv(n_envs=int(n_cars), track=None, device=device, render=False,
+                              img_h=int(self.cfg.get("img_h", 120)), img_w=int(self.cfg.get("img_w", 160)))
+        self.env.pilot_load(weights)
+        self.speed_control_threshold = float(self.cfg.get("spd_ctl_threshold", 1.1))
+        self.speed_control_break = bool(self.cfg.get("spd_ctl_break", False))
+        self.speed_control_reverse_multiplier = float(self.cfg.get("spd_ctl_reverse_multiplier", 1.0))
+        self.speed_control_break_multiplier = float(self.cfg.get("spd_ctl_break_multiplier", 1.0))
+        self.smooth_steering = bool(self.cfg.get("smooth_steering_enabled", False))
+        self.smooth_steering_threshold = float(self.cfg.get("smooth_steering_threshold", 0.9))
+        self.on = True
+
+    def step(self, *args):
+        from . import control
+        img, mode = args[0], getattr(args[-1], "value", args[-1])
+        if img is None or mode not in ("ai", "ai_steering"):               # keras_pilot.py:46-48,139
+            return 0.0, 0.0, 0.0
+        img = np.asarray(img, dtype=np.uint8)
+        single = img.ndim == 3
+        raw = self.env.pilot_forward_host(img[None] if single else img)    # [n, 2]: steering, speed / 20
+        steering = np.clip(raw[:, 0].astype(np.float64), -1.0, 1.0)        # __cap (:142-145)
+        predicted = raw[:, 1].astype(np.float64) * 20                      # :83
+        real = np.broadcast_to(np.asarray(args[1], dtype=np.float64), predicted.shape)
+        throttle = control.calc_throttle(real, predicted * self.speed_control_threshold, self.speed_control_reverse_multiplier)
+        breaking = np.zeros_like(throttle)
+        if self.speed_control_break:                                       # :88-90
+            throttle = np.where(predicted - real > 0.0, 1.0, 0.0)
+            breaking = control.calc_break(real, predicted * self.speed_control_threshold, self.speed_control_break_multiplier)
+        if self.smooth_steering:                                           # :147-153
+            steering = np.where(steering > self.smooth_steering_threshold, 1.0,
+                                np.where(steering < -self.smooth_steering_threshold, -1.0, steering))
+        if single:
+            return float(steering[0]), float(throttle[0]), float(breaking[0])
+        return steering, throttle, breaking
+
+    def onStart(self):
+        if self.cfg.get("preprocessing_enabled"):
+            print("[WARNING] Image preprocessing is enabled. Autopilot is fed with FILTERED image.")
+
+    def onShutdown(self):
+        self.on = False
+        self.env.close()
+
+    def getName(self):
+        return "Keras Pilot"
