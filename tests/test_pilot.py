@@ -185,3 +185,21 @@ def test_keras_pilot_component_contract(tmp_path):
     brake.onShutdown()
     with pytest.raises(ValueError, match="CNN_2D_SPD_CTL"):
         HipKerasPilot(cfg, weights=ws, model_type="cnn_2d")
+
+
+def test_pilot_is_deterministic(make_env):
+    """No atomics anywhere: the same frames give bit-identical outputs, and two closed loops stay identical step by step."""
+    n = 96
+    ws = make_weights(120, 160, seed=9)
+    a = make_env("hip", n_envs=n, auto_reset=True)
+    b = make_env("hip", n_envs=n, auto_reset=True)
+    for env in (a, b):
+        env.pilot_load(ws)
+        env.step_synthetic(5, 1)
+    frames = a.fetch("img")
+    r1, r2, r3 = a.pilot_forward_host(frames), a.pilot_forward_host(frames), b.pilot_forward_host(frames)
+    assert np.array_equal(r1, r2) and np.array_equal(r1, r3)
+    for env in (a, b):
+        env.step_pilot(25)
+    for name in ("pos_x", "pos_z", "yaw", "speed", "cte", "seg_idx", "ep_return", "img"):
+        assert np.array_equal(a.fetch(name), b.fetch(name)), name

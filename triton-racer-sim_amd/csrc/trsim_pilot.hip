@@ -61,7 +61,7 @@ struct ConvParams {
     int G, G_pad, M;           // granules (even-padded), GEMM rows = N*OH*OW
     int gchunk;                // granules per LDS stage (even)
     int relu, out_f32, in_px_bytes;   // in_px_bytes: bytes per input pixel (CIN*2, conv1: 3)
-    int ksplit;                // > 1: blockIdx.y owns a slice of the granules and adds its partial sums atomically (fp32 out, no ReLU)
+    int ksplit;                // > 1: blockIdx.y owns a slice of the granules and writes its partial sums to slab blockIdx.y of `out` (fp32 [ksplit][M][COUT], no ReLU)
     int nt_out;                // non-temporal activation stores (outputs far larger than L2; measured: conv1 86 -> 80 us, small layers lose)
     int KH, KW, run_pad, cg, span_nl;   // span kernel: kernel rows, granules per kernel row (padded), granules per pixel, load instructions per kernel row
 };
@@ -197,7 +197,10 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
             const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (row >= p.M) continue;
             float v = acc[nb][i];
-            if (p.ksplit > 1) { atomicAdd(&static_cast<float*>(p.out)[(size_t)row * p.COUT + col], v); continue; }
+            if (p.ksplit > 1) {   // this K slice's partial sums go to its own slab; the consumer adds the slabs in slice order (deterministic, no atomics)
+                static_cast<float*>(p.out)[((size_t)blockIdx.y * p.M + row) * p.COUT + col] = v;
+                continue;
+            }
             if (p.relu) v = v > 0.0f ? v : 0.0f;
             if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
             else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2bf(v);
@@ -588,7 +591,8 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
 
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
 struct TailParams {
-    const float* h1;           // [n][100] dense1 output (after ReLU), fp32
+    const float* h1;           // dense1 output before ReLU, fp32: h1_slices slabs of [n][100] (split-K partial sums, added here in slice order)
+    int h1_slices; size_t h1_stride;
     const float *w2, *b2, *w3, *b3, *w4, *b4;    // Keras layouts [IN][OUT]
     float* raw_out;            // [n][2] or nullptr
     const float* speed;        // 'gym/speed' or nullptr (no post-processing)
@@ -605,7 +609,20 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     if (i >= p.n) return;
-    for (int k = lane; k < 100; k += 64) { const float x = p.h1[(size_t)i * 100 + k]; s1[wv][k] = x > 0.f ? x : 0.f; }   // dense1's ReLU
+    for (int k = lane; k < 100; k += 64) {
+        float x = 0.0f;                                                     // fixed order: run-to-run identical; eight loads in flight
+        const float* src = p.h1 + (size_t)i * 100 + k;
+        int sl = 0;
+        for (; sl + 8 <= p.h1_slices; sl += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(sl + q) * p.h1_stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x += v[q];
+        }
+        for (; sl < p.h1_slices; ++sl) x += src[(size_t)sl * p.h1_stride];
+        s1[wv][k] = x > 0.f ? x : 0.f;                                      // dense1's ReLU
+    }
     __builtin_amdgcn_wave_barrier();
     if (lane < 50) { float s = p.b2[lane]; for (int k = 0; k < 100; ++k) s = fmaf(s1[wv][k], p.w2[k * 50 + lane], s); s2[wv][lane] = s > 0.f ? s : 0.f; }
     __builtin_amdgcn_wave_barrier();
@@ -669,7 +686,8 @@ struct PilotCtx {
     float *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr, *w4 = nullptr, *b4 = nullptr;
     float* raw = nullptr;                 // [n_cap][2]
     uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
-    int last_n = 0;
+    int last_n = 0, last_slices = 1;
+    void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
 };
 
 unsigned short host_f2bf(float f)
@@ -685,7 +703,7 @@ void free_ctx(PilotCtx* c)
     for (auto& l : c->L) { (void)hipFree(l.w); (void)hipFree(l.bias); (void)hipFree(l.goff); }
     for (auto& a : c->act) (void)hipFree(a);
     (void)hipFree(c->w2); (void)hipFree(c->b2); (void)hipFree(c->w3); (void)hipFree(c->b3); (void)hipFree(c->w4); (void)hipFree(c->b4);
-    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames);
+    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab);
     delete c;
 }
 
@@ -695,6 +713,19 @@ int upload(T** dst, const std::vector<T>& v)
     HIPCHK(hipMalloc((void**)dst, v.size() * sizeof(T)));
     HIPCHK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return TRS_OK;
+}
+
+// split-K only as far as it takes to fill the chip about twice (every extra slice is another slab for the tail kernel to add;
+// dense1 at 240x320: 551 one-chunk slices x 4 row tiles spent 166 us), and never an empty slice
+int split_k_slices(const ConvLayer& l, int n_img, int cu_count)
+{
+    if (l.ksplit <= 1) return 1;
+    const int M = n_img * l.OH * l.OW, grid = (M + kRowsPerWg - 1) / kRowsPerWg;
+    int want = std::max(1, (2 * cu_count + grid - 1) / grid);
+    if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
+    const int ks = std::min(l.ksplit, want);
+    const int nchunks = (l.G_pad + l.gchunk - 1) / l.gchunk, cps = (nchunks + ks - 1) / ks;
+    return (nchunks + cps - 1) / cps;
 }
 
 int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count)
@@ -748,16 +779,8 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         return TRS_OK;
     }
     const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
-    // split-K only as far as it takes to fill the chip about twice: every extra slice adds a full tile of fp32 atomics
-    // (dense1 at 240x320: 551 one-chunk slices x 4 row tiles spent 166 us mostly in atomics)
-    int ks = l.ksplit;
-    if (ks > 1) {
-        int want = std::max(1, (2 * cu_count + grid - 1) / grid);
-        if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
-        ks = std::min(ks, want);
-    }
+    const int ks = split_k_slices(l, n_img, cu_count);                     // > 1: `out` is the slab buffer [ks][M][COUT]
     p.ksplit = ks;
-    if (ks > 1) HIPCHK(hipMemsetAsync(out, 0, (size_t)p.M * l.COUT * sizeof(float), s));   // partial sums are added atomically
     const int nb = l.COUT_PAD / 32;
 #define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, ks), dim3(kConvBlock), l.lds, s, p)
     if (l.u8in) LAUNCH(1, true);
@@ -774,7 +797,19 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
     const void* in = d_frames;
     size_t in_bytes = (size_t)n * c->H * c->W * 3;
     for (int i = 0; i < 8; ++i) {
-        int rc = launch_conv(c->L[i], in, in_bytes, c->act[i], n, v.stream, c->cu_count);
+        void* out = c->act[i];
+        if (i == 7) {                                                       // dense1: one fp32 slab per K slice, added in order by the tail kernel
+            c->last_slices = split_k_slices(c->L[7], n, c->cu_count);
+            const size_t need = (size_t)c->last_slices * n * c->act_elems[7] * sizeof(float);
+            if (c->slab_bytes < need) {
+                HIPCHK(hipStreamSynchronize(v.stream));
+                (void)hipFree(c->slab); c->slab = nullptr; c->slab_bytes = 0;
+                HIPCHK(hipMalloc(&c->slab, need));
+                c->slab_bytes = need;
+            }
+            out = c->slab;
+        }
+        int rc = launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
         if (rc) return rc;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
@@ -786,7 +821,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
 int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act)
 {
     TailParams t{};
-    t.h1 = static_cast<const float*>(c->act[7]);
+    t.h1 = static_cast<const float*>(c->slab); t.h1_slices = c->last_slices; t.h1_stride = (size_t)n * c->act_elems[7];
     t.w2 = c->w2; t.b2 = c->b2; t.w3 = c->w3; t.b3 = c->b3; t.w4 = c->w4; t.b4 = c->b4;
     t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
     if (act) {
@@ -990,9 +1025,14 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
     HIPCHK(hipSetDevice(v.device));
     HIPCHK(hipStreamSynchronize(v.stream));
-    if (c->L[layer].out_f32) {
-        HIPCHK(hipMemcpy(h_dst, c->act[layer], total * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < total; ++i) h_dst[i] = h_dst[i] > 0.0f ? h_dst[i] : 0.0f;    // dense1's ReLU lives in the tail kernel
+    if (c->L[layer].out_f32) {                                              // dense1: add the K-slice slabs in slice order, then the ReLU (both live in the tail kernel)
+        std::vector<float> part(total);
+        for (size_t i = 0; i < total; ++i) h_dst[i] = 0.0f;
+        for (int sl = 0; sl < c->last_slices; ++sl) {
+            HIPCHK(hipMemcpy(part.data(), static_cast<const float*>(c->slab) + (size_t)sl * total, total * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < total; ++i) h_dst[i] += part[i];
+        }
+        for (size_t i = 0; i < total; ++i) h_dst[i] = h_dst[i] > 0.0f ? h_dst[i] : 0.0f;
         return TRS_OK;
     }
     std::vector<unsigned short> tmp(total);
