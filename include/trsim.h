@@ -90,7 +90,10 @@ enum {
     TRS_F_STEER_FILT,/* float[n_envs] synthetic low-pass state */
     TRS_F_STATS,     /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [8..] diagnostics */
     TRS_F_DEPTH,     /* float[n_envs][img_h][img_w] */
-    TRS_F_ROWDEPTH   /* float[img_h] */
+    TRS_F_ROWDEPTH,  /* float[img_h] */
+    TRS_F_CTL_STEER, /* float[n_envs]: the handle's own control arrays — what trs_step_host uploaded or the pilot of  */
+    TRS_F_CTL_THR,   /*   trs_step_pilot produced last ('ai/steering', 'ai/throttle', 'ai/breaking' of KerasPilot.step, */
+    TRS_F_CTL_BRK    /*   keras_pilot.py:92-95)                                                                       */
 };
 
 typedef struct trs_map_info {

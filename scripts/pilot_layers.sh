@@ -9,7 +9,7 @@ echo "== $tag $*"
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("gpurun_out/prof_pl_$tag/**/*kernel_trace.csv",recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if "conv_" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
+rows=[r for r in csv.DictReader(open(f)) if "trs_conv" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 steps=len([r for r in rows if "tail" in r["Kernel_Name"]])
 # position of a launch inside its step identifies the layer
@@ -20,12 +20,14 @@ for r in rows:
         seq.append(cur); cur=[]
 seq=[s for s in seq if len(s)==len(seq[-1])]
 names=["env step","conv1","conv2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
+fused=["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
 tot=0
 for j in range(len(seq[-1])):
     d=[int(s[j]["End_Timestamp"])-int(s[j]["Start_Timestamp"]) for s in seq]
     r=seq[-1][j]
-    kind="resident" if "resident" in r["Kernel_Name"] else "chunked" if "conv_mfma" in r["Kernel_Name"] else "-"
-    nm=names[j] if len(seq[-1])==len(names) else str(j)
+    kn=r["Kernel_Name"]
+    kind="fused" if "conv12" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
+    nm=names[j] if len(seq[-1])==len(names) else (fused[j] if len(seq[-1])==len(fused) else str(j))
     tot+=sum(d)/len(d)
     print(f"  {nm:9s} {kind:8s} grid={r['Grid_Size_X']:>8s}x{r['Grid_Size_Y']} wg={r['Workgroup_Size_X']:>4s} lds={r.get('LDS_Block_Size','?'):>7s}  mean {sum(d)/len(d)/1e3:8.1f} us")
 print(f"  all kernels per step: {tot/1e3:.1f} us   (steps seen: {len(seq)})")

@@ -203,3 +203,65 @@ def test_pilot_is_deterministic(make_env):
         env.step_pilot(25)
     for name in ("pos_x", "pos_z", "yaw", "speed", "cte", "seg_idx", "ep_return", "img"):
         assert np.array_equal(a.fetch(name), b.fetch(name)), name
+
+
+def test_closed_loop_is_unaffected_by_another_stream(make_env):
+    """The pilot loop beside a second handle that keeps its own loop running from a thread (workgroups of other kernels
+    share the CUs with the step kernel) gives the states, controls and frames of the same loop run alone.  A race screen:
+    an in-place packed multiply in the rasteriser failed it within ~100 steps (scripts/coresidency_probe.py)."""
+    import threading
+    n, steps = 96, 300
+    ws = make_weights(120, 160, seed=9)
+
+    def fresh():
+        env = make_env("hip", n_envs=n, auto_reset=True)
+        env.pilot_load(ws)
+        env.step_synthetic(5, 1)
+        return env
+
+    names = ("pos_x", "pos_z", "yaw", "speed", "ctl_steer", "ctl_thr", "img")
+    alone = fresh()
+    want = []
+    for _ in range(steps // 4):
+        alone.step_pilot(4)
+        want.append([alone.fetch(f) for f in names])
+    victim, other = fresh(), fresh()
+    stop = threading.Event()
+
+    def busy():
+        while not stop.is_set():
+            other.step_pilot(8)
+            other.sync()
+
+    t = threading.Thread(target=busy)
+    t.start()
+    try:
+        for k in range(steps // 4):
+            victim.step_pilot(4)
+            for f, w in zip(names, want[k]):
+                assert np.array_equal(victim.fetch(f), w), (f, 4 * (k + 1))
+    finally:
+        stop.set()
+        t.join()
+
+
+@pytest.mark.parametrize("size", [(120, 160), (240, 320), (100, 132)])
+def test_fused_head_is_bit_identical_to_the_two_layers(make_env, size, monkeypatch):
+    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels: the same bf16 values go
+    into the same MFMA order, so conv2's output and everything after it are bit-identical."""
+    h, w = size
+    n = 21
+    ws = make_weights(h, w, seed=3)
+    env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+    env.pilot_load(ws)
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    oh1, ow1 = (h - 5) // 2 + 1, (w - 5) // 2 + 1
+    oh2, ow2 = (oh1 - 5) // 2 + 1, (ow1 - 5) // 2 + 1
+    fused_out = env.pilot_forward_host(frames)
+    fused_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
+    monkeypatch.setenv("TRS_PILOT_NO_FUSE", "1")
+    plain_out = env.pilot_forward_host(frames)
+    plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
+    assert np.array_equal(fused_l1, plain_l1)
+    assert np.array_equal(fused_out, plain_out)

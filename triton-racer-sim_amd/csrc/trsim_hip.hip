@@ -472,6 +472,22 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
+// (dx, dz) of a row as two scalar multiplies.  The packed form (v_pk_mul_f32 with the row-table register pair as source AND
+// destination) returned +-0 for dx in lanes 48..63 of one row pass now and then, but only while workgroups of other kernels
+// shared the CU (scripts/det_probe*.py: 1-3 % of the steps beside a pilot loop on another stream; never alone).  Same
+// IEEE products, so results are unchanged.
+__device__ __forceinline__ f2v ray_step(f2v kk2, f2v cns)
+{
+#ifdef TRS_PACKED_RAY_STEP
+    return kk2 * cns;
+#else
+    float dx, dz;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(dx) : "v"(kk2.x), "v"(cns.x));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(dz) : "v"(kk2.y), "v"(cns.y));
+    return f2v{dx, dz};
+#endif
+}
+
 template <bool DEPTH, bool DYN>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 const f2v rt = lrow[v];
                 const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
                 const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
-                const f2v d = kk2 * cns;
+                const f2v d = ray_step(kk2, cns);
                 auto cls_of = [&](f2v uf) -> unsigned {
                     const f2v g = __builtin_elementwise_fma(uf, d, a);
                     const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
@@ -797,7 +813,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
             const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
             const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
-            const f2v d = kk2 * cns;                                           // (dx, dz) = (k*c, -(k*s))
+            const f2v d = ray_step(kk2, cns);                                  // (dx, dz) = (k*c, -(k*s))
             auto shade = [&](f2v uf) -> uint32_t {
                 const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
                 const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
@@ -1754,6 +1770,9 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_EP_LEN: src = k.ep_len; need = n * 4; break;
     case TRS_F_DONE: src = k.done; need = n; break;
     case TRS_F_STEER_FILT: src = k.steer_filt; need = n * 4; break;
+    case TRS_F_CTL_STEER: src = e->ctl_steer; need = n * 4; break;
+    case TRS_F_CTL_THR: src = e->ctl_thr; need = n * 4; break;
+    case TRS_F_CTL_BRK: src = e->ctl_brk; need = n * 4; break;
     case TRS_F_STATS: src = e->stats; need = 64 * sizeof(unsigned long long); break;
     case TRS_F_DEPTH: src = (e->cfg.render && e->cfg.depth) ? e->depth[(e->step_count + 1) & 1] : nullptr; need = n * e->H * e->W * 4; break;
     case TRS_F_ROWDEPTH: if (e->track_loaded) { src = e->blob_r + e->rp.off_depth; need = (size_t)e->H * 4; } break;
@@ -2262,3 +2281,52 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
+
+#ifdef TRS_DEBUG_PROBES
+// Debug build only (scripts/det_probe.py; never part of libtrsim.so): fill the whole LDS of every CU with a pattern on the
+// handle's stream, so that a kernel reading LDS bytes it has not (yet) written shows a wrong result instead of silently
+// re-reading what its own previous launch left there.
+__global__ __launch_bounds__(1024) void trs_debug_poison_kernel(unsigned pattern, int bytes, int spin)
+{
+    u4v* d = reinterpret_cast<u4v*>(smem);
+    for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = (u4v)(pattern);
+    __syncthreads();
+    const long long t0 = clock64();
+    while (clock64() - t0 < spin) __builtin_amdgcn_s_sleep(8);            // stay resident so that every CU gets a workgroup
+}
+
+TRS_EXPORT int trs_debug_poison_lds(trs_env* e, unsigned pattern, int bytes)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_debug_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipLaunchKernelGGL(trs_debug_poison_kernel, dim3(512), dim3(1024), bytes, e->sP, pattern, bytes, 20000);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
+// ... and: occupy a slice of every CU's LDS from another stream for `cycles` clocks (touch = 1: keep rewriting that slice), so
+// that workgroups launched meanwhile get an LDS allocation that does not start at the CU's LDS address 0.
+__global__ __launch_bounds__(64) void trs_debug_spin_kernel(int bytes, long long cycles, int touch)
+{
+    u4v* d = reinterpret_cast<u4v*>(smem);
+    const long long t0 = clock64();
+    unsigned k = 0;
+    while (clock64() - t0 < cycles) {
+        if (touch) for (int i = threadIdx.x; i < bytes / 16; i += 64) d[i] = (u4v)(0xDEAD0000u + k++);
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+TRS_EXPORT int trs_debug_spin(trs_env* e, int wgs, int bytes, long long cycles, int touch)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    static hipStream_t side = nullptr;
+    HIPCHK(hipSetDevice(e->device));
+    if (!side) HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_debug_spin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipLaunchKernelGGL(trs_debug_spin_kernel, dim3(wgs), dim3(64), bytes, side, bytes, cycles, touch);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+#endif

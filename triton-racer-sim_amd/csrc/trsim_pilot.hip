@@ -227,8 +227,8 @@ __device__ __forceinline__ int window_base(const ConvParams& p, int n0, int rem0
 // lookup per lane: 31 us of conv2's 131).  Stage layout: [pixel][16-B chunk ^ f(pixel)], f spreads the 16 lanes of a
 // ds_write_b64 / ds_read_b128 group over the bank row.  NB = 2 (128 B per pixel) goes in two passes of 16 pixels.
 template <int NB>
-__device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int tile, int cbase, int lane)
-{
+__device__ __forceinline__ void store_tile_at(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int m_base, int m_limit, int cbase, int lane)
+{   // the tile's 32 pixels are output pixels m_base .. m_base + 31 (consecutive in memory); those >= m_limit are not stored
     constexpr int CR = NB * 4;                                              // 16-B chunks per pixel row of this slice
     constexpr int PP = 128 / CR;                                            // pixels per pass (2 KB stage)
     const int r = lane & 31, h = lane >> 5;
@@ -252,16 +252,16 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
             }
         }
         const int total = PP * crv;                                         // 16-B chunks to write out in this pass
-        const size_t pass_byte0 = (size_t)(tile * 32 + pass * PP) * p.COUT * 2;
+        const size_t pass_byte0 = (size_t)(m_base + pass * PP) * p.COUT * 2;
         const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out) + pass_byte0, 0, PP * p.COUT * 2, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int g = i * 64 + lane;
             if (g < total) {
                 const int pix = (int)(((unsigned)g * magic) >> 16), c = g - pix * crv;
-                const int m = tile * 32 + pass * PP + pix;
+                const int m = m_base + pass * PP + pix;
                 const int f = NB == 1 ? (pix >> 1) & 3 : pix & 7;
-                if (m < p.M) {
+                if (m < m_limit) {
                     const u4v v = stage[pix * CR + (c ^ f)];
                     // a buffer store so that the cache policy can be chosen per layer (immediate aux bits): activations far
                     // larger than L2 leave non-temporally and do not displace what the next layer is about to read
@@ -273,6 +273,12 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
             }
         }
     }
+}
+
+template <int NB>
+__device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int tile, int cbase, int lane)
+{
+    store_tile_at<NB>(stage, acc, lbias, p, tile * 32, p.M, cbase, lane);
 }
 
 // conv1 (uint8 frame in, kPf = 3 trips = the whole K of 5 kernel rows x 16 bytes): resident weights, persistent workgroups,
@@ -589,6 +595,122 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
     }
 }
 
+// conv1 -> conv2 fused: conv1's activation (217 KB per 120x160 frame, the largest tensor of the network: 222 MB per 1024
+// frames, written once and read once) never leaves the CU.  A workgroup takes a band of R2 conv2 output rows of one
+// frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + bf16 rounding as the unfused
+// layer, so conv2's result is bit-identical), and runs conv2 on that tile with its fragments read by ds_read_b128.
+// Neighbouring bands recompute 3 conv1 rows each ((2 R2 + 3) / (2 R2) of the conv1 work).
+struct Fuse12Params {
+    const uint8_t* frames; int frames_bytes;
+    const u4v* w1; const float* b1; const int* goff1;      // conv1: [12][32] granules, [32], [12]
+    const u4v* w2;                                          // conv2: [80][32] granules (kernel rows padded 15 -> 16)
+    ConvParams c2;                                          // conv2's output side (out, COUT, relu, nt_out, bias)
+    int N, IH, IW, OH1, OW1, OH2, OW2, R2, bands;
+    int off_w2, off_b, off_goff, off_tile, off_stage;       // LDS layout
+    int tile_bytes;
+};
+
+__global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    u4v* lw1 = reinterpret_cast<u4v*>(psmem);                              // [12][32]
+    u4v* lw2 = reinterpret_cast<u4v*>(psmem + q.off_w2);                   // [80][32]
+    float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
+    float4* lb2 = lb1 + 8;                                                 // [8]
+    int* lgoff1 = reinterpret_cast<int*>(psmem + q.off_goff);              // [12]
+    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] bf16 (+ padding)
+    u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + wave * 128;
+    for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
+    for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
+    for (int i = tid; i < 8; i += blockDim.x) { lb1[i] = *reinterpret_cast<const float4*>(q.b1 + 4 * i); lb2[i] = *reinterpret_cast<const float4*>(q.c2.bias + 4 * i); }
+    for (int i = tid; i < 12; i += blockDim.x) lgoff1[i] = q.goff1[i];
+    for (int i = tid; i < q.tile_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(tile1)[i] = (u4v)(0u);   // never multiply an uninitialised bit pattern by a zero weight
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
+    const float inv_ow1 = 1.0f / (float)q.OW1, inv_ow2 = 1.0f / (float)q.OW2;
+    int goffs[6];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) goffs[s6] = lgoff1[min(2 * s6 + h, 11)];
+    auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
+        qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
+        if (rm < 0) { --qt; rm += d; } else if (rm >= d) { ++qt; rm -= d; }
+    };
+    for (int wt = blockIdx.x; wt < q.N * q.bands; wt += gridDim.x) {
+        const int n = wt / q.bands, b = wt - n * q.bands;
+        const int y2_0 = b * q.R2, r2 = min(q.R2, q.OH2 - y2_0);
+        const int y1_0 = 2 * y2_0, r1 = 2 * (r2 - 1) + 5;
+        // ---- phase 1: conv1 rows y1_0 .. y1_0 + r1 - 1 of frame n -> LDS tile (bf16 NHWC) ----
+        const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
+        for (int t1 = wave; t1 < ntile1; t1 += nwaves) {                    // (requesting the next tile's dwords ahead measured 6 % slower)
+            const int pp = min(t1 * 32 + r, npx1 - 1);
+            int yl, x;
+            divmod(pp, q.OW1, inv_ow1, yl, x);
+            const int fbase = ((n * q.IH + (y1_0 + yl) * 2) * q.IW + x * 2) * 3;
+            bf16x8 xf[6];
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int addr = fbase + goffs[s6], al = addr & ~3;
+                const unsigned sh = (unsigned)addr & 3u;
+                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
+                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
+                const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
+                const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                auto pair = [](unsigned w, int j) -> unsigned {
+                    const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
+                    return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                };
+                const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
+                xf[s6] = __builtin_bit_cast(bf16x8, packed);
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, lw1[(2 * s6 + h) * 32 + r]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xf[s6], acc, 0, 0, 0);
+            }
+            if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)pp * 48);
+#pragma unroll
+                for (int qd = 0; qd < 3; ++qd) {
+                    const float4 bb = lb1[2 * qd + h];
+                    float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    dst[2 * qd + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: conv2 rows y2_0 .. y2_0 + r2 - 1 from the tile ----
+        const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
+        const int m0 = (n * q.OH2 + y2_0) * q.OW2;                          // first output pixel of the band (consecutive in memory)
+        for (int t2 = wave; t2 < ntile2; t2 += nwaves) {
+            const int mm = min(t2 * 32 + r, npx2 - 1);
+            int yl2, x2;
+            divmod(mm, q.OW2, inv_ow2, yl2, x2);
+            const unsigned char* abase = tile1 + (size_t)((2 * yl2) * q.OW1 + 2 * x2) * 48 + h * 16;
+            f32x16 acc2[1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
+            for (int kh = 0; kh < 5; ++kh) {
+                const unsigned char* arow = abase + (size_t)kh * q.OW1 * 48;
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
+                    const bf16x8 w = __builtin_bit_cast(bf16x8, lw2[(kh * 16 + t + h) * 32 + r]);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
+                }
+            }
+            store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
+        }
+        __syncthreads();                                                    // the tile is rewritten by the next band
+    }
+}
+
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
 struct TailParams {
     const float* h1;           // dense1 output before ReLU, fp32: h1_slices slabs of [n][100] (split-K partial sums, added here in slice order)
@@ -687,6 +809,9 @@ struct PilotCtx {
     float* raw = nullptr;                 // [n_cap][2]
     uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
     int last_n = 0, last_slices = 1;
+    bool no_fuse = false;
+    bool fuse12 = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
+    const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
 };
 
@@ -796,7 +921,23 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
 {
     const void* in = d_frames;
     size_t in_bytes = (size_t)n * c->H * c->W * 3;
-    for (int i = 0; i < 8; ++i) {
+    int first = 0;
+    c->last_frames = d_frames; c->act0_valid = false;
+    if (c->fuse12 && !c->no_fuse) {
+        if (in_bytes > 0x7FFFFFFFull) return trs_internal_fail(TRS_ERR_LIMIT, "frames larger than 2 GiB: lower the batch");
+        Fuse12Params q = c->fuse;
+        q.frames = d_frames; q.frames_bytes = (int)in_bytes; q.N = n;
+        q.c2.out = c->act[1]; q.c2.M = n * c->L[1].OH * c->L[1].OW;
+        q.c2.nt_out = 0;
+        const int grid = std::max(1, std::min(n * q.bands, c->cu_count));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+        hipLaunchKernelGGL(trs_conv12_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+        HIPCHK(hipGetLastError());
+        in = c->act[1];
+        in_bytes = (size_t)n * c->act_elems[1] * 2;
+        first = 2;
+    }
+    for (int i = first; i < 8; ++i) {
         void* out = c->act[i];
         if (i == 7) {                                                       // dense1: one fp32 slab per K slice, added in order by the tail kernel
             c->last_slices = split_k_slices(c->L[7], n, c->cu_count);
@@ -811,6 +952,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         }
         int rc = launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
         if (rc) return rc;
+        if (i == 0) c->act0_valid = true;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
     }
@@ -963,6 +1105,28 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     if (!rc) rc = up(&c->w3, arr[18], 50 * 25); if (!rc) rc = up(&c->b3, arr[19], 25);
     if (!rc) rc = up(&c->w4, arr[20], 25 * 2); if (!rc) rc = up(&c->b4, arr[21], 2);
     if (rc) { free_ctx(c); return rc; }
+    {   // conv1 -> conv2 fusion: needs the 5x5/2 + 5x5/2 head of Keras_2D_CNN and an LDS tile of 2 R2 + 3 conv1 rows
+        const ConvLayer& l0 = c->L[0]; const ConvLayer& l1 = c->L[1];
+        Fuse12Params& q = c->fuse;
+        q = Fuse12Params{};
+        q.w1 = l0.w; q.b1 = l0.bias; q.goff1 = l0.goff; q.w2 = l1.w;
+        q.c2 = ConvParams{};
+        q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1;
+        q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
+        const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
+        int want_r2 = 6;                                                  // measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
+        if (const char* e = std::getenv("TRS_PILOT_FUSE_R2")) want_r2 = std::max(1, std::atoi(e));
+        c->fuse12 = false; c->no_fuse = std::getenv("TRS_PILOT_NO_FUSE") != nullptr;
+        for (int r2 = std::min(want_r2, l1.OH); shape_ok && r2 >= 1; --r2) {
+            int off = 12 * 32 * 16;
+            q.off_w2 = off; off += 80 * 32 * 16;
+            q.off_b = off; off += 16 * 16;
+            q.off_goff = off; off += 64;
+            q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * l0.OW * 48 + 64) + 15) & ~15; off += q.tile_bytes;
+            q.off_stage = off; off += 16 * 2048;
+            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
+        }
+    }
     HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
     for (const ConvLayer& l : c->L) {
         const int nb = l.COUT_PAD / 32;
@@ -1024,6 +1188,11 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     const size_t total = (size_t)c->last_n * c->act_elems[layer];
     if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
     HIPCHK(hipSetDevice(v.device));
+    if (layer == 0 && !c->act0_valid) {                                     // the fused head never wrote conv1's activation: run the unfused conv1 now
+        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count);
+        if (rc) return rc;
+        c->act0_valid = true;
+    }
     HIPCHK(hipStreamSynchronize(v.stream));
     if (c->L[layer].out_f32) {                                              // dense1: add the K-slice slabs in slice order, then the ReLU (both live in the tail kernel)
         std::vector<float> part(total);

@@ -21,6 +21,7 @@ _FIELD_DTYPES = {
     "cte": np.float32, "yaw": np.float32, "vel": np.float32, "seg_idx": np.int32, "ep_return": np.float32,
     "last_return": np.float32, "ep_len": np.int32, "done": np.uint8, "map": np.uint32, "rowtab": np.float32,
     "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32, "stats": np.uint64, "depth": np.float32, "rowdepth": np.float32,
+    "ctl_steer": np.float32, "ctl_thr": np.float32, "ctl_brk": np.float32,
 }
 
 
