@@ -133,3 +133,17 @@ def test_batched_writer_and_loader_walk(tmp_path):
     import pytest
     with pytest.raises(FileNotFoundError):
         load_records(str(tmp_path / "nope"))
+
+
+def test_keras_weight_files(tmp_path):
+    """`.npz` of model.get_weights() loads in order; a Keras `.h5` needs h5py and says so when it is missing."""
+    from triton_racer_sim_amd.components import load_keras_weights
+    arrs = [np.full((2, 3), 1.5, np.float32), np.arange(3, dtype=np.float32), np.zeros((3, 1), np.float32)]
+    np.savez(tmp_path / "m.npz", *arrs)
+    got = load_keras_weights(str(tmp_path / "m.npz"))
+    assert len(got) == 3 and all(np.array_equal(a, b) for a, b in zip(arrs, got))
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            load_keras_weights(str(tmp_path / "m.h5"))

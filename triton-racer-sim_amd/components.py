@@ -217,6 +217,30 @@ PILOT_INPUTS = ["cam/img", "gym/speed", "loc/segment", "gym/cte", "usr/mode"]   
 PILOT_OUTPUTS = ["ai/steering", "ai/throttle", "ai/breaking"]
 
 
+def load_keras_weights(path):
+    """The arrays of ``model.get_weights()`` from an ``.npz`` (``np.savez(path, *model.get_weights())``) or, where h5py is
+    installed (it is wherever the reference's TensorFlow is; not in this image), from the Keras HDF5 file the reference
+    trains and loads (``keras_train.py:407``, ``keras_pilot.py:26``): layers in ``layer_names`` order, each layer's
+    arrays in ``weight_names`` order — the order ``get_weights()`` uses."""
+    if str(path).endswith(".npz"):
+        with np.load(path) as z:
+            return [z[k] for k in z.files]
+    try:
+        import h5py
+    except ImportError as exc:
+        raise RuntimeError(f"{path}: reading a Keras HDF5 model needs h5py; convert once with "
+                           "np.savez('model.npz', *model.get_weights())") from exc
+    out = []
+    with h5py.File(path, "r") as f:
+        g = f["model_weights"] if "model_weights" in f else f
+        for layer in g.attrs["layer_names"]:
+            layer = layer.decode() if isinstance(layer, bytes) else layer
+            for name in g[layer].attrs["weight_names"]:
+                name = name.decode() if isinstance(name, bytes) else name
+                out.append(np.asarray(g[layer][name], dtype=np.float32))
+    return out
+
+
 class HipKerasPilot(Component):
     """``KerasPilot`` for ``ModelType.CNN_2D_SPD_CTL`` (reference ``components/keras_pilot.py:17-153``): same ports, same
     ``spd_ctl_*`` / ``smooth_steering_*`` config keys, same rule "``(0.0, 0.0, 0.0)`` without a frame or outside the two AI
@@ -225,8 +249,8 @@ class HipKerasPilot(Component):
     steering; ``:78-95``) is the reference's scalar arithmetic on the host.
 
     ``weights``: the 22 arrays of ``model.get_weights()`` (kernel, bias of conv1..conv7, dense1..dense3, output_layer), or
-    ``model_path``: an ``.npz`` with those arrays in that order (``np.savez(path, *model.get_weights())``) — reading a
-    Keras ``.h5`` needs h5py / TensorFlow, which this image does not have.  Ports may carry one frame (N = 1, the
+    ``model_path``: an ``.npz`` with those arrays in that order (``np.savez(path, *model.get_weights())``) or the Keras
+    ``.h5`` itself where h5py is installed (``load_keras_weights``).  Ports may carry one frame (N = 1, the
     reference's use) or a batch ``uint8[N,H,W,3]`` with per-car speeds; the outputs are then arrays."""
 
     def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0):
@@ -237,9 +261,8 @@ class HipKerasPilot(Component):
         self.cfg = dict(cfg or {})
         if weights is None:
             if model_path is None:
-                raise ValueError("weights or model_path (.npz of model.get_weights()) is required")
-            with np.load(model_path) as z:
-                weights = [z[k] for k in z.files]
+                raise ValueError("weights or model_path (.npz of model.get_weights(), or the Keras .h5) is required")
+            weights = load_keras_weights(model_path)
         self.env = BatchedEnv(n_envs=int(n_cars), track=None, device=device, render=False,
                               img_h=int(self.cfg.get("img_h", 120)), img_w=int(self.cfg.get("img_w", 160)))
         self.env.pilot_load(weights)
