@@ -600,6 +600,9 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
 // frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + bf16 rounding as the unfused
 // layer, so conv2's result is bit-identical), and runs conv2 on that tile with its fragments read by ds_read_b128.
 // Neighbouring bands recompute 3 conv1 rows each ((2 R2 + 3) / (2 R2) of the conv1 work).
+#ifndef TRS_FUSE_ABLATE
+#define TRS_FUSE_ABLATE 0
+#endif
 struct Fuse12Params {
     const uint8_t* frames; int frames_bytes;
     const u4v* w1; const float* b1; const int* goff1;      // conv1: [12][32] granules, [32], [12]
@@ -643,6 +646,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
         const int y1_0 = 2 * y2_0, r1 = 2 * (r2 - 1) + 5;
         // ---- phase 1: conv1 rows y1_0 .. y1_0 + r1 - 1 of frame n -> LDS tile (bf16 NHWC) ----
         const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
+#if TRS_FUSE_ABLATE != 1   /* diagnostic build 1: no conv1 phase */
         for (int t1 = wave; t1 < ntile1; t1 += nwaves) {                    // (requesting the next tile's dwords ahead measured 6 % slower)
             const int pp = min(t1 * 32 + r, npx1 - 1);
             int yl, x;
@@ -684,10 +688,12 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
                 }
             }
         }
+#endif
         __syncthreads();
         // ---- phase 2: conv2 rows y2_0 .. y2_0 + r2 - 1 from the tile ----
         const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
         const int m0 = (n * q.OH2 + y2_0) * q.OW2;                          // first output pixel of the band (consecutive in memory)
+#if TRS_FUSE_ABLATE != 2   /* diagnostic build 2: no conv2 phase */
         for (int t2 = wave; t2 < ntile2; t2 += nwaves) {
             const int mm = min(t2 * 32 + r, npx2 - 1);
             int yl2, x2;
@@ -707,6 +713,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
             }
             store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
         }
+#endif
         __syncthreads();                                                    // the tile is rewritten by the next band
     }
 }
