@@ -600,6 +600,12 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
 // frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + bf16 rounding as the unfused
 // layer, so conv2's result is bit-identical), and runs conv2 on that tile with its fragments read by ds_read_b128.
 // Neighbouring bands recompute 3 conv1 rows each ((2 R2 + 3) / (2 R2) of the conv1 work).
+// Measured and dropped (1024 frames of 120x160; this form: 128-131 us):
+//   * two wave teams and two tiles (conv1 of the next item beside conv2 of the current one): 8 / 10 / 12 of the 16 waves on
+//     conv1 -> 209 / 180 / 160 us - conv1 scales with the waves it gets;
+//   * two conv1 tiles requested together per wave (36 dwords in flight): 141 us;
+//   * ONE unaligned 8-byte load per k-step instead of three aligned dwords + v_alignbyte: 144 us (267 -> 297 us at 240x320) -
+//     the misaligned 8-byte loads cost the addresser more than the three aligned ones.
 #ifndef TRS_FUSE_ABLATE
 #define TRS_FUSE_ABLATE 0
 #endif
