@@ -264,7 +264,7 @@ def main():
             line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
             line["dtype"] += " / bf16 MFMA convolutions, f32 accumulate"
             line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
-                                "traffic": None, "kernel": "trs_conv12_kernel (conv1 + conv2 fused) + trs_conv_span_kernel + 4 x trs_conv_lt_kernel + trs_conv_mfma_kernel (dense1) + trs_step_kernel + trs_pilot_tail_kernel per step",
+                                "traffic": None, "kernel": "trs_conv12_band_kernel / trs_conv12_kernel (conv1 + conv2 fused) + trs_conv_span_kernel + 4 x trs_conv_lt_kernel + trs_conv_mfma_kernel (dense1) + trs_step_kernel + trs_pilot_tail_kernel per step",
                                 "flops_per_frame": pilot_flops, "avg_step_us": round(kernel_ms * 1e3 / args.steps, 3),
                                 "note": "whole closed-loop step by HIP events; per-layer times in profiles/r01_pilot_conv_v2.txt"}
         if gathered is not None:

@@ -617,6 +617,7 @@ struct Fuse12Params {
     int N, IH, IW, OH1, OW1, OH2, OW2, R2, bands;
     int off_w2, off_b, off_goff, off_tile, off_stage;       // LDS layout
     int tile_bytes;
+    int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as bf16 [rows][IW * 3]
 };
 
 __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
@@ -724,6 +725,158 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
     }
 }
 
+// The same fused head with conv1's input staged once per band.  In the kernel above every conv1 tile fetches its windows
+// straight from the frame: 18 scattered dword loads and ~100 VALU ops (byte alignment, u8 -> bf16) per lane and 32-pixel tile
+// for 6 MFMAs, each frame byte fetched and unpacked ~6 times - conv1's phase is 70 of the 131 us and bound by the texture
+// addresser.  Here the workgroup loads the band's frame rows ONCE (contiguous in the frame: one coalesced 16-byte load per
+// thread, requested one item ahead so that its latency hides behind conv1 of the current item), unpacks them once into a bf16
+// image in LDS, and conv1 reads its k-steps (8 consecutive values, 4-byte aligned) from there with two ds_read2_b32.
+// Same values into the same MFMA order: bit-identical to the kernel above and to the separate layers.
+constexpr int kBandPf = 4;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads)
+__global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Params q)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    u4v* lw1 = reinterpret_cast<u4v*>(psmem);                              // [12][32]
+    u4v* lw2 = reinterpret_cast<u4v*>(psmem + q.off_w2);                   // [80][32]
+    float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
+    float4* lb2 = lb1 + 8;                                                 // [8]
+    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] bf16 (+ padding)
+    unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] bf16 (+ padding)
+    u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + (wave & 7) * 128;   // conv2's output transpose: waves 0..7 only
+    for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
+    for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
+    for (int i = tid; i < 8; i += blockDim.x) { lb1[i] = *reinterpret_cast<const float4*>(q.b1 + 4 * i); lb2[i] = *reinterpret_cast<const float4*>(q.c2.bias + 4 * i); }
+    for (int i = tid; i < q.tile_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(tile1)[i] = (u4v)(0u);   // never multiply an uninitialised bit pattern by a zero weight
+    for (int i = tid; i < q.band_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(band)[i] = (u4v)(0u);
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
+    const float inv_ow1 = 1.0f / (float)q.OW1, inv_ow2 = 1.0f / (float)q.OW2;
+    const int row_in = q.IW * 3;                                            // bytes per frame row = values per band row
+    auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
+        qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
+        if (rm < 0) { --qt; rm += d; } else if (rm >= d) { ++qt; rm -= d; }
+    };
+    auto geometry = [&](int wt, int& n, int& y2_0, int& r2, int& r1) {
+        n = wt / q.bands;
+        const int b = wt - n * q.bands;
+        y2_0 = b * q.R2; r2 = min(q.R2, q.OH2 - y2_0); r1 = 2 * (r2 - 1) + 5;
+    };
+    // the band of item wt: frame rows 4 b R2 .. + 2 r1 + 2, contiguous in the frame
+    auto request = [&](int wt, u4v (&raw)[kBandPf]) {
+        int n, y2_0, r2, r1;
+        geometry(wt, n, y2_0, r2, r1);
+        const int start = (n * q.IH + 4 * y2_0) * row_in, nchunk = ((2 * r1 + 3) * row_in) >> 4;
+#pragma unroll
+        for (int j = 0; j < kBandPf; ++j) {
+            const int c = (tid - 512) + j * 512;
+            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + 16 * c : q.frames_bytes, 0, 0);   // past the end: zeros
+        }
+    };
+    auto unpack = [&](const u4v (&raw)[kBandPf]) {                           // 16 uint8 -> 16 bf16 (exact), 32 bytes of the band image
+#pragma unroll
+        for (int j = 0; j < kBandPf; ++j) {
+            const int c = (tid - 512) + j * 512;
+            if (c * 32 + 32 > q.band_bytes) continue;
+            auto pair = [](unsigned w, int k) -> unsigned {
+                const float f0 = (float)((w >> (8 * k)) & 255u), f1 = (float)((w >> (8 * k + 8)) & 255u);
+                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+            };
+            u4v* dst = reinterpret_cast<u4v*>(band + (size_t)c * 32);
+            dst[0] = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
+            dst[1] = u4v{pair(raw[j].z, 0), pair(raw[j].z, 2), pair(raw[j].w, 0), pair(raw[j].w, 2)};
+        }
+    };
+
+    // Waves 8..15 are the loaders: they have no conv2 tiles (and so no stores in their memory queue to wait behind), request a
+    // band a whole item ahead and unpack it while waves 0..7 run conv2.
+    const int total = q.N * q.bands;
+    const bool loader = wave >= 8;
+    int wt = blockIdx.x;
+    u4v raw[kBandPf];
+    if (loader && wt < total) request(wt, raw);
+    __syncthreads();                                                        // weights staged, tile and band zeroed
+    if (loader && wt < total) {
+        unpack(raw);
+        if (wt + (int)gridDim.x < total) request(wt + gridDim.x, raw);      // the second item's band is on its way
+    }
+    __syncthreads();
+    while (wt < total) {
+        const int nxt = wt + gridDim.x;                                     // uniform per workgroup
+        int n, y2_0, r2, r1;
+        geometry(wt, n, y2_0, r2, r1);
+        // ---- phase 1: conv1 rows of the band, from the bf16 image ----
+        const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
+#if TRS_FUSE_ABLATE != 1
+        for (int t1 = wave; t1 < ntile1; t1 += nwaves) {
+            const int pp = min(t1 * 32 + r, npx1 - 1);
+            int yl, x;
+            divmod(pp, q.OW1, inv_ow1, yl, x);
+            const unsigned char* wbase = band + ((size_t)(2 * yl) * row_in + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            u4v xv[5], wv[6];                                               // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
+#pragma unroll
+            for (int s6 = 0; s6 < 5; ++s6) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (size_t)s6 * row_in * 2);
+                xv[s6] = u4v{src[0], src[1], src[2], src[3]};
+            }
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
+            __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6)                                  // k-step 5 is padding (zero weights): any finite operand
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[min(s6, 4)]), acc, 0, 0, 0);
+            if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)pp * 48);
+#pragma unroll
+                for (int qd = 0; qd < 3; ++qd) {
+                    const float4 bb = lb1[2 * qd + h];
+                    float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    dst[2 * qd + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+        }
+#endif
+        __syncthreads();                                                    // the tile is complete, the band image is free
+        if (loader) {
+            if (nxt < total) {
+                unpack(raw);                                                // the next item's band (requested an item ago)
+                if (nxt + (int)gridDim.x < total) request(nxt + gridDim.x, raw);
+            }
+        } else {
+            // ---- phase 2: conv2 rows from the tile (waves 0..7: at most a handful of tiles per band) ----
+            const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
+            const int m0 = (n * q.OH2 + y2_0) * q.OW2;                      // first output pixel of the band (consecutive in memory)
+#if TRS_FUSE_ABLATE != 2
+            for (int t2 = wave; t2 < ntile2; t2 += 8) {
+                const int mm = min(t2 * 32 + r, npx2 - 1);
+                int yl2, x2;
+                divmod(mm, q.OW2, inv_ow2, yl2, x2);
+                const unsigned char* abase = tile1 + (size_t)((2 * yl2) * q.OW1 + 2 * x2) * 48 + h * 16;
+                f32x16 acc2[1];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
+                for (int kh = 0; kh < 5; ++kh) {
+                    const unsigned char* arow = abase + (size_t)kh * q.OW1 * 48;
+#pragma unroll
+                    for (int t = 0; t < 16; t += 2) {
+                        const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
+                        const bf16x8 w = __builtin_bit_cast(bf16x8, lw2[(kh * 16 + t + h) * 32 + r]);
+                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
+                    }
+                }
+                store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
+            }
+#endif
+        }
+        __syncthreads();                                                    // the tile is free, the next band image is complete
+        wt = nxt;
+    }
+}
+
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
 struct TailParams {
     const float* h1;           // dense1 output before ReLU, fp32: h1_slices slabs of [n][100] (split-K partial sums, added here in slice order)
@@ -823,7 +976,7 @@ struct PilotCtx {
     uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
     int last_n = 0, last_slices = 1;
     bool no_fuse = false;
-    bool fuse12 = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
+    bool fuse12 = false, fuse_band = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
 };
@@ -943,8 +1096,13 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         q.c2.out = c->act[1]; q.c2.M = n * c->L[1].OH * c->L[1].OW;
         q.c2.nt_out = 0;
         const int grid = std::max(1, std::min(n * q.bands, c->cu_count));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
-        hipLaunchKernelGGL(trs_conv12_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+        if (c->fuse_band) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+            hipLaunchKernelGGL(trs_conv12_band_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+        } else {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+            hipLaunchKernelGGL(trs_conv12_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+        }
         HIPCHK(hipGetLastError());
         in = c->act[1];
         in_bytes = (size_t)n * c->act_elems[1] * 2;
@@ -1129,8 +1287,25 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         int want_r2 = 6;                                                  // measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
         if (const char* e = std::getenv("TRS_PILOT_FUSE_R2")) want_r2 = std::max(1, std::atoi(e));
-        c->fuse12 = false; c->no_fuse = std::getenv("TRS_PILOT_NO_FUSE") != nullptr;
-        for (int r2 = std::min(want_r2, l1.OH); shape_ok && r2 >= 1; --r2) {
+        c->fuse12 = false; c->fuse_band = false; c->no_fuse = std::getenv("TRS_PILOT_NO_FUSE") != nullptr;
+        // band form (conv1's input staged once per band as a bf16 image): tile + band image + 8 wave stages
+        // (measured, 1024 frames of 120x160: R2 = 7 / 6 / 5 -> 129 / 114 / 125 us against 131 for the direct form; 512 frames of
+        // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
+        int band_r2 = 6;
+        if (const char* e = std::getenv("TRS_PILOT_FUSE_BAND_R2")) band_r2 = std::atoi(e);            // 0 = use the direct form
+        for (int r2 = std::min(band_r2, l1.OH); shape_ok && r2 >= std::min(4, l1.OH); --r2) {
+            const int rows_in = 2 * (2 * r2 + 3) + 3, row_in = l0.IW * 3;
+            if (row_in % 16 != 0 || rows_in * row_in > kBandPf * 512 * 16) continue;
+            int off = 12 * 32 * 16;
+            q.off_w2 = off; off += 80 * 32 * 16;
+            q.off_b = off; off += 16 * 16;
+            q.off_goff = off; off += 64;
+            q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * l0.OW * 48 + 64) + 15) & ~15; off += q.tile_bytes;
+            q.off_band = off; q.band_bytes = rows_in * row_in * 2 + 64; off += q.band_bytes;
+            q.off_stage = off; off += 8 * 2048;
+            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
+        }
+        for (int r2 = std::min(want_r2, l1.OH); shape_ok && !c->fuse12 && r2 >= 1; --r2) {
             int off = 12 * 32 * 16;
             q.off_w2 = off; off += 80 * 32 * 16;
             q.off_b = off; off += 16 * 16;
