@@ -897,19 +897,30 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     if (i >= p.n) return;
-    for (int k = lane; k < 100; k += 64) {
-        float x = 0.0f;                                                     // fixed order: run-to-run identical; eight loads in flight
-        const float* src = p.h1 + (size_t)i * 100 + k;
+    {   // dense1's 100 outputs of this frame = the K-slice slabs added in slice order (fixed order: run-to-run identical).  A lane
+        // owns outputs `lane` and `lane + 64`; the phase is pure load latency, so 16 slices x 2 outputs are requested together.
+        const bool two = lane + 64 < 100;
+        const float* src0 = p.h1 + (size_t)i * 100 + lane;
+        const float* src1 = src0 + (two ? 64 : 0);
+        float x0 = 0.0f, x1 = 0.0f;
         int sl = 0;
-        for (; sl + 8 <= p.h1_slices; sl += 8) {
-            float v[8];
+        for (; sl + 16 <= p.h1_slices; sl += 16) {
+            float v0[16], v1[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(sl + q) * p.h1_stride];
+            for (int q = 0; q < 16; ++q) { v0[q] = src0[(size_t)(sl + q) * p.h1_stride]; v1[q] = src1[(size_t)(sl + q) * p.h1_stride]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x += v[q];
+            for (int q = 0; q < 16; ++q) { x0 += v0[q]; x1 += v1[q]; }
         }
-        for (; sl < p.h1_slices; ++sl) x += src[(size_t)sl * p.h1_stride];
-        s1[wv][k] = x > 0.f ? x : 0.f;                                      // dense1's ReLU
+        for (; sl + 4 <= p.h1_slices; sl += 4) {
+            float v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v0[q] = src0[(size_t)(sl + q) * p.h1_stride]; v1[q] = src1[(size_t)(sl + q) * p.h1_stride]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { x0 += v0[q]; x1 += v1[q]; }
+        }
+        for (; sl < p.h1_slices; ++sl) { x0 += src0[(size_t)sl * p.h1_stride]; x1 += src1[(size_t)sl * p.h1_stride]; }
+        s1[wv][lane] = x0 > 0.f ? x0 : 0.f;                                 // dense1's ReLU
+        if (two) s1[wv][lane + 64] = x1 > 0.f ? x1 : 0.f;
     }
     __builtin_amdgcn_wave_barrier();
     if (lane < 50) { float s = p.b2[lane]; for (int k = 0; k < 100; ++k) s = fmaf(s1[wv][k], p.w2[k * 50 + lane], s); s2[wv][lane] = s > 0.f ? s : 0.f; }
