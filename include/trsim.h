@@ -275,7 +275,13 @@ typedef struct trs_pilot_config {
     float   spd_ctl_break_multiplier;     /* 1.0 */
     int32_t smooth_steering_enabled;      /* keras_pilot.py:147-153 */
     float   smooth_steering_threshold;    /* 0.9 */
+    int32_t model_type;                   /* TRS_PILOT_* below; both types run the same network (keras_train.py:386-395) */
 } trs_pilot_config;
+
+enum {
+    TRS_PILOT_SPD_CTL = 0,  /* ModelType.CNN_2D_SPD_CTL: outputs (steering, speed / 20) + the speed controller (keras_pilot.py:78-95) */
+    TRS_PILOT_CNN_2D = 1    /* ModelType.CNN_2D: outputs (steering, throttle), both capped to [-1, 1], breaking 0 (keras_pilot.py:56-64) */
+};
 
 void trs_default_pilot_config(trs_pilot_config* cfg);
 
@@ -296,7 +302,8 @@ int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats
 
 /* Closed loop for n_steps (the reference's tick order, car_templates/manage.py:46-75: the pilot acts on the frame the
  * sim stored on the previous tick): controls = KerasPilot.step(frame, speed) for ModelType.CNN_2D_SPD_CTL
- * (keras_pilot.py:78-95: cap steering, predicted speed x 20, calcThrottle / calcBreak of utils/mapping.py:23-35),
+ * (keras_pilot.py:78-95: cap steering, predicted speed x 20, calcThrottle / calcBreak of utils/mapping.py:23-35) or for
+ * ModelType.CNN_2D (:56-64: both outputs capped, breaking 0), smooth steering for both,
  * then one env step with those controls.  Before the first frame exists the controls are (0, 0, 0) (keras_pilot.py:46-47). */
 int trs_step_pilot(trs_env* env, const trs_pilot_config* cfg, int n_steps);
 

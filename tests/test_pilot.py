@@ -138,6 +138,30 @@ def test_closed_loop_controls_follow_the_reference_tick_order(make_env):
     assert np.array_equal(a.fetch("img"), b.fetch("img"))
 
 
+def test_cnn_2d_model_type_closed_loop(make_env):
+    """ModelType.CNN_2D (keras_pilot.py:56-64): the same network, outputs are (steering, throttle) capped to [-1, 1],
+    breaking 0, smooth steering applied - against the loop done by hand."""
+    n = 16
+    ws = make_weights(120, 160, seed=6)
+    ws[-1] = ws[-1] + np.float32([0.0, 0.6])                         # bias the throttle output so that the cars move
+    cfg = {"model_type": "cnn_2d", "smooth_steering_enabled": True, "smooth_steering_threshold": 0.02}
+    a = make_env("hip", n_envs=n)
+    b = make_env("hip", n_envs=n)
+    a.pilot_load(ws); b.pilot_load(ws)
+    a.step_pilot(6, cfg)
+    b.step(0.0, 0.0, 0.0)                                            # tick 1: no frame yet
+    for _ in range(5):
+        out = b.pilot_forward_host(b.fetch("img"))
+        steer = np.clip(out[:, 0], -1.0, 1.0)
+        steer = np.where(steer > 0.02, 1.0, np.where(steer < -0.02, -1.0, steer)).astype(np.float32)
+        b.step(steer, np.clip(out[:, 1], -1.0, 1.0), 0.0)
+    for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img", "ctl_steer", "ctl_thr", "ctl_brk"):
+        assert np.array_equal(a.fetch(name), b.fetch(name)), name   # no transcendental in this post-processing: bit for bit
+    assert a.fetch("speed").max() > 0.1 and np.all(a.fetch("ctl_brk") == 0.0)
+    with pytest.raises(ValueError, match="model_type"):
+        a.step_pilot(1, {"model_type": "cnn_2d_full_house"})
+
+
 def test_break_mode_and_errors(make_env):
     env = make_env("hip", n_envs=4)
     with pytest.raises(RuntimeError, match="no pilot loaded"):
@@ -171,7 +195,6 @@ def test_keras_pilot_component_contract(tmp_path):
     st, thr, brk = pilot_postprocess(raw, 3.0, cfg)
     st = 1.0 if st > 0.02 else (-1.0 if st < -0.02 else st)                        # smooth steering (:147-153)
     assert all(isinstance(v, float) for v in got)
-    # dense1 sums its K slices with fp32 atomics: two forward passes agree to ~1e-7 relative, not bit for bit
     assert abs(got[0] - st) < 1e-6 and abs(got[1] - thr) < 1e-5 and got[2] == brk == 0.0
     part.onShutdown()
     brake = HipKerasPilot(dict(cfg, spd_ctl_break=True, smooth_steering_enabled=False), weights=ws, n_cars=3)
@@ -183,8 +206,13 @@ def test_keras_pilot_component_contract(tmp_path):
         want = pilot_postprocess(raws[i], float(speeds[i]), dict(cfg, spd_ctl_break=True))
         assert abs(s3[i] - want[0]) < 1e-6 and abs(t3[i] - want[1]) < 1e-5 and abs(b3[i] - want[2]) < 1e-5
     brake.onShutdown()
+    direct = HipKerasPilot(dict(cfg, smooth_steering_enabled=False), weights=ws, model_type="cnn_2d")     # ModelType.CNN_2D (:56-64)
+    raw = direct.env.pilot_forward_host(frame[None])[0]
+    got = direct.step(frame, 3.0, 0.0, 0.0, "ai")
+    assert got == (float(np.clip(np.float64(raw[0]), -1, 1)), float(np.clip(np.float64(raw[1]), -1, 1)), 0.0)
+    direct.onShutdown()
     with pytest.raises(ValueError, match="CNN_2D_SPD_CTL"):
-        HipKerasPilot(cfg, weights=ws, model_type="cnn_2d")
+        HipKerasPilot(cfg, weights=ws, model_type="cnn_2d_full_house")
 
 
 def test_pilot_is_deterministic(make_env):

@@ -92,7 +92,11 @@ class TrsPilotConfig(C.Structure):
         ("struct_size", C.c_uint32), ("spd_ctl_threshold", C.c_float), ("spd_ctl_break", C.c_int32),
         ("spd_ctl_reverse_multiplier", C.c_float), ("spd_ctl_break_multiplier", C.c_float),
         ("smooth_steering_enabled", C.c_int32), ("smooth_steering_threshold", C.c_float),
+        ("model_type", C.c_int32),
     ]
+
+
+PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1}          # TRS_PILOT_*; ModelType values of components/keras_train.py
 
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle

@@ -242,7 +242,8 @@ def load_keras_weights(path):
 
 
 class HipKerasPilot(Component):
-    """``KerasPilot`` for ``ModelType.CNN_2D_SPD_CTL`` (reference ``components/keras_pilot.py:17-153``): same ports, same
+    """``KerasPilot`` for ``ModelType.CNN_2D_SPD_CTL`` and ``ModelType.CNN_2D`` (reference ``components/keras_pilot.py:17-153``;
+    both run the same network, ``keras_train.py:386-395``): same ports, same
     ``spd_ctl_*`` / ``smooth_steering_*`` config keys, same rule "``(0.0, 0.0, 0.0)`` without a frame or outside the two AI
     modes".  The network (``Keras_2D_CNN.get_model``, ``keras_train.py:127-174``) runs on the GPU in bf16 MFMA
     convolutions (``trs_pilot_forward_host``); the post-processing (cap, x20, ``calcThrottle`` / ``calcBreak``, smooth
@@ -255,8 +256,10 @@ class HipKerasPilot(Component):
 
     def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0):
         mt = getattr(model_type, "value", model_type)
-        if mt != "cnn_2d_speed_control":
-            raise ValueError("HipKerasPilot implements ModelType.CNN_2D_SPD_CTL ('cnn_2d_speed_control') only")
+        if mt not in ("cnn_2d_speed_control", "cnn_2d"):
+            raise ValueError("HipKerasPilot implements ModelType.CNN_2D_SPD_CTL ('cnn_2d_speed_control') and ModelType.CNN_2D ('cnn_2d'): "
+                             "the two types that run Keras_2D_CNN.get_model(input_shape, num_outputs=2, num_feature_vectors=0)")
+        self.model_type = mt
         Component.__init__(self, inputs=list(PILOT_INPUTS), outputs=list(PILOT_OUTPUTS), threaded=False)
         self.cfg = dict(cfg or {})
         if weights is None:
@@ -283,6 +286,14 @@ class HipKerasPilot(Component):
         single = img.ndim == 3
         raw = self.env.pilot_forward_host(img[None] if single else img)    # [n, 2]: steering, speed / 20
         steering = np.clip(raw[:, 0].astype(np.float64), -1.0, 1.0)        # __cap (:142-145)
+        if self.model_type == "cnn_2d":                                    # :56-64: (steering, throttle) capped, no brake
+            throttle = np.clip(raw[:, 1].astype(np.float64), -1.0, 1.0)
+            if self.smooth_steering:
+                steering = np.where(steering > self.smooth_steering_threshold, 1.0,
+                                    np.where(steering < -self.smooth_steering_threshold, -1.0, steering))
+            if single:
+                return float(steering[0]), float(throttle[0]), 0.0
+            return steering, throttle, np.zeros_like(throttle)
         predicted = raw[:, 1].astype(np.float64) * 20                      # :83
         real = np.broadcast_to(np.asarray(args[1], dtype=np.float64), predicted.shape)
         throttle = control.calc_throttle(real, predicted * self.speed_control_threshold, self.speed_control_reverse_multiplier)

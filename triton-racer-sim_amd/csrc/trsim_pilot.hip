@@ -887,7 +887,7 @@ struct TailParams {
     float *steer, *thr, *brk;  // next controls
     int n, act;
     float threshold, rev_mult, brk_mult, smooth_thr;
-    int use_break, smooth;
+    int use_break, smooth, direct;   // direct: ModelType.CNN_2D (outputs are steering and throttle)
 };
 
 __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
@@ -941,7 +941,8 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     float throttle = p.rev_mult * atanf(delta * 2.0f) / kHalfPi;
     if (throttle > -0.2f && throttle < 0.0f) throttle = 0.0f;
     float breaking = 0.0f;
-    if (p.use_break) {                                                              // keras_pilot.py:88-90, mapping.py:30-35
+    if (p.direct) throttle = out[1] < -1.0f ? -1.0f : (out[1] > 1.0f ? 1.0f : out[1]);   // ModelType.CNN_2D: __cap of both outputs (:60)
+    else if (p.use_break) {                                                         // keras_pilot.py:88-90, mapping.py:30-35
         throttle = (predicted - real > 0.0f) ? 1.0f : 0.0f;
         breaking = -1.0f * p.brk_mult * atanf(delta * 1.0f) / kHalfPi;
         if (breaking < 0.4f) breaking = 0.0f;
@@ -1152,6 +1153,7 @@ int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_
         t.speed = v.speed; t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
         t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
         t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
+        t.direct = cfg->model_type == TRS_PILOT_CNN_2D;
     }
     hipLaunchKernelGGL(trs_pilot_tail_kernel, dim3((n + 3) / 4), dim3(256), 0, v.stream, t);
     HIPCHK(hipGetLastError());
@@ -1417,6 +1419,7 @@ TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_ste
     if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
     if (!cfg || cfg->struct_size != sizeof(trs_pilot_config)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.struct_size mismatch");
     if (n_steps < 1) return trs_internal_fail(TRS_ERR_ARG, "n_steps < 1");
+    if (cfg->model_type != TRS_PILOT_SPD_CTL && cfg->model_type != TRS_PILOT_CNN_2D) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type: cnn_2d_speed_control or cnn_2d");
     if (!v.render) return trs_internal_fail(TRS_ERR_STATE, "the pilot needs a camera (render = 1)");
     HIPCHK(hipSetDevice(v.device));
     for (int k = 0; k < n_steps; ++k) {

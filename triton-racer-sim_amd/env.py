@@ -349,6 +349,10 @@ class BatchedEnv:
         pc.spd_ctl_break_multiplier = float(cfg.get("spd_ctl_break_multiplier", 1.0))
         pc.smooth_steering_enabled = int(bool(cfg.get("smooth_steering_enabled", False)))
         pc.smooth_steering_threshold = float(cfg.get("smooth_steering_threshold", 0.9))
+        mt = getattr(cfg.get("model_type", "cnn_2d_speed_control"), "value", cfg.get("model_type", "cnn_2d_speed_control"))
+        if mt not in _ffi.PILOT_MODEL_TYPES:
+            raise ValueError(f"model_type {mt!r}: the GPU pilot runs 'cnn_2d_speed_control' and 'cnn_2d'")
+        pc.model_type = _ffi.PILOT_MODEL_TYPES[mt]
         return pc
 
     def pilot_forward_host(self, frames):
