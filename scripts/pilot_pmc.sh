@@ -19,7 +19,7 @@ for name in ("sq","tcp"):
     fs=glob.glob("gpurun_out/pmc_${tag}_%s/**/*counter_collection.csv"%name,recursive=True)
     if not fs: print("no csv for",name); continue
     rows=list(csv.DictReader(open(fs[0])))
-    rows=[r for r in rows if "conv_" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
+    rows=[r for r in rows if "trs_conv" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
     # group by dispatch id -> counters
     disp=collections.OrderedDict()
     for r in rows:
@@ -31,9 +31,11 @@ for name in ("sq","tcp"):
     for d in ds:
         cur.append(d)
         if "tail" in d["k"]: steps.append(cur);cur=[]
-    steps=[s for s in steps if len(s)==len(names)]
+    fused=["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
+    steps=[s for s in steps if len(s) in (len(names),len(fused))]
     if not steps: print("no complete step for",name); continue
     last=steps[-1]
+    if len(last)==len(fused): names=fused
     ctrs=[c for c in last[1] if c!="k"]
     print("== %s (last step)"%name)
     print("  %-9s "%"layer"+" ".join("%22s"%c[-22:] for c in ctrs))
