@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the fused physics + camera step on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 1024] [--steps-per-launch 1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu E | --total-envs T] [--steps-per-launch 1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over every env of every shard: bicycle-model integration, binary64
 nearest-point index, cte/done/return, and one 120x160 RGB frame per env written to HBM (inputs and
 outputs device-resident; controls from the counter-based generator of include/trsim_spec.h).
-Workload = BASELINE.json configs[2] (1024 envs, physics + 120x160 RGB pinhole rasteriser, one MI355X);
-with N GPUs every rank owns its own 1024-env shard (weak scaling) and the job ends with the single
-RCCL all-gather of episode returns.  Rank 0 prints ONE JSON line.
+Workload at N = 1: BASELINE.json configs[2] (1024 envs, physics + 120x160 RGB pinhole rasteriser, one MI355X).
+Workload at N > 1: BASELINE.json configs[3] (4096 envs in total, sharded over the N GPUs = 512 per GPU at N = 8,
+one RCCL all-gather of the episode returns closing the job).  --envs-per-gpu / --total-envs override either.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
@@ -106,7 +107,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs-per-gpu", type=int, default=1024)
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="envs per shard (default: 1024 at N = 1 = configs[2]; 4096 / N at N > 1 = configs[3])")
+    ap.add_argument("--total-envs", type=int, default=None, help="envs over all shards (alternative to --envs-per-gpu)")
     ap.add_argument("--img-h", type=int, default=120)
     ap.add_argument("--img-w", type=int, default=160)
     ap.add_argument("--steps-per-launch", type=int, default=1)
@@ -139,7 +141,21 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n = args.envs_per_gpu
+    if args.envs_per_gpu is not None and args.total_envs is not None:
+        sys.exit("give --envs-per-gpu or --total-envs, not both")
+    if args.envs_per_gpu is not None:
+        n, picked = args.envs_per_gpu, "override (--envs-per-gpu)"
+    elif args.total_envs is not None:
+        if args.total_envs % world:
+            sys.exit("--total-envs must be divisible by the number of GPUs")
+        n, picked = args.total_envs // world, "override (--total-envs)"
+    elif world == 1:
+        n, picked = 1024, "BASELINE configs[2]"
+    else:
+        if 4096 % world:
+            sys.exit("BASELINE configs[3] (4096 envs) needs a GPU count that divides 4096; use --envs-per-gpu")
+        n, picked = 4096 // world, "BASELINE configs[3]"
+    fixed_total = args.envs_per_gpu is None and world > 1          # total fixed as N grows -> strong scaling
     render = not args.no_render
     shard = ShardedEnvs(n * world, rank, world, device=local_rank, img_h=args.img_h, img_w=args.img_w, render=render, auto_reset=True,
                         depth=args.depth)
@@ -206,11 +222,30 @@ def main():
         env.step_sequence_device(seq_steer.data_ptr(), seq_thr.data_ptr(), n_steps=args.steps, steps_per_launch=8)
         env.event_record(5)
         ms_seq = env.event_elapsed_ms(4, 5)
-        also = {"sequence_steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms_seq * 1e-3), 1),
-                                                "frac_of_hbm_peak": round(algorithmic_bytes(args.img_h, args.img_w, render, args.depth) * n * args.steps / (ms_seq * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        # ... and the consumer-paced call: ONE trs_step per tick with that tick's (device-resident) controls, n_steps = 1 per call,
+        # the way Car.start drives GymInterface.step (core/car.py:45-53)
+        one_steer = (torch.rand(n, device="cuda") * 2 - 1) * 0.3
+        one_thr = torch.rand(n, device="cuda") * 0.6 + 0.2
+        torch.cuda.synchronize()
+        for _ in range(min(50, args.steps)):
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.sync()
+        t1 = time.perf_counter()
+        env.event_record(6)
+        for _ in range(args.steps):
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.event_record(7)
+        ms_one = env.event_elapsed_ms(6, 7)
+        wall_one = time.perf_counter() - t1
+        Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
+        rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
+        frac = lambda ms: round(Bx * n * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        also = {"single_step_call": {"env_steps_per_s": rate(ms_one), "frac_of_hbm_peak": frac(ms_one), "us_per_call": round(ms_one * 1e3 / args.steps, 3),
+                                     "host_wall_us_per_call": round(wall_one * 1e6 / args.steps, 3),
+                                     "note": "trs_step(device controls, n_steps = 1) called once per step: the consumer-paced path (one launch per call, raster waits for that step's physics); device time by HIP events"},
+                "sequence_steps_per_launch_8": {"env_steps_per_s": rate(ms_seq), "frac_of_hbm_peak": frac(ms_seq),
                                                 "note": "trs_step_sequence: a different device-resident control set per step (open-loop action sequences), 8 steps per launch"},
-                "steps_per_launch_8": {"env_steps_per_s": round(n * args.steps / (ms8 * 1e-3), 1),
-                                       "frac_of_hbm_peak": round(algorithmic_bytes(args.img_h, args.img_w, render, args.depth) * n * args.steps / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "steps_per_launch_8": {"env_steps_per_s": rate(ms8), "frac_of_hbm_peak": frac(ms8),
                                        "note": "synthetic controls; physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
@@ -231,25 +266,29 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
+                # scripts/summarize_profile.py writes {"<envs>x<H>x<W>x<steps per launch>[+depth]": HBM bytes per launch, ...} from the
+                # WRITE_SIZE / FETCH_SIZE passes of scripts/profile.sh (unit + gfx950 corrections of MI355X_MICROARCH.md applied)
                 with open(pmc) as f:
-                    traffic = json.load(f).get(f"{n}x{args.img_h}x{args.img_w}x{spl}")
+                    traffic = json.load(f).get("per_launch", {}).get(f"{n}x{args.img_h}x{args.img_w}x{spl}" + ("+depth" if args.depth else ""))
             except Exception:
                 traffic = None
         line = {
             "metric": "env-steps/s (whole node) at N envs x 120x160 RGB",
             "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(wall * 1e3 / args.steps, 6), "higher_is_better": True, "scaling": "strong" if fixed_total else "weak",
             "vs_baseline": None, "dtype": "f32 state / f64 nearest-point / u8 image", "data": "synthetic",
             "config": {
                 "workload": f"{n} envs/GPU x {world} GPU, bicycle physics + L1 nearest point"
                             + (f" + {args.img_h}x{args.img_w} RGB pinhole rasteriser" if render else " (no camera)")
                             + (" + fp32 depth" if render and args.depth else "")
-                            + " (BASELINE configs[2] per GPU), generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
-                "envs_total": n * world, "steps_per_launch": spl, "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
+                            + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
+                            + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
+                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac_by_wall_clock": round(B * n * args.steps / wall / 1e9 / HBM_PEAK_GBS, 5),
                 "kernel": "trs_step_kernel" if render else "trs_physics_kernel", "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },

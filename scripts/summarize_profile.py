@@ -44,4 +44,22 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
 if len(vals) == 2:
     traffic = (vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"]) * 1024
     print(f"== traffic per launch: {traffic:.0f} B (WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB, FETCH_SIZE {vals['FETCH_SIZE']:.1f} KiB x2)")
-    json.dump({"traffic_bytes_per_launch": traffic, **vals}, open(os.path.join(out, "traffic.json"), "w"))
+    key = None
+    try:   # the bench line of the traced run names the workload the counters belong to
+        with open(os.path.join(out, "bench_trace.json")) as fh:
+            cfg = [json.loads(l) for l in fh if l.strip().startswith("{")][-1]["config"]
+        key = f"{cfg['envs_per_gpu']}x{cfg['img_h']}x{cfg['img_w']}x{cfg['steps_per_launch']}" + ("+depth" if cfg.get("depth") else "")
+    except Exception as exc:
+        print("   (no bench line to key the traffic figure by:", exc, ")")
+    json.dump({"traffic_bytes_per_launch": traffic, "key": key, **vals}, open(os.path.join(out, "traffic.json"), "w"))
+    # profiles/pmc_traffic.json is what bench.py reads for roofline.traffic: {"per_launch": {key: bytes}}
+    if key:
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        dst = os.path.join(repo, "gpurun_out", "pmc_traffic.json")
+        cur = {"per_launch": {}}
+        for cand in (dst, os.path.join(repo, "profiles", "pmc_traffic.json")):
+            if os.path.exists(cand):
+                cur = json.load(open(cand)); break
+        cur.setdefault("per_launch", {})[key] = traffic
+        json.dump(cur, open(dst, "w"), indent=1)
+        print("== merged into gpurun_out/pmc_traffic.json under", key, "(copy to profiles/ to publish)")
