@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--img-h", type=int, default=120)
     ap.add_argument("--img-w", type=int, default=160)
     ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--resident", action="store_true", help="resident step mode (trs_set_step_mode): a worker kernel stays on the GPU, every step is POSTED (no launch per step)")
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
     ap.add_argument("--pilot", action="store_true", help="closed loop with cnn_2d_speed_control inference on the device frame each step (BASELINE configs[4] shape)")
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
@@ -181,6 +182,9 @@ def main():
         run = lambda k_: env.step_pilot(k_)
     else:
         run = lambda k_: env.step_synthetic(k_, spl)
+    resident = bool(args.resident and render and not args.pilot)
+    if resident:
+        env.set_step_mode(True)
 
     def barrier():
         env.sync()
@@ -224,6 +228,8 @@ def main():
         ms_seq = env.event_elapsed_ms(4, 5)
         # ... and the consumer-paced call: ONE trs_step per tick with that tick's (device-resident) controls, n_steps = 1 per call,
         # the way Car.start drives GymInterface.step (core/car.py:45-53)
+        if resident:
+            env.set_step_mode(False)
         one_steer = (torch.rand(n, device="cuda") * 2 - 1) * 0.3
         one_thr = torch.rand(n, device="cuda") * 0.6 + 0.2
         torch.cuda.synchronize()
@@ -237,12 +243,38 @@ def main():
         env.event_record(7)
         ms_one = env.event_elapsed_ms(6, 7)
         wall_one = time.perf_counter() - t1
+        # ... the same loop in resident mode: every call only posts its control pointers to the worker kernel
+        env.set_step_mode(True)
+        for _ in range(min(50, args.steps)):
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.sync()
+        t2 = time.perf_counter()
+        env.event_record(6)                                       # (asks the worker to leave: the timed span holds a whole worker launch)
+        for _ in range(args.steps):
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.event_record(7)
+        ms_res = env.event_elapsed_ms(6, 7)
+        wall_res = time.perf_counter() - t2
+        # ... and lock-step: the consumer waits for every frame before it posts the next step (PCIe round trips included)
+        env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.sync()
+        lock_steps = min(args.steps, 500)
+        t3 = time.perf_counter()
+        for _ in range(lock_steps):
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.sync()
+        wall_lock = time.perf_counter() - t3
+        env.set_step_mode(resident)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
         frac = lambda ms: round(Bx * n * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         also = {"single_step_call": {"env_steps_per_s": rate(ms_one), "frac_of_hbm_peak": frac(ms_one), "us_per_call": round(ms_one * 1e3 / args.steps, 3),
                                      "host_wall_us_per_call": round(wall_one * 1e6 / args.steps, 3),
                                      "note": "trs_step(device controls, n_steps = 1) called once per step: the consumer-paced path (one launch per call, raster waits for that step's physics); device time by HIP events"},
+                "resident_single_step_call": {"env_steps_per_s": rate(ms_res), "frac_of_hbm_peak": frac(ms_res), "us_per_call": round(ms_res * 1e3 / args.steps, 3),
+                                              "host_wall_us_per_call": round(wall_res * 1e6 / args.steps, 3),
+                                              "lock_step_us_per_call": round(wall_lock * 1e6 / lock_steps, 3),
+                                              "note": "trs_set_step_mode(TRS_STEP_RESIDENT): the same calls only POST to the resident worker kernel (no launch, no kernel boundary, tables staged once); device time = the worker launch that served all the calls, by HIP events; lock_step = post, wait for the frame, post (host wall clock)"},
                 "sequence_steps_per_launch_8": {"env_steps_per_s": rate(ms_seq), "frac_of_hbm_peak": frac(ms_seq),
                                                 "note": "trs_step_sequence: a different device-resident control set per step (open-loop action sequences), 8 steps per launch"},
                 "steps_per_launch_8": {"env_steps_per_s": rate(ms8), "frac_of_hbm_peak": frac(ms8),
@@ -259,6 +291,8 @@ def main():
         # camera on: the library pipelines a call over ceil(steps/spl)+1 launches of trs_step_kernel (physics runs ahead of the
         # raster inside and across launches); physics only: steps/spl launches of trs_physics_kernel
         launches = ((args.steps + spl - 1) // spl + 1) if render else (args.steps + spl - 1) // spl
+        if resident:
+            launches = 1                                                # one trs_worker_kernel launch serves every posted step of the timed region
         avg_launch_s = kernel_ms * 1e-3 / launches
         per_launch = n * args.steps / launches                         # env-steps one launch completes
         achieved = B * per_launch / avg_launch_s / 1e9                 # GB/s of algorithmic bytes, dominant (only) kernel
@@ -283,13 +317,13 @@ def main():
                             + (" + fp32 depth" if render and args.depth else "")
                             + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
                             + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
-                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
+                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "frac_by_wall_clock": round(B * n * args.steps / wall / 1e9 / HBM_PEAK_GBS, 5),
-                "kernel": "trs_step_kernel" if render else "trs_physics_kernel", "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                "kernel": "trs_worker_kernel" if resident else ("trs_step_kernel" if render else "trs_physics_kernel"), "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },
         }

@@ -146,6 +146,24 @@ int trs_step_sequence(trs_env* env, const float* d_steering, const float* d_thro
 int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h_throttle, const float* h_brake,
                            const uint8_t* h_reset, int n_steps, int steps_per_launch);
 
+/* How trs_step / trs_step_host / trs_step_synthetic / trs_step_sequence reach the GPU — the per-tick call of the reference's
+ * drive loop (core/car.py:45-53: one component.step per tick with that tick's values; components/gyminterface.py:66-76).
+ *   TRS_STEP_LAUNCH   (default) every call launches the step kernel(s) on the handle's stream.
+ *   TRS_STEP_RESIDENT a worker kernel stays on the GPU (tables staged once, env state in LDS, one workgroup per CU) and a
+ *     call only POSTS the step: control pointers into a ring in pinned host memory that the worker polls.  No kernel launch,
+ *     no kernel boundary, no table re-staging per step; the physics team runs ahead of the raster team as far as posted
+ *     steps allow; up to 8 steps may be in flight, a post beyond that waits.  The worker leaves by itself after `idle_us`
+ *     (<= 0: 2000) without a post and is started again by the next one.  While it is resident it owns the handle's stream:
+ *     trs_sync waits for the posted steps only (completion flags in host memory), trs_copy_to_host / trs_fetch_outputs copy
+ *     on a side stream, and every OTHER call that needs the stream (reset, set_pose, load_track, image path, control glue,
+ *     pilot, events) first asks the worker to leave.  Frames and telemetry of a completed step are in HBM (written through);
+ *     a consumer that reads them on its own stream does so after trs_sync.  Device-resident controls must be complete
+ *     (their producer synchronised) when trs_step is called, and stay untouched until that step is done.  Needs a camera
+ *     (cfg.render); with the in-kernel dynamic-brightness filter (trs_set_frame_filter) calls fall back to launches.
+ *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident. */
+enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
+int trs_set_step_mode(trs_env* env, int mode, int idle_us);
+
 /* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
 int trs_get_state(trs_env* env, trs_state_view* out);
 

@@ -587,6 +587,8 @@ EXPORT int trso_map_info_get(trs_env* e, trs_map_info* o)
 }
 
 EXPORT int trso_sync(trs_env* e) { (void)e; return TRS_OK; }
+/* how steps reach the GPU (include/trsim.h: trs_set_step_mode) changes no result: accepted and ignored here */
+EXPORT int trso_set_step_mode(trs_env* e, int mode, int idle_us) { (void)idle_us; if (!e) return TRS_ERR_ARG; return (mode == 0 || mode == 1) ? TRS_OK : TRS_ERR_ARG; }
 EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return TRS_OK; }
 EXPORT int trso_event_elapsed_ms(trs_env* e, int a, int b, float* ms) { (void)e; (void)a; (void)b; if (ms) *ms = 0.0f; return TRS_OK; }
 EXPORT int trso_device_count(int* out) { if (out) *out = 0; return TRS_OK; }

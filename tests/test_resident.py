@@ -1,0 +1,159 @@
+"""Resident step mode (``trs_set_step_mode(TRS_STEP_RESIDENT)``): a worker kernel stays on the GPU and every ``trs_step``
+only posts its controls — the consumer-paced call of the reference's drive loop (``core/car.py:45-53``: one
+``component.step`` per tick with that tick's values; ``components/gyminterface.py:66-76``) without a launch per step.
+
+The results must not depend on HOW the steps reach the GPU: every test compares the resident path with the CPU oracle
+(images, indices and flags bit-exact; pose / speed within 1e-5), through the C ABI.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_frames_equal(g, o, where=""):
+    a, b = g.fetch("img"), o.fetch("img")
+    assert np.array_equal(a, b), f"image differs {where}: {np.flatnonzero((a != b).reshape(a.shape[0], -1).any(axis=1))[:8]}"
+
+
+def controls(rng, n):
+    return (rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-0.2, 1, n).astype(np.float32),
+            (rng.uniform(0, 1, n) * (rng.uniform(0, 1, n) < 0.1)).astype(np.float32))
+
+
+def test_resident_synthetic_and_host_controls_equal_the_oracle(make_env):
+    n = 64
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    rng = np.random.default_rng(1)
+    for env in (g, o):
+        env.step_synthetic(11, 1)
+    assert_state_equal(g, o, "after 11 synthetic steps")
+    assert_frames_equal(g, o, "after 11 synthetic steps")
+    for k in range(9):                                           # more posts than ring slots
+        st, th, br = controls(rng, n)
+        rs = (rng.uniform(0, 1, n) < 0.05) if k == 4 else None
+        for env in (g, o):
+            env.step(st, th, br, reset=rs)
+    assert_state_equal(g, o, "after host-controlled steps")
+    assert_frames_equal(g, o, "after host-controlled steps")
+    assert g.fetch("stats")[2] == 0
+
+
+def test_resident_1024_envs_many_steps_in_flight(make_env):
+    """BASELINE configs[2] shape: 1024 envs (4 per workgroup, one workgroup per CU), posts queued 8 deep."""
+    n = 1024
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    for env in (g, o):
+        env.step_synthetic(48, 1)
+    assert_state_equal(g, o, "1024 envs x 48")
+    assert_frames_equal(g, o, "1024 envs x 48")
+    for env in (g, o):
+        env.step_synthetic(1, 1)                                 # odd step count: the other frame buffer
+    assert_frames_equal(g, o, "1024 envs x 49")
+
+
+def test_resident_device_controls_rewritten_in_place(make_env):
+    """Controls produced on the device by another stream into the SAME arrays every step (what a policy does): no step may
+    see the values an earlier step read from those addresses."""
+    torch = pytest.importorskip("torch")
+    n = 512
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    rng = np.random.default_rng(2)
+    d_st, d_th, d_br = (torch.zeros(n, device="cuda") for _ in range(3))
+    for k in range(40):
+        st, th, br = controls(rng, n)
+        d_st.copy_(torch.from_numpy(st)); d_th.copy_(torch.from_numpy(th)); d_br.copy_(torch.from_numpy(br))
+        d_st.mul_(1.0)                                           # a kernel of torch's stream is the last writer
+        torch.cuda.synchronize()
+        g.step_device(d_st.data_ptr(), d_th.data_ptr(), d_br.data_ptr())
+        g.sync()                                                 # the step has consumed them before they are rewritten
+        o.step(st, th, br)
+        if k % 13 == 12:
+            assert_state_equal(g, o, f"device controls, step {k}")
+    assert_state_equal(g, o, "device controls")
+    assert_frames_equal(g, o, "device controls")
+    frames = torch.as_tensor(g.device_array("img"), device="cuda")         # a consumer kernel launched after trs_sync sees the frame
+    assert np.array_equal(frames.cpu().numpy(), o.fetch("img"))
+
+
+def test_resident_tick_loop_with_fetch_every_step(make_env):
+    """The N = 1 Car-loop pattern: step, take the whole output tuple, step ... with the worker resident throughout."""
+    g, o = make_env("hip", n_envs=1), make_env("oracle", n_envs=1)
+    g.set_step_mode(True)
+    rng = np.random.default_rng(3)
+    for k in range(60):
+        st, th = float(rng.uniform(-1, 1)), float(rng.uniform(0, 1))
+        for env in (g, o):
+            env.step(st, th, 0.0, reset=(k == 30))
+        a, b = g.fetch_outputs(), o.fetch_outputs()
+        assert np.array_equal(a[0], b[0]), f"frame, tick {k}"
+        for x, y in zip(a[1:6], b[1:6]):
+            assert np.max(np.abs(x - y)) <= 1e-5
+        assert np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+
+
+def test_resident_mixed_with_launches_resets_and_idle_exit(make_env):
+    n = 96
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True, idle_us=300)
+    rng = np.random.default_rng(4)
+    for env in (g, o):
+        env.step_synthetic(5, 1)
+    time.sleep(0.05)                                             # the worker leaves by itself (idle) ...
+    for env in (g, o):
+        env.step_synthetic(3, 1)                                 # ... and the next post starts it again
+    assert_state_equal(g, o, "after the idle exit")
+    mask = rng.uniform(0, 1, n) < 0.3
+    for env in (g, o):
+        env.reset(mask)                                          # needs the stream: the worker is asked to leave first
+        env.step_synthetic(4, 1)
+    assert_state_equal(g, o, "after a reset between resident steps")
+    g.set_step_mode(False)
+    for env in (g, o):
+        env.step_synthetic(6, 2)                                 # launches (pipelined) on the state the worker left
+    g.set_step_mode(True)
+    st, th, br = controls(rng, n)
+    for env in (g, o):
+        env.step(st, th, br, n_steps=3)                          # held controls: three posts
+        env.step_synthetic(2, 1)
+    assert_state_equal(g, o, "resident -> launches -> resident")
+    assert_frames_equal(g, o, "resident -> launches -> resident")
+
+
+@pytest.mark.parametrize("n,h,w,depth", [(2048, 120, 160, False), (24, 240, 320, True), (300, 60, 80, True)])
+def test_resident_shapes(make_env, n, h, w, depth):
+    """Several envs per workgroup (state in LDS, step-major physics), the depth frame, ragged last workgroup."""
+    kw = dict(n_envs=n, img_h=h, img_w=w, depth=depth, auto_reset=True)
+    g, o = make_env("hip", **kw), make_env("oracle", **kw)
+    g.set_step_mode(True)
+    for env in (g, o):
+        env.step_synthetic(13, 1)
+    assert_state_equal(g, o, f"{n} envs {h}x{w}")
+    assert_frames_equal(g, o, f"{n} envs {h}x{w}")
+    if depth:
+        assert np.array_equal(g.fetch("depth").view(np.uint32), o.fetch("depth").view(np.uint32))
+
+
+def test_resident_sequence_and_mode_errors(make_env, hip_api):
+    n = 32
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    rng = np.random.default_rng(5)
+    k = 11
+    st = rng.uniform(-1, 1, (k, n)).astype(np.float32)
+    th = rng.uniform(0, 1, (k, n)).astype(np.float32)
+    for env in (g, o):
+        env.step_sequence(st, th, steps_per_launch=4)
+    assert_state_equal(g, o, "sequence through the worker")
+    assert_frames_equal(g, o, "sequence through the worker")
+    p = make_env("hip", n_envs=4, render=False)
+    with pytest.raises(RuntimeError):
+        p.set_step_mode(True)                                    # no camera: refused
+    assert hip_api.set_step_mode(g._h, 7, 0) != 0

@@ -1,0 +1,509 @@
+// trsim_device.hpp — device-side pieces shared by the step kernels (trsim_hip.hip) and the resident worker
+// (trsim_resident.hip): the spec's arithmetic (include/trsim_spec.h), the wave-parallel nearest-point search
+// (= reference LocationTracker.__find_closest, components/track_data_process.py:89-104), one env step on registers, and the
+// per-thread raster walk.  Everything is force-inlined; both translation units compile their own copy.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/trsim.h"
+#include "../../include/trsim_spec.h"
+
+#ifndef TRS_ABLATE
+#define TRS_ABLATE 0   /* 0 = product; 1/2 = timing-only diagnostic builds (scripts/ablate.sh), never shipped */
+#endif
+
+namespace trsim {
+
+struct PParams {                        // physics kernel
+    float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
+    int32_t *seg_idx, *ep_len;
+    uint8_t *done, *pending;
+    const float *ctl_steer, *ctl_thr, *ctl_brk;
+    const uint8_t* ctl_reset;
+    int ctl_stride;                     // elements between the control arrays of consecutive steps of a launch (0 = the same controls every step)
+    float4* cam;                        // [kRing][n_envs] camx, camz, sin, cos (cell units) for the raster kernel
+    const unsigned char* blob;          // physics LDS image: px | py | pz | tangent
+    const float* start_yaw;             // [np]
+    const float* tangent_g;             // [np][2] global copy, used when the table does not fit in LDS
+    unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
+    int n_envs, env_id_base, envs_per_wg, np;
+    int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
+    int off_gstart, off_gpts, grid_nx, grid_nz;   // nearest-point accelerator: uint16 cell starts / point lists in the LDS image
+    double grid_x0, grid_z0;
+    float map_x0f, map_z0f, inv_cellf;
+    float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
+    float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
+    int auto_reset, synth, n_steps, write_cam;
+    uint32_t step_off;
+    unsigned long long seed;
+};
+
+struct RParams {                        // raster side of the step kernel
+    const unsigned char* blob;          // raster LDS image: map (pitched rows) @0 | rowtab | palette
+    unsigned long long* stats;
+    int n_envs, envs_per_wg;
+    int H, W, gpr, gpe, rows_per_pass;  // gpr/gpe: 4-pixel groups per row / per env
+    int map_w, map_h, map_pitch_b;
+    int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
+    int depth;                          // 1 = also write the binary32 z-depth frame
+    int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane)
+};
+
+}  // namespace trsim
+
+namespace {
+
+#ifndef TRS_RASTER_WAVES
+#define TRS_RASTER_WAVES 8    /* raster waves per workgroup: 512 threads = 12 full rows of 40 groups per pass, 10 passes exactly at 120x160, and 12 waves balance over the 4 SIMDs (10 + 5 waves: 72.5 M env-steps/s, 8 + 4: 77.0 M; profiles/r01_step_kernel_waves_ab.txt) */
+#endif
+#ifndef TRS_PHYS_WAVES
+#define TRS_PHYS_WAVES 4      /* physics waves per workgroup: one env per wave at 1024 envs */
+#endif
+constexpr int kBlock = 64 * (TRS_RASTER_WAVES + TRS_PHYS_WAVES);   // 12 waves
+constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
+constexpr int kRing = 4;               // global camera-parameter ring: the last step of launch i is the first frame of launch i+1
+[[maybe_unused]] constexpr int kRasterStampThread = 64 * TRS_RASTER_WAVES;  // diagnostic stamps: wave 0 and the first physics wave
+constexpr int kRasterThreads = 64 * TRS_RASTER_WAVES;
+constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;
+
+using trsim::PParams;
+using trsim::RParams;
+
+// ---------------------------------------------------------------------------------------------
+// device pieces of the spec
+
+__device__ __forceinline__ void spec_sincos(float a, float& so, float& co)
+{
+    const float q = rintf(a * TRS_TWO_OVER_PI);
+    float r = fmaf(q, -TRS_PIO2_HI, a);
+    r = fmaf(q, -TRS_PIO2_LO, r);
+    const float zz = r * r;
+    const float ps = fmaf(fmaf(TRS_S0, zz, TRS_S1), zz, TRS_S2);
+    const float s = fmaf(r * zz, ps, r);
+    const float pc = fmaf(fmaf(TRS_C0, zz, TRS_C1), zz, TRS_C2);
+    const float c = fmaf(zz * zz, pc, fmaf(zz, -0.5f, 1.0f));
+    const int n = ((int)q) & 3;
+    so = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
+    co = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
+}
+
+__device__ __forceinline__ float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
+
+// wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.
+// DPP reduction (row_shr 1,2,4,8 then row_bcast15 / row_bcast31): data moves through the VALU's DPP path
+// instead of the LDS crossbar that __shfl (ds_bpermute) uses.  The wave's result ends in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmin_dpp_step(double& d, int& i)
+{
+    const int lo = __double2loint(d), hi = __double2hiint(d);
+    // lanes without a valid source (row edge / masked rows) read their own value: combining with self is a no-op
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    const double od = __hiloint2double(ohi, olo);
+    const bool take = (od < d) || (od == d && oi < i);
+    d = take ? od : d;
+    i = take ? oi : i;
+}
+
+__device__ __forceinline__ void wave_argmin(double& d, int& i)
+{
+    argmin_dpp_step<0x111, 0xf>(d, i);   // row_shr:1
+    argmin_dpp_step<0x112, 0xf>(d, i);   // row_shr:2
+    argmin_dpp_step<0x114, 0xf>(d, i);   // row_shr:4
+    argmin_dpp_step<0x118, 0xf>(d, i);   // row_shr:8   -> lane 15 of each row holds the row's result
+    argmin_dpp_step<0x142, 0xa>(d, i);   // row_bcast:15 into rows 1 and 3
+    argmin_dpp_step<0x143, 0xc>(d, i);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+}
+
+__device__ __forceinline__ unsigned cvt_u32_sat(float x)
+{
+    // v_cvt_u32_f32: truncate toward zero, saturate (negative / NaN -> 0).  For the rasteriser's
+    // clamp(floor(g), 0, G-1) this equals min(cvt_u32_sat(g), G-1): g < 0 -> 0, g >= 0 -> trunc == floor.
+    unsigned r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__device__ __forceinline__ void synth_controls(unsigned long long seed, uint32_t gid, uint32_t step, float& sf, float& steer, float& thr)
+{
+    unsigned long long z = seed + (((unsigned long long)gid << 32) | (unsigned long long)step) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float us = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+    const float ut = (float)(uint32_t)((z >> 16) & 0xFFFFFFu) * 5.9604644775390625e-08f;
+    const float raw = us * 2.0f - 1.0f;
+    sf = sf + TRS_SYNTH_ALPHA * (raw - sf);
+    steer = sf;
+    thr = TRS_SYNTH_THR_LO + TRS_SYNTH_THR_SPAN * ut;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));   // 16-B register tuple (HIP's uint4 struct defeats SROA here)
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+
+#ifndef TRS_STORE_AUX
+#define TRS_STORE_AUX 17   /* cache policy of the image stores: 0 plain, 2 nt, 16 sc1, 17 sc0 sc1 (write-through: the frame streams to HBM while the kernel computes instead of being flushed from L2 at kernel end; +13% at 1024 envs, profiles/r01_store_policy_ab.txt) */
+#endif
+
+// one wave advances one env (all lanes compute the same scalars; the track scan is lane-parallel)
+template <typename T>
+__device__ __forceinline__ T coherent_load(const T* ptr)
+{   // vector load that bypasses the per-CU L1 and the scalar cache: inside a K-step launch the value may have been
+    // stored by lane 0 of this wave one step earlier
+    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Nearest raw track point of (qx, qy, qz) by one wave: binary64 L1, strict '<' with the lowest index winning ties
+// (reference LocationTracker.__find_closest, components/track_data_process.py:89-104).  First the 3x3 block of 4-unit
+// cells around the query (typically ~100 of the 1185 points); a block result below one cell size is provably the global
+// one (include/trsim_spec.h R3), otherwise every point is scanned.  All lanes get the result.
+struct NearParams { int np, off_py, off_pz, off_gstart, off_gpts, nx, nz; double x0, z0; };
+
+__device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned char* lphys, double qx, double qy, double qz, int lane,
+                                             double& best_out, int& idx_out)
+{
+    const double* lpx = reinterpret_cast<const double*>(lphys);
+    const double* lpy = reinterpret_cast<const double*>(lphys + g.off_py);
+    const double* lpz = reinterpret_cast<const double*>(lphys + g.off_pz);
+    if (g.nx > 0) {
+        const double fx = floor((qx - g.x0) * (1.0 / TRS_NEAR_GRID_CELL)), fz = floor((qz - g.z0) * (1.0 / TRS_NEAR_GRID_CELL));
+        if (fx >= -1.0 && fx <= (double)g.nx && fz >= -1.0 && fz <= (double)g.nz) {
+            const unsigned short* gstart = reinterpret_cast<const unsigned short*>(lphys + g.off_gstart);
+            const unsigned short* gpts = reinterpret_cast<const unsigned short*>(lphys + g.off_gpts);
+            const int cx = (int)fx, cz = (int)fz;
+            const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.nx - 1);
+            double best = TRS_LOST_L1;
+            int bi = 0;
+            if (x_lo <= x_hi)
+                for (int rz = max(cz - 1, 0); rz <= min(cz + 1, g.nz - 1); ++rz) {
+                    const int lo = gstart[rz * g.nx + x_lo], hi = gstart[rz * g.nx + x_hi + 1];      // the three cells of a row are contiguous
+                    for (int i = lo + lane; i < hi; i += 64) {
+                        const int idx = gpts[i];
+                        const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
+                        if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
+                    }
+                }
+            wave_argmin(best, bi);
+            const int idx = __builtin_amdgcn_readlane(bi, 63);
+            const double bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+            if (bd < TRS_NEAR_GRID_CELL) { best_out = bd; idx_out = idx; return; }
+        }
+    }
+    double best = TRS_LOST_L1;
+    int bi = 0;
+    int i = lane;
+    for (; i + 64 < g.np; i += 128) {                       // two points per trip: the LDS reads of one overlap the arithmetic of the other
+        const int i2 = i + 64;
+        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
+        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
+        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
+        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
+        if (d1 < best) { best = d1; bi = i; }
+        if (d2 < best) { best = d2; bi = i2; }
+    }
+    if (i < g.np) {
+        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
+        if (d1 < best) { best = d1; bi = i; }
+    }
+    wave_argmin(best, bi);
+    idx_out = __builtin_amdgcn_readlane(bi, 63);
+    best_out = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
+}
+
+__device__ __forceinline__ NearParams near_of(const PParams& p)
+{
+    return NearParams{p.np, p.off_py, p.off_pz, p.off_gstart, p.off_gpts, p.grid_nx, p.grid_nz, p.grid_x0, p.grid_z0};
+}
+
+// Per-env state held in registers by the wave that owns the env (every lane holds the same values).
+struct EnvRegs {
+    float x, y, z, yaw, v, sf, epr, speed, cte;
+    int seg, epl, done, pend;
+};
+
+__device__ __forceinline__ void env_load(const PParams& p, int e, EnvRegs& s)
+{
+    s.pend = coherent_load(&p.pending[e]); s.done = coherent_load(&p.done[e]);
+    s.sf = coherent_load(&p.steer_filt[e]);
+    s.x = coherent_load(&p.x[e]); s.y = coherent_load(&p.y[e]); s.z = coherent_load(&p.z[e]);
+    s.yaw = coherent_load(&p.yaw[e]); s.v = coherent_load(&p.v[e]);
+    s.seg = coherent_load(&p.seg_idx[e]);
+    s.epr = coherent_load(&p.ep_return[e]);
+    s.epl = coherent_load(&p.ep_len[e]);
+    s.speed = 0.f; s.cte = 0.f;
+}
+
+__device__ __forceinline__ void env_store(const PParams& p, int e, const EnvRegs& s, int lane)
+{
+    if (lane == 0) {
+        p.x[e] = s.x; p.y[e] = s.y; p.z[e] = s.z; p.yaw[e] = s.yaw; p.v[e] = s.v;
+        p.speed[e] = s.speed; p.cte[e] = s.cte; p.seg_idx[e] = s.seg; p.done[e] = (uint8_t)s.done;
+        p.ep_return[e] = s.epr; p.ep_len[e] = s.epl; p.steer_filt[e] = s.sf; p.pending[e] = (uint8_t)s.pend;
+    }
+}
+// What one env step hands on besides the new state: the camera parameters of the new pose (map-cell units) and the flags.
+struct StepOut { float4 cam; int is_done, do_reset; };
+
+template <bool WT, typename T>
+__device__ __forceinline__ void store_out(T* ptr, T v)
+{   // WT: write-through at system scope (sc0 sc1) — the resident worker's outputs are read by other agents while the kernel
+    // is still running, so nothing may sit dirty in this XCD's L2
+    if constexpr (WT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else *ptr = v;
+}
+
+// One wave advances one env by one step on registers (include/trsim_spec.h, "one env step"): every lane computes the same
+// scalars, the track scan is lane-parallel.  Controls are this step's (already fetched; generated here when `synth`); `rin` =
+// the user's reset request.  Side effects: last_return[e] on a reset, nothing else.
+template <bool WT>
+__device__ __forceinline__ void env_advance(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int synth,
+                                            float steer, float thr, float brk, uint8_t rin, int lane, StepOut& o)
+{
+    const double* lpx = reinterpret_cast<const double*>(lphys);
+    const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
+    const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
+    const float2* ltan = reinterpret_cast<const float2*>(lphys + p.off_tan);
+    const int gid = p.env_id_base + e;
+    float sf = s.sf;
+    const int prev_idx = s.seg;
+    float epr = s.epr;
+    int epl = s.epl;
+    const int do_reset = (s.pend != 0) || (rin != 0) || (p.auto_reset && s.done != 0);
+    float x1, y0, z1, yaw1, v2, hs, hc;
+    if (do_reset) {
+        const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
+        x1 = (float)lpx[si]; y0 = (float)lpy[si]; z1 = (float)lpz[si];
+        yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
+        spec_sincos(yaw1, hs, hc);
+    } else {
+        if (synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
+        steer = clampf(steer, -1.0f, 1.0f);
+        thr = clampf(thr, -1.0f, 1.0f);
+        brk = clampf(brk, 0.0f, 1.0f);
+        float sd, cd;
+        spec_sincos(steer * p.max_steer, sd, cd);
+        const float tan_d = sd / cd;
+        const float a = thr * p.accel_max - p.drag_lin * s.v;
+        const float v1 = s.v + a * p.dt;
+        const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
+        if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
+        else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
+        else v2 = 0.0f;
+        v2 = clampf(v2, -p.v_rev_max, p.v_max);
+        yaw1 = s.yaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
+        if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
+        if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
+        spec_sincos(yaw1, hs, hc);
+        x1 = s.x + (v2 * hs) * p.dt;
+        z1 = s.z + (v2 * hc) * p.dt;
+        y0 = s.y;
+    }
+    double bestd;
+    int idx;
+    wave_nearest(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
+
+    const float y1 = (float)lpy[idx];
+    // the tangent sits in LDS or (long tracks) in global memory: two typed loads — one load through a selected pointer is a flat
+    // load, which waits on both memory counters
+    typedef __attribute__((address_space(3))) const float2* lds_f2p;
+    typedef __attribute__((address_space(1))) const float2* glb_f2p;
+    float2 tg;
+    if (p.tan_in_lds) tg = *(lds_f2p)(uintptr_t)((unsigned)(uintptr_t)ltan + ((unsigned)idx << 3));
+    else tg = *(glb_f2p)(uintptr_t)(p.tangent_g + 2 * (size_t)idx);
+    const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
+    const bool lost = bestd >= TRS_LOST_L1;
+    const int is_done = (fabsf(cte) > p.offtrack_cte) || lost;
+    if (do_reset) {
+        if (lane == 0) store_out<WT>(&p.last_return[e], epr);
+        epr = 0.0f; epl = 0;
+    } else {
+        int d = idx - prev_idx;
+        const int half = p.np / 2;
+        if (d >= p.np - half) d -= p.np;
+        if (d < -half) d += p.np;
+        const float reward = (float)d - (is_done ? p.offtrack_penalty : 0.0f);
+        epr = epr + reward;
+        epl += 1;
+    }
+    s.x = x1; s.y = y1; s.z = z1; s.yaw = yaw1; s.v = v2; s.sf = sf; s.epr = epr; s.epl = epl;
+    s.speed = fabsf(v2); s.cte = cte; s.seg = idx; s.done = is_done; s.pend = 0;
+    const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
+    const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
+    o.cam = make_float4(camx, camz, hs, hc);
+    o.is_done = is_done; o.do_reset = do_reset;
+}
+
+// ... inside the step kernels: controls from the launch's arrays, camera parameters to the global ring (the next launch's
+// first frame) and to this launch's LDS ring, then the progress counter the raster team waits on.
+__device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
+                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane)
+{
+    const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
+    float steer = 0.f, thr = 0.f, brk = 0.f;
+    if (!p.synth) {
+        const size_t ci = (size_t)k * (size_t)p.ctl_stride + (size_t)e;
+        steer = p.ctl_steer[ci]; thr = p.ctl_thr[ci]; brk = p.ctl_brk ? p.ctl_brk[ci] : 0.0f;
+    }
+    StepOut o;
+    env_advance<false>(p, lphys, e, s, t, p.synth, steer, thr, brk, rin, lane, o);
+    if (lane == 0) {
+        if (p.write_cam) cam_out[e] = o.cam;                // for the next launch (its first frame)
+        *lcam_slot = o.cam;                                 // for this launch's raster team
+        if (o.is_done) atomicAdd(&p.stats[0], 1ull);
+        if (o.do_reset) atomicAdd(&p.stats[1], 1ull);
+        __hip_atomic_store(pprog_j, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish: step k of this env is done
+    }
+}
+
+// (dx, dz) of a row as two scalar multiplies.  The packed form (v_pk_mul_f32 with the row-table register pair as source AND
+// destination) returned +-0 for dx in lanes 48..63 of one row pass now and then, but only while workgroups of other kernels
+// shared the CU (scripts/det_probe*.py: 1-3 % of the steps beside a pilot loop on another stream; never alone).  Same
+// IEEE products, so results are unchanged.
+__device__ __forceinline__ f2v ray_step(f2v kk2, f2v cns)
+{
+#ifdef TRS_PACKED_RAY_STEP
+    return kk2 * cns;
+#else
+    float dx, dz;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(dx) : "v"(kk2.x), "v"(cns.x));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(dz) : "v"(kk2.y), "v"(cns.y));
+    return f2v{dx, dz};
+#endif
+}
+
+// ---- the raster walk of one thread ----------------------------------------------------------------------------------
+// A thread owns one 4-pixel column group (u0 fixed) and walks image rows `rows_per_pass` apart, so the pixel-centre offsets
+// are loop constants.  The first `uni_rows` rows (sky, ground beyond the far plane) have four equal class colours and need
+// neither the class map nor the camera pose.  Per pixel of the other rows: 1 packed fma (gx, gz), 2 saturating converts + 2
+// min (= floor + clamp), 3 address ops, 1 LDS map read (the map lives at LDS offset 0), shift + bit-field extract, 1 palette
+// address op, 1 LDS palette read; 4 pixels -> 12 bytes with v_perm_b32 and ONE buffer_store_dwordx3 per lane (768 contiguous
+// bytes = 6 full 128-B lines per wave instruction), write-through.
+struct RasterThread {
+    const f2v* lrow;
+    const float* lrowdepth;
+    f2v ufa, ufb, ufc, ufd;
+    unsigned gwm1, ghm1, pitch;
+    int cg, vstart, vground, col_off, row_bytes;
+};
+
+__device__ __forceinline__ RasterThread raster_thread(const RParams& p, const unsigned char* lds, int tid)
+{
+    RasterThread t;
+    t.lrow = reinterpret_cast<const f2v*>(lds + p.off_rowtab);
+    t.lrowdepth = reinterpret_cast<const float*>(lds + p.off_depth);
+    const float half_w = (float)(p.W / 2);
+    t.gwm1 = (unsigned)(p.map_w - 1); t.ghm1 = (unsigned)(p.map_h - 1);
+    t.cg = tid % p.gpr;
+    const int r0 = tid / p.gpr;                          // threads with r0 >= rows_per_pass idle (32 of 512 at W = 160: 12 x 40 = 480)
+    const float uf0 = (float)(t.cg << 2) + 0.5f - half_w;
+    t.ufa = f2v{uf0, uf0}; t.ufb = f2v{uf0 + 1.0f, uf0 + 1.0f}; t.ufc = f2v{uf0 + 2.0f, uf0 + 2.0f}; t.ufd = f2v{uf0 + 3.0f, uf0 + 3.0f};
+    t.pitch = (unsigned)p.map_pitch_b;
+    t.vstart = r0 < p.rows_per_pass ? r0 : p.H;
+    t.vground = t.vstart;                                // this thread's first row that needs the map
+    while (t.vground < p.uni_rows) t.vground += p.rows_per_pass;
+    t.row_bytes = p.gpr * 12;
+    t.col_off = t.cg * 12;
+    return t;
+}
+
+// the frame (and z-depth frame) of env e as buffer descriptors: stores carry the cache-policy bits TRS_STORE_AUX
+struct FrameDesc { __amdgpu_buffer_rsrc_t rgb, dep; };
+
+template <bool DEPTH>
+__device__ __forceinline__ FrameDesc frame_desc(const RParams& p, uint8_t* img, float* dep, int e)
+{
+    FrameDesc f;
+    f.rgb = __builtin_amdgcn_make_buffer_rsrc(img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+    f.dep = f.rgb;
+    if constexpr (DEPTH) f.dep = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+    return f;
+}
+
+// rows with four equal class colours: one palette read per 4 pixels, no map lookup, no pose
+template <bool DEPTH>
+__device__ __forceinline__ void raster_uniform_rows(const RParams& p, const RasterThread& t, const FrameDesc& f)
+{
+    for (int v = t.vstart; v < p.uni_rows; v += p.rows_per_pass) {
+        const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)v << 4));
+        const u3v px3 = {__builtin_amdgcn_perm(c, c, 0x04020100u), __builtin_amdgcn_perm(c, c, 0x05040201u), __builtin_amdgcn_perm(c, c, 0x06050402u)};
+        __builtin_amdgcn_raw_buffer_store_b96(px3, f.rgb, t.col_off + v * t.row_bytes, 0, TRS_STORE_AUX);
+        if constexpr (DEPTH) {
+            const unsigned dz = __float_as_uint(t.lrowdepth[v]);
+            const u4v d4 = {dz, dz, dz, dz};
+            __builtin_amdgcn_raw_buffer_store_b128(d4, f.dep, (t.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+        }
+    }
+}
+
+// rows that see the track, from the camera parameters (camx, camz, sin, cos) of the env's pose
+template <bool DEPTH>
+__device__ __forceinline__ void raster_ground_rows(const RParams& p, const RasterThread& t, const FrameDesc& f, const float4 cam)
+{
+    const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
+    f2v rt = t.lrow[t.vground < p.H ? t.vground : 0];
+    for (int v = t.vground; v < p.H; v += p.rows_per_pass) {
+        const int vn = v + p.rows_per_pass;
+        const f2v rtn = t.lrow[vn < p.H ? vn : v];                          // prefetch the next row's table entry
+        const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
+        const f2v d = ray_step(kk2, cns);                                  // (dx, dz) = (k*c, -(k*s))
+        auto shade = [&](f2v uf) -> uint32_t {
+            const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
+            const unsigned ix = min(cvt_u32_sat(g.x), t.gwm1);
+            const unsigned iz = min(cvt_u32_sat(g.y), t.ghm1);
+            const unsigned xoff = (ix >> 2) & ~3u;                          // byte offset of the map word in its row
+            unsigned waddr, paddr;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(t.pitch), "v"(xoff));
+            const uint32_t w = *(lds_u32p)(uintptr_t)waddr;                 // map lives at LDS offset 0 (checked by the kernels)
+            const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);      // offset uses bits [4:0] = 2*(ix&15)
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(paddr) : "v"(cls), "v"(pal_a));
+            return *(lds_u32p)(uintptr_t)paddr;
+        };
+#if TRS_ABLATE == 2   /* diagnostic build: stores only */
+        const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
+#else
+        const uint32_t c0p = shade(t.ufa), c1p = shade(t.ufb), c2p = shade(t.ufc), c3p = shade(t.ufd);
+#endif
+        // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
+        const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
+        const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
+        const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
+#if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
+        asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)f;
+#else
+        const u3v px3 = {w0, w1, w2};
+        __builtin_amdgcn_raw_buffer_store_b96(px3, f.rgb, t.col_off + v * t.row_bytes, 0, TRS_STORE_AUX);
+        if constexpr (DEPTH) {   // z-depth is constant along a row of a ground-plane camera: 4 pixels = one 16-B store
+            const unsigned dz = __float_as_uint(t.lrowdepth[v]);
+            const u4v d4 = {dz, dz, dz, dz};
+            __builtin_amdgcn_raw_buffer_store_b128(d4, f.dep, (t.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+        }
+#endif
+        rt = rtn;
+    }
+}
+
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves 64 lanes x 16 B = 1 KB, lane-linear, no
+// registers and no ds_write pass): `n_waves` waves share the pieces of `bytes` (a multiple of 16), wave `w` of them issues
+// its own; the caller waits (s_waitcnt vmcnt(0)) and closes the stage with a barrier.
+__device__ __forceinline__ void stage_lds_dma(const unsigned char* blob, int bytes, unsigned lds_byte_addr, int w, int n_waves, int lane)
+{
+    const u4v* src = reinterpret_cast<const u4v*>(blob);
+    const int n16 = bytes >> 4;
+    for (int g0 = w * 64; g0 < n16; g0 += n_waves * 64) {
+        const int g = g0 + lane;
+        if (g < n16)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)(lds_byte_addr + g0 * 16), 16, 0, 0);
+    }
+}
+
+}  // namespace

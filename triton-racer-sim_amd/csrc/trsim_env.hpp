@@ -1,0 +1,67 @@
+// trsim_env.hpp — the handle behind `trs_env*` (include/trsim.h), shared by the translation units of libtrsim.so.
+// Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/trsim.h"
+#include "trsim_device.hpp"
+#include "trsim_tables.hpp"
+
+namespace trsim { struct Resident; }
+
+struct trs_env {
+    trs_config cfg{};
+    int device = 0, n = 0, H = 0, W = 0, cu_count = 0;
+    hipStream_t sP = nullptr;            // the handle's stream: every launch, copy and timing event
+    hipEvent_t ev[8] = {};
+    // device memory
+    unsigned char* slab = nullptr;       // state + controls
+    uint8_t* img[2] = {nullptr, nullptr};
+    float* depth[2] = {nullptr, nullptr};
+    unsigned char* blob_p = nullptr;     // physics LDS image
+    unsigned char* blob_r = nullptr;     // raster LDS image
+    float* tangent = nullptr;
+    float* start_yaw = nullptr;
+    float4* cam = nullptr;               // [kRing][n]
+    unsigned long long* stats = nullptr;
+    double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
+    uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
+    trs_pre_config frame_filter{}; bool has_frame_filter = false, filter_dynamic = false;   // trs_set_frame_filter
+    unsigned char* pinned = nullptr; size_t pinned_bytes = 0;   // trs_fetch_outputs staging (hipHostMalloc)
+    int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
+    uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
+    int* hsv_tab = nullptr;
+    unsigned char* edge_scratch = nullptr; size_t edge_scratch_bytes = 0;   // work arrays of the Canny layer for frames beyond LDS
+    trsim::PParams pp{};
+    trsim::RParams rp{};
+    trsim::TrackTables tab;
+    bool track_loaded = false;
+    int lds_p = 0, lds_r = 0, pts_bytes = 0;
+    uint64_t step_count = 0;
+    float *ctl_steer = nullptr, *ctl_thr = nullptr, *ctl_brk = nullptr;
+    uint8_t* ctl_reset = nullptr;
+    size_t img_bytes = 0;
+    int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
+    float* seq_buf = nullptr; size_t seq_cap = 0;   // device copy of host control sequences (trs_step_sequence_host)
+    int seq_stride = 0;                  // trs_step_sequence: n_envs while a sequence call is running, else 0
+    int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
+    void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
+    float* glue = nullptr; size_t glue_bytes = 0;   // device scratch of the *_host control glue (trs_driver_assist_host, trs_control_mux_host)
+    trsim::Resident* res = nullptr;      // trsim_resident.hip: the resident worker (trs_set_step_mode), nullptr = never used
+};
+
+// ---- trsim_resident.hip (the resident worker: one step per trs_step call without a launch per step) ----
+namespace trsim {
+bool resident_on(const trs_env* e);                       // resident mode selected for this handle
+// hand n steps to the worker; controls as in trs_step (device pointers, or host-pinned pointers the device can read);
+// stride: elements between consecutive steps' control arrays (0 = held), synth: controls from the spec's generator
+int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride);
+int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps);
+hipStream_t resident_copy_stream(trs_env* e);             // a stream that is not blocked by the worker (the handle's own when none runs)
+int resident_wait(trs_env* e);                            // every posted step complete (the worker stays resident)
+int resident_quiesce(trs_env* e);                         // ... and the worker has left the GPU: the stream is free again
+void resident_destroy(trs_env* e);
+}  // namespace trsim

@@ -33,134 +33,17 @@
 
 #include "../../include/trsim.h"
 #include "../../include/trsim_spec.h"
+#include "trsim_device.hpp"
+#include "trsim_env.hpp"
 #include "trsim_internal.hpp"
 #include "trsim_tables.hpp"
 
-#ifndef TRS_ABLATE
-#define TRS_ABLATE 0   /* 0 = product; 1/2 = timing-only diagnostic builds (scripts/ablate.sh), never shipped */
-#endif
 
 #define TRS_EXPORT extern "C" __attribute__((visibility("default")))
 
 namespace {
 
-#ifndef TRS_RASTER_WAVES
-#define TRS_RASTER_WAVES 8    /* raster waves per workgroup: 512 threads = 12 full rows of 40 groups per pass, 10 passes exactly at 120x160, and 12 waves balance over the 4 SIMDs (10 + 5 waves: 72.5 M env-steps/s, 8 + 4: 77.0 M; profiles/r01_step_kernel_waves_ab.txt) */
-#endif
-#ifndef TRS_PHYS_WAVES
-#define TRS_PHYS_WAVES 4      /* physics waves per workgroup: one env per wave at 1024 envs */
-#endif
-constexpr int kBlock = 64 * (TRS_RASTER_WAVES + TRS_PHYS_WAVES);   // 12 waves
-constexpr int kLocBlock = 1024;        // locate kernel: 16 waves = 16 queries in flight per workgroup
-constexpr int kRing = 4;               // global camera-parameter ring: the last step of launch i is the first frame of launch i+1
-[[maybe_unused]] constexpr int kRasterStampThread = 64 * TRS_RASTER_WAVES;  // diagnostic stamps: wave 0 and the first physics wave
 
-struct PParams {                        // physics kernel
-    float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
-    int32_t *seg_idx, *ep_len;
-    uint8_t *done, *pending;
-    const float *ctl_steer, *ctl_thr, *ctl_brk;
-    const uint8_t* ctl_reset;
-    int ctl_stride;                     // elements between the control arrays of consecutive steps of a launch (0 = the same controls every step)
-    float4* cam;                        // [kRing][n_envs] camx, camz, sin, cos (cell units) for the raster kernel
-    const unsigned char* blob;          // physics LDS image: px | py | pz | tangent
-    const float* start_yaw;             // [np]
-    const float* tangent_g;             // [np][2] global copy, used when the table does not fit in LDS
-    unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
-    int n_envs, env_id_base, envs_per_wg, np;
-    int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
-    int off_gstart, off_gpts, grid_nx, grid_nz;   // nearest-point accelerator: uint16 cell starts / point lists in the LDS image
-    double grid_x0, grid_z0;
-    float map_x0f, map_z0f, inv_cellf;
-    float dt, max_steer, inv_wheelbase, accel_max, drag_lin, roll_res, brake_max;
-    float v_max, v_rev_max, offtrack_cte, offtrack_penalty, cam_fwd;
-    int auto_reset, synth, n_steps, write_cam;
-    uint32_t step_off;
-    unsigned long long seed;
-};
-
-struct RParams {                        // raster side of the step kernel
-    const unsigned char* blob;          // raster LDS image: map (pitched rows) @0 | rowtab | palette
-    unsigned long long* stats;
-    int n_envs, envs_per_wg;
-    int H, W, gpr, gpe, rows_per_pass;  // gpr/gpe: 4-pixel groups per row / per env
-    int map_w, map_h, map_pitch_b;
-    int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
-    int depth;                          // 1 = also write the binary32 z-depth frame
-    int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane)
-};
-
-// ---------------------------------------------------------------------------------------------
-// device pieces of the spec
-
-__device__ __forceinline__ void spec_sincos(float a, float& so, float& co)
-{
-    const float q = rintf(a * TRS_TWO_OVER_PI);
-    float r = fmaf(q, -TRS_PIO2_HI, a);
-    r = fmaf(q, -TRS_PIO2_LO, r);
-    const float zz = r * r;
-    const float ps = fmaf(fmaf(TRS_S0, zz, TRS_S1), zz, TRS_S2);
-    const float s = fmaf(r * zz, ps, r);
-    const float pc = fmaf(fmaf(TRS_C0, zz, TRS_C1), zz, TRS_C2);
-    const float c = fmaf(zz * zz, pc, fmaf(zz, -0.5f, 1.0f));
-    const int n = ((int)q) & 3;
-    so = (n == 0) ? s : (n == 1) ? c : (n == 2) ? -s : -c;
-    co = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
-}
-
-__device__ __forceinline__ float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
-
-// wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.
-// DPP reduction (row_shr 1,2,4,8 then row_bcast15 / row_bcast31): data moves through the VALU's DPP path
-// instead of the LDS crossbar that __shfl (ds_bpermute) uses.  The wave's result ends in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void argmin_dpp_step(double& d, int& i)
-{
-    const int lo = __double2loint(d), hi = __double2hiint(d);
-    // lanes without a valid source (row edge / masked rows) read their own value: combining with self is a no-op
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
-    const double od = __hiloint2double(ohi, olo);
-    const bool take = (od < d) || (od == d && oi < i);
-    d = take ? od : d;
-    i = take ? oi : i;
-}
-
-__device__ __forceinline__ void wave_argmin(double& d, int& i)
-{
-    argmin_dpp_step<0x111, 0xf>(d, i);   // row_shr:1
-    argmin_dpp_step<0x112, 0xf>(d, i);   // row_shr:2
-    argmin_dpp_step<0x114, 0xf>(d, i);   // row_shr:4
-    argmin_dpp_step<0x118, 0xf>(d, i);   // row_shr:8   -> lane 15 of each row holds the row's result
-    argmin_dpp_step<0x142, 0xa>(d, i);   // row_bcast:15 into rows 1 and 3
-    argmin_dpp_step<0x143, 0xc>(d, i);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
-}
-
-__device__ __forceinline__ unsigned cvt_u32_sat(float x)
-{
-    // v_cvt_u32_f32: truncate toward zero, saturate (negative / NaN -> 0).  For the rasteriser's
-    // clamp(floor(g), 0, G-1) this equals min(cvt_u32_sat(g), G-1): g < 0 -> 0, g >= 0 -> trunc == floor.
-    unsigned r;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-__device__ __forceinline__ void synth_controls(unsigned long long seed, uint32_t gid, uint32_t step, float& sf, float& steer, float& thr)
-{
-    unsigned long long z = seed + (((unsigned long long)gid << 32) | (unsigned long long)step) * 0x9E3779B97F4A7C15ull;
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float us = (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
-    const float ut = (float)(uint32_t)((z >> 16) & 0xFFFFFFu) * 5.9604644775390625e-08f;
-    const float raw = us * 2.0f - 1.0f;
-    sf = sf + TRS_SYNTH_ALPHA * (raw - sf);
-    steer = sf;
-    thr = TRS_SYNTH_THR_LO + TRS_SYNTH_THR_SPAN * ut;
-}
-
-extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 #ifndef TRS_STAMPS
 #define TRS_STAMPS 0   /* 1 = diagnostic build: s_memtime stamps per phase into stats[8..] (scripts/stamps.sh), never shipped */
@@ -178,14 +61,6 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #define STAMP(slot) do { } while (0)
 #endif
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));   // 16-B register tuple (HIP's uint4 struct defeats SROA here)
-typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
-typedef unsigned u3v __attribute__((ext_vector_type(3)));
-
-#ifndef TRS_STORE_AUX
-#define TRS_STORE_AUX 17   /* cache policy of the image stores: 0 plain, 2 nt, 16 sc1, 17 sc0 sc1 (write-through: the frame streams to HBM while the kernel computes instead of being flushed from L2 at kernel end; +13% at 1024 envs, profiles/r01_store_policy_ab.txt) */
-#endif
 
 #undef STAMP_STATS
 #define STAMP_STATS sp.ra.stats
@@ -198,8 +73,6 @@ typedef unsigned u3v __attribute__((ext_vector_type(3)));
 //   seq = 0  (inside a multi-step call): raster renders the PREVIOUS step while physics computes the next one;
 //            the host issues a physics-only first launch and a raster-only last launch, so the lag never
 //            leaves the call.
-constexpr int kRasterThreads = 64 * TRS_RASTER_WAVES;
-constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;
 
 struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernel (DYN instantiation)
     double baseline;
@@ -260,186 +133,6 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
     return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
 }
 
-// one wave advances one env (all lanes compute the same scalars; the track scan is lane-parallel)
-template <typename T>
-__device__ __forceinline__ T coherent_load(const T* ptr)
-{   // vector load that bypasses the per-CU L1 and the scalar cache: inside a K-step launch the value may have been
-    // stored by lane 0 of this wave one step earlier
-    return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Nearest raw track point of (qx, qy, qz) by one wave: binary64 L1, strict '<' with the lowest index winning ties
-// (reference LocationTracker.__find_closest, components/track_data_process.py:89-104).  First the 3x3 block of 4-unit
-// cells around the query (typically ~100 of the 1185 points); a block result below one cell size is provably the global
-// one (include/trsim_spec.h R3), otherwise every point is scanned.  All lanes get the result.
-struct NearParams { int np, off_py, off_pz, off_gstart, off_gpts, nx, nz; double x0, z0; };
-
-__device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned char* lphys, double qx, double qy, double qz, int lane,
-                                             double& best_out, int& idx_out)
-{
-    const double* lpx = reinterpret_cast<const double*>(lphys);
-    const double* lpy = reinterpret_cast<const double*>(lphys + g.off_py);
-    const double* lpz = reinterpret_cast<const double*>(lphys + g.off_pz);
-    if (g.nx > 0) {
-        const double fx = floor((qx - g.x0) * (1.0 / TRS_NEAR_GRID_CELL)), fz = floor((qz - g.z0) * (1.0 / TRS_NEAR_GRID_CELL));
-        if (fx >= -1.0 && fx <= (double)g.nx && fz >= -1.0 && fz <= (double)g.nz) {
-            const unsigned short* gstart = reinterpret_cast<const unsigned short*>(lphys + g.off_gstart);
-            const unsigned short* gpts = reinterpret_cast<const unsigned short*>(lphys + g.off_gpts);
-            const int cx = (int)fx, cz = (int)fz;
-            const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.nx - 1);
-            double best = TRS_LOST_L1;
-            int bi = 0;
-            if (x_lo <= x_hi)
-                for (int rz = max(cz - 1, 0); rz <= min(cz + 1, g.nz - 1); ++rz) {
-                    const int lo = gstart[rz * g.nx + x_lo], hi = gstart[rz * g.nx + x_hi + 1];      // the three cells of a row are contiguous
-                    for (int i = lo + lane; i < hi; i += 64) {
-                        const int idx = gpts[i];
-                        const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
-                        if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
-                    }
-                }
-            wave_argmin(best, bi);
-            const int idx = __builtin_amdgcn_readlane(bi, 63);
-            const double bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
-            if (bd < TRS_NEAR_GRID_CELL) { best_out = bd; idx_out = idx; return; }
-        }
-    }
-    double best = TRS_LOST_L1;
-    int bi = 0;
-    int i = lane;
-    for (; i + 64 < g.np; i += 128) {                       // two points per trip: the LDS reads of one overlap the arithmetic of the other
-        const int i2 = i + 64;
-        const double ax = lpx[i], ay = lpy[i], az = lpz[i];
-        const double bx = lpx[i2], by = lpy[i2], bz = lpz[i2];
-        const double d1 = (fabs(qx - ax) + fabs(qy - ay)) + fabs(qz - az);
-        const double d2 = (fabs(qx - bx) + fabs(qy - by)) + fabs(qz - bz);
-        if (d1 < best) { best = d1; bi = i; }
-        if (d2 < best) { best = d2; bi = i2; }
-    }
-    if (i < g.np) {
-        const double d1 = (fabs(qx - lpx[i]) + fabs(qy - lpy[i])) + fabs(qz - lpz[i]);
-        if (d1 < best) { best = d1; bi = i; }
-    }
-    wave_argmin(best, bi);
-    idx_out = __builtin_amdgcn_readlane(bi, 63);
-    best_out = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
-}
-
-__device__ __forceinline__ NearParams near_of(const PParams& p)
-{
-    return NearParams{p.np, p.off_py, p.off_pz, p.off_gstart, p.off_gpts, p.grid_nx, p.grid_nz, p.grid_x0, p.grid_z0};
-}
-
-// Per-env state held in registers by the wave that owns the env (every lane holds the same values).
-struct EnvRegs {
-    float x, y, z, yaw, v, sf, epr, speed, cte;
-    int seg, epl, done, pend;
-};
-
-__device__ __forceinline__ void env_load(const PParams& p, int e, EnvRegs& s)
-{
-    s.pend = coherent_load(&p.pending[e]); s.done = coherent_load(&p.done[e]);
-    s.sf = coherent_load(&p.steer_filt[e]);
-    s.x = coherent_load(&p.x[e]); s.y = coherent_load(&p.y[e]); s.z = coherent_load(&p.z[e]);
-    s.yaw = coherent_load(&p.yaw[e]); s.v = coherent_load(&p.v[e]);
-    s.seg = coherent_load(&p.seg_idx[e]);
-    s.epr = coherent_load(&p.ep_return[e]);
-    s.epl = coherent_load(&p.ep_len[e]);
-    s.speed = 0.f; s.cte = 0.f;
-}
-
-__device__ __forceinline__ void env_store(const PParams& p, int e, const EnvRegs& s, int lane)
-{
-    if (lane == 0) {
-        p.x[e] = s.x; p.y[e] = s.y; p.z[e] = s.z; p.yaw[e] = s.yaw; p.v[e] = s.v;
-        p.speed[e] = s.speed; p.cte[e] = s.cte; p.seg_idx[e] = s.seg; p.done[e] = (uint8_t)s.done;
-        p.ep_return[e] = s.epr; p.ep_len[e] = s.epl; p.steer_filt[e] = s.sf; p.pending[e] = (uint8_t)s.pend;
-    }
-}
-
-// One wave advances one env by one step, state in registers (include/trsim_spec.h, "one env step").
-__device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
-                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane)
-{
-    const double* lpx = reinterpret_cast<const double*>(lphys);
-    const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
-    const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
-    const float2* ltan = reinterpret_cast<const float2*>(lphys + p.off_tan);
-    const int gid = p.env_id_base + e;
-    const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
-    float sf = s.sf;
-    float steer = 0.f, thr = 0.f, brk = 0.f;
-    if (!p.synth) {
-        const size_t ci = (size_t)k * (size_t)p.ctl_stride + (size_t)e;
-        steer = p.ctl_steer[ci]; thr = p.ctl_thr[ci]; brk = p.ctl_brk ? p.ctl_brk[ci] : 0.0f;
-    }
-    const int prev_idx = s.seg;
-    float epr = s.epr;
-    int epl = s.epl;
-    const int do_reset = (s.pend != 0) || (rin != 0) || (p.auto_reset && s.done != 0);
-    float x1, y0, z1, yaw1, v2, hs, hc;
-    if (do_reset) {
-        const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
-        x1 = (float)lpx[si]; y0 = (float)lpy[si]; z1 = (float)lpz[si];
-        yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
-        spec_sincos(yaw1, hs, hc);
-    } else {
-        if (p.synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
-        steer = clampf(steer, -1.0f, 1.0f);
-        thr = clampf(thr, -1.0f, 1.0f);
-        brk = clampf(brk, 0.0f, 1.0f);
-        float sd, cd;
-        spec_sincos(steer * p.max_steer, sd, cd);
-        const float tan_d = sd / cd;
-        const float a = thr * p.accel_max - p.drag_lin * s.v;
-        const float v1 = s.v + a * p.dt;
-        const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
-        if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
-        else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
-        else v2 = 0.0f;
-        v2 = clampf(v2, -p.v_rev_max, p.v_max);
-        yaw1 = s.yaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
-        if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
-        if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
-        spec_sincos(yaw1, hs, hc);
-        x1 = s.x + (v2 * hs) * p.dt;
-        z1 = s.z + (v2 * hc) * p.dt;
-        y0 = s.y;
-    }
-    double bestd;
-    int idx;
-    wave_nearest(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
-
-    const float y1 = (float)lpy[idx];
-    const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
-    const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
-    const bool lost = bestd >= TRS_LOST_L1;
-    const int is_done = (fabsf(cte) > p.offtrack_cte) || lost;
-    if (do_reset) {
-        if (lane == 0) p.last_return[e] = epr;
-        epr = 0.0f; epl = 0;
-    } else {
-        int d = idx - prev_idx;
-        const int half = p.np / 2;
-        if (d >= p.np - half) d -= p.np;
-        if (d < -half) d += p.np;
-        const float reward = (float)d - (is_done ? p.offtrack_penalty : 0.0f);
-        epr = epr + reward;
-        epl += 1;
-    }
-    s.x = x1; s.y = y1; s.z = z1; s.yaw = yaw1; s.v = v2; s.sf = sf; s.epr = epr; s.epl = epl;
-    s.speed = fabsf(v2); s.cte = cte; s.seg = idx; s.done = is_done; s.pend = 0;
-    if (lane == 0) {
-        const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
-        const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
-        const float4 cam = make_float4(camx, camz, hs, hc);
-        if (p.write_cam) cam_out[e] = cam;                  // for the next launch (its first frame)
-        *lcam_slot = cam;                                   // for this launch's raster team
-        if (is_done) atomicAdd(&p.stats[0], 1ull);
-        if (do_reset) atomicAdd(&p.stats[1], 1ull);
-        __hip_atomic_store(pprog_j, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish: step k of this env is done
-    }
-}
 
 // Physics-only envs (BASELINE config 2): the same barrier-free wave-per-env routine, 4 envs per 256-thread workgroup,
 // K steps per launch.  The track image is staged once per launch; nothing is synchronised after that.
@@ -448,18 +141,9 @@ constexpr int kPhysBlock = 256;
 __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    {   // the track image goes global -> LDS by LDS-DMA (1 KB per wave instruction, no registers, no ds_write pass)
-        const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-        const int n16 = p.blob_bytes >> 4;
-        const unsigned lds_base = (unsigned)(uintptr_t)smem;                  // LDS byte address of the dynamic segment
-        for (int g0 = wave * 64; g0 < n16; g0 += (kPhysBlock / 64) * 64) {
-            const int g = g0 + lane;
-            if (g < n16)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
-                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + g0 * 16), 16, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // the track image goes global -> LDS by LDS-DMA (1 KB per wave instruction, no registers, no ds_write pass)
+    stage_lds_dma(p.blob, p.blob_bytes, (unsigned)(uintptr_t)smem, wave, kPhysBlock / 64, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float4* const lsink = reinterpret_cast<float4*>(smem + p.off_scratch);          // per-wave sinks for the camera hand-off slots
     int* const psink = reinterpret_cast<int*>(smem + p.off_scratch + (kPhysBlock / 64) * 16);
     __syncthreads();
@@ -472,21 +156,6 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     env_store(p, e, st, lane);
 }
 
-// (dx, dz) of a row as two scalar multiplies.  The packed form (v_pk_mul_f32 with the row-table register pair as source AND
-// destination) returned +-0 for dx in lanes 48..63 of one row pass now and then, but only while workgroups of other kernels
-// shared the CU (scripts/det_probe*.py: 1-3 % of the steps beside a pilot loop on another stream; never alone).  Same
-// IEEE products, so results are unchanged.
-__device__ __forceinline__ f2v ray_step(f2v kk2, f2v cns)
-{
-#ifdef TRS_PACKED_RAY_STEP
-    return kk2 * cns;
-#else
-    float dx, dz;
-    asm("v_mul_f32 %0, %1, %2" : "=v"(dx) : "v"(kk2.x), "v"(cns.x));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(dz) : "v"(kk2.y), "v"(cns.y));
-    return f2v{dx, dz};
-#endif
-}
 
 template <bool DEPTH, bool DYN>
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
@@ -521,25 +190,9 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         const float4* const cam_prev = sp.ph.cam + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
         if (has_c) cv = cam_prev[e_begin + tid];
         if (raster_team) {
-            if (rendering) {
-                const u4v* src = reinterpret_cast<const u4v*>(p.blob);
-                const int n16 = p.blob_bytes >> 4;
-                for (int g0 = wave * 64; g0 < n16; g0 += (kRasterThreads / 64) * 64) {
-                    const int g = g0 + lane;
-                    if (g < n16)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
-                                                         (__attribute__((address_space(3))) void*)(uintptr_t)(g0 * 16), 16, 0, 0);
-                }
-            }
+            if (rendering) stage_lds_dma(p.blob, p.blob_bytes, 0u, wave, kRasterThreads / 64, lane);
         } else if (sp.n_phys > 0) {
-            const u4v* src = reinterpret_cast<const u4v*>(sp.ph.blob);
-            const int n16 = sp.ph.blob_bytes >> 4;
-            for (int g0 = pw * 64; g0 < n16; g0 += kPhysWaves * 64) {
-                const int g = g0 + lane;
-                if (g < n16)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g),
-                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(sp.lds_off_phys + g0 * 16), 16, 0, 0);
-            }
+            stage_lds_dma(sp.ph.blob, sp.ph.blob_bytes, (unsigned)sp.lds_off_phys, pw, kPhysWaves, lane);
         }
         if (has_c) lcam_prev[tid] = cv;
         if (raster_team && rendering && sp.r_first < 0)
@@ -595,41 +248,17 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     // single-step call) while the physics team integrates.  Per pixel of the other rows: 1 packed fma (gx,gz), 2
     // saturating converts + 2 min (= floor + clamp), 3 address ops, 1 LDS map read, shift + bit-field extract, 1 palette
     // address op, 1 LDS palette read.
-    const f2v* lrow = reinterpret_cast<const f2v*>(smem + p.off_rowtab);
-    const float* lrowdepth = reinterpret_cast<const float*>(smem + p.off_depth);
-    const float half_w = (float)(p.W / 2);
-    const unsigned gwm1 = (unsigned)(p.map_w - 1), ghm1 = (unsigned)(p.map_h - 1);
-    const int cg = tid % p.gpr, r0 = tid / p.gpr;       // threads with r0 >= rows_per_pass idle (32 of 512 at W = 160: 12 x 40 = 480)
-    const float uf0 = (float)(cg << 2) + 0.5f - half_w;
-    const f2v ufa = {uf0, uf0}, ufb = {uf0 + 1.0f, uf0 + 1.0f}, ufc = {uf0 + 2.0f, uf0 + 2.0f}, ufd = {uf0 + 3.0f, uf0 + 3.0f};
-    const unsigned pitch = (unsigned)p.map_pitch_b;
-    const int vstart = r0 < p.rows_per_pass ? r0 : p.H;
-    int vground = vstart;                                // this thread's first row that needs the map
-    while (vground < p.uni_rows) vground += p.rows_per_pass;
-    const size_t row_bytes = (size_t)p.gpr * 12;
-    const int col_off = cg * 12;
+    const RasterThread rth = raster_thread(p, smem, tid);
+    [[maybe_unused]] const f2v* const lrow = rth.lrow;
+    [[maybe_unused]] const float* const lrowdepth = rth.lrowdepth;
+    [[maybe_unused]] const unsigned gwm1 = rth.gwm1, ghm1 = rth.ghm1, pitch = rth.pitch;
+    [[maybe_unused]] const int cg = rth.cg, vstart = rth.vstart, col_off = rth.col_off;
+    [[maybe_unused]] const f2v ufa = rth.ufa, ufb = rth.ufb, ufc = rth.ufc, ufd = rth.ufd;
+    [[maybe_unused]] const size_t row_bytes = (size_t)rth.row_bytes;
     for (int sidx = sp.r_first; sidx <= sp.r_last; ++sidx) {
     const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
     uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
     float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
-    // rows with four equal class colours need no map lookup and no pose: one palette read per 4 pixels, and in a
-    // single-step call they are written while the physics team still integrates
-    auto uniform_rows = [&](int e) {
-        const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(
-            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
-        __amdgpu_buffer_rsrc_t udrs = ursrc;
-        if constexpr (DEPTH) udrs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
-        for (int v = vstart; v < p.uni_rows; v += p.rows_per_pass) {
-            const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)v << 4));
-            const u3v px3 = {__builtin_amdgcn_perm(c, c, 0x04020100u), __builtin_amdgcn_perm(c, c, 0x05040201u), __builtin_amdgcn_perm(c, c, 0x06050402u)};
-            __builtin_amdgcn_raw_buffer_store_b96(px3, ursrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
-            if constexpr (DEPTH) {
-                const unsigned dz = __float_as_uint(lrowdepth[v]);
-                const u4v d4 = {dz, dz, dz, dz};
-                __builtin_amdgcn_raw_buffer_store_b128(d4, udrs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
-            }
-        }
-    };
     for (int e = e_begin; e < e_end; ++e) {
         if constexpr (DYN) {
             // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
@@ -790,12 +419,10 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             }
             continue;
         }
-        uniform_rows(e);
-        // one buffer descriptor per env image (wave-uniform): stores carry the cache-policy bits TRS_STORE_AUX
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            img + (size_t)e * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
-        __amdgpu_buffer_rsrc_t drs = rsrc;
-        if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)e * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+        // rows with four equal class colours need no map lookup and no pose: they are written first, and in a single-step
+        // call while the physics team still integrates
+        const FrameDesc fd = frame_desc<DEPTH>(p, img, dep, e);
+        raster_uniform_rows<DEPTH>(p, rth, fd);
         // -- rows that see the track
         float4 cam;
         const int j = e - e_begin;
@@ -805,49 +432,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
             cam = lcam[sidx * sp.cam_stride + j];
         }
-        const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-        f2v rt = lrow[vground < p.H ? vground : 0];
-        for (int v = vground; v < p.H; v += p.rows_per_pass) {
-            const int vn = v + p.rows_per_pass;
-            const f2v rtn = lrow[vn < p.H ? vn : v];                            // prefetch the next row's table entry
-            const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
-            const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
-            const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
-            const f2v d = ray_step(kk2, cns);                                  // (dx, dz) = (k*c, -(k*s))
-            auto shade = [&](f2v uf) -> uint32_t {
-                const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)
-                const unsigned ix = min(cvt_u32_sat(g.x), gwm1);
-                const unsigned iz = min(cvt_u32_sat(g.y), ghm1);
-                const unsigned xoff = (ix >> 2) & ~3u;                          // byte offset of the map word in its row
-                unsigned waddr, paddr;
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(pitch), "v"(xoff));
-                const uint32_t w = *(lds_u32p)(uintptr_t)waddr;                 // map lives at LDS offset 0 (checked above)
-                const uint32_t cls = __builtin_amdgcn_ubfe(w, ix << 1, 2);      // offset uses bits [4:0] = 2*(ix&15)
-                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(paddr) : "v"(cls), "v"(pal_a));
-                return *(lds_u32p)(uintptr_t)paddr;
-            };
-#if TRS_ABLATE == 2   /* diagnostic build: stores only */
-            const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
-#else
-            const uint32_t c0p = shade(ufa), c1p = shade(ufb), c2p = shade(ufc), c3p = shade(ufd);
-#endif
-            // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
-            const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
-            const uint32_t w1 = __builtin_amdgcn_perm(c2p, c1p, 0x05040201u);
-            const uint32_t w2 = __builtin_amdgcn_perm(c3p, c2p, 0x06050402u);
-#if TRS_ABLATE == 1   /* diagnostic build: compute, no stores */
-            asm volatile("" :: "v"(w0), "v"(w1), "v"(w2)); (void)rsrc; (void)col_off;
-#else
-            const u3v px3 = {w0, w1, w2};
-            __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, col_off + v * (int)row_bytes, 0, TRS_STORE_AUX);
-            if constexpr (DEPTH) {   // z-depth is constant along a row of a ground-plane camera: 4 pixels = one 16-B store
-                const unsigned dz = __float_as_uint(lrowdepth[v]);
-                const u4v d4 = {dz, dz, dz, dz};
-                __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
-            }
-#endif
-            rt = rtn;
-        }
+        raster_ground_rows<DEPTH>(p, rth, fd, cam);
     }
     }
     STAMP(5);
@@ -1273,54 +858,23 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-struct trs_env {
-    trs_config cfg{};
-    int device = 0, n = 0, H = 0, W = 0, cu_count = 0;
-    hipStream_t sP = nullptr;            // the handle's stream: every launch, copy and timing event
-    hipEvent_t ev[8] = {};
-    // device memory
-    unsigned char* slab = nullptr;       // state + controls
-    uint8_t* img[2] = {nullptr, nullptr};
-    float* depth[2] = {nullptr, nullptr};
-    unsigned char* blob_p = nullptr;     // physics LDS image
-    unsigned char* blob_r = nullptr;     // raster LDS image
-    float* tangent = nullptr;
-    float* start_yaw = nullptr;
-    float4* cam = nullptr;               // [kRing][n]
-    unsigned long long* stats = nullptr;
-    double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
-    uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)
-    trs_pre_config frame_filter{}; bool has_frame_filter = false, filter_dynamic = false;   // trs_set_frame_filter
-    unsigned char* pinned = nullptr; size_t pinned_bytes = 0;   // trs_fetch_outputs staging (hipHostMalloc)
-    int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
-    uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
-    int* hsv_tab = nullptr;
-    unsigned char* edge_scratch = nullptr; size_t edge_scratch_bytes = 0;   // work arrays of the Canny layer for frames beyond LDS
-    PParams pp{};
-    RParams rp{};
-    trsim::TrackTables tab;
-    bool track_loaded = false;
-    int lds_p = 0, lds_r = 0, pts_bytes = 0;
-    uint64_t step_count = 0;
-    float *ctl_steer = nullptr, *ctl_thr = nullptr, *ctl_brk = nullptr;
-    uint8_t* ctl_reset = nullptr;
-    size_t img_bytes = 0;
-    int lds_step = 0, lds_off_phys = 0, max_steps_per_launch = 1;
-    float* seq_buf = nullptr; size_t seq_cap = 0;   // device copy of host control sequences (trs_step_sequence_host)
-    int seq_stride = 0;                  // trs_step_sequence: n_envs while a sequence call is running, else 0
-    int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
-    void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
-};
-
 namespace {
 
 int grid_of(const trs_env* e) { return (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg; }
 
+// the handle's stream is idle: a resident worker (trs_set_step_mode) is asked to leave first — it owns the stream while it runs
 int sync_all(trs_env* e)
 {
+    if (e->res) { int rc = trsim::resident_quiesce(e); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
 }
+
+// anything about to be queued on the handle's stream must not end up behind a resident worker
+int quiesce(trs_env* e) { return e->res ? trsim::resident_quiesce(e) : TRS_OK; }
+
+// steps go to the resident worker: resident mode is on and the worker can render them (no in-kernel dynamic-brightness filter)
+bool resident_steps(const trs_env* e) { return trsim::resident_on(e) && e->cfg.render && !(e->has_frame_filter && e->filter_dynamic); }
 
 // one launch of the fused step kernel: physics steps [step_base, step_base + n_phys) and the frames of launch-local
 // steps r_first..r_last (-1 = step_base - 1, whose camera parameters the previous launch left in the global ring)
@@ -1514,12 +1068,13 @@ TRS_EXPORT int trs_destroy(trs_env* e)
 {
     if (!e) return TRS_OK;
     (void)hipSetDevice(e->device);
+    trsim::resident_destroy(e);
     if (e->sP) (void)hipStreamSynchronize(e->sP);
     if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
-    (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf);
+    (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf); (void)hipFree(e->glue);
     if (e->pinned) (void)hipHostFree(e->pinned);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1673,6 +1228,8 @@ TRS_EXPORT int trs_step(trs_env* e, const float* d_st, const float* d_th, const 
     if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
+    if (resident_steps(e)) return trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, 0);
+    { int rq = quiesce(e); if (rq) return rq; }
     // held controls; the reset request applies to the first step only
     return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, n_steps)
                          : run_physics_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, 1);
@@ -1684,6 +1241,8 @@ TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, c
     if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
     if (!h_st || !h_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
+    if (resident_steps(e)) return trsim::resident_post_host(e, h_st, h_th, h_br, h_rs, n_steps);
+    { int rq = quiesce(e); if (rq) return rq; }
     const size_t n = (size_t)e->n;
     HIPCHK(hipMemcpyAsync(e->ctl_steer, h_st, n * 4, hipMemcpyHostToDevice, e->sP));
     HIPCHK(hipMemcpyAsync(e->ctl_thr, h_th, n * 4, hipMemcpyHostToDevice, e->sP));
@@ -1698,6 +1257,8 @@ TRS_EXPORT int trs_step_sequence(trs_env* e, const float* d_st, const float* d_t
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
+    if (resident_steps(e)) return trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, (size_t)e->n);
+    { int rq = quiesce(e); if (rq) return rq; }
     e->seq_stride = e->n;
     const int rc = e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, steps_per_launch)
                                  : run_physics_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, steps_per_launch);
@@ -1711,6 +1272,7 @@ TRS_EXPORT int trs_step_sequence_host(trs_env* e, const float* h_st, const float
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     if (!h_st || !h_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }            // the sequence is copied through the handle's stream
     const size_t cnt = (size_t)n_steps * (size_t)e->n;
     if (e->seq_cap < cnt) {
         HIPCHK(hipStreamSynchronize(e->sP));
@@ -1731,6 +1293,8 @@ TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     HIPCHK(hipSetDevice(e->device));
+    if (resident_steps(e)) return trsim::resident_post(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, 0);
+    { int rq = quiesce(e); if (rq) return rq; }
     return e->cfg.render ? run_camera_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch)
                          : run_physics_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch);
 }
@@ -1786,6 +1350,16 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     if (!src) return fail(TRS_ERR_STATE, "field not available");
     if (bytes != need) return fail(TRS_ERR_ARG, "byte count mismatch");
     if (host_src) { std::memcpy(dst, src, need); return TRS_OK; }
+    if (resident_steps(e) && which != TRS_F_STATS) {
+        // the worker keeps the handle's stream: wait for its posted steps (their bytes are written through to memory before
+        // the completion flag), then copy on the side stream
+        int rw = trsim::resident_wait(e);
+        if (rw) return rw;
+        hipStream_t sc = trsim::resident_copy_stream(e);
+        HIPCHK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, sc));
+        HIPCHK(hipStreamSynchronize(sc));
+        return TRS_OK;
+    }
     int rc = sync_all(e);
     if (rc) return rc;
     HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
@@ -1804,7 +1378,7 @@ TRS_EXPORT int trs_fetch_outputs(trs_env* e, uint8_t* h_img, float* h_x, float* 
     const size_t n = (size_t)e->n, img_b = h_img ? e->img_bytes : 0;
     const size_t need = ((img_b + 15) & ~(size_t)15) + 7 * ((n * 4 + 15) & ~(size_t)15) + 16;   // every item starts 16-B aligned
     if (e->pinned_bytes < need) {
-        if (e->pinned) { HIPCHK(hipStreamSynchronize(e->sP)); (void)hipHostFree(e->pinned); e->pinned = nullptr; e->pinned_bytes = 0; }
+        if (e->pinned) { int rq = sync_all(e); if (rq) return rq; (void)hipHostFree(e->pinned); e->pinned = nullptr; e->pinned_bytes = 0; }
         HIPCHK(hipHostMalloc((void**)&e->pinned, need, hipHostMallocDefault));
         e->pinned_bytes = need;
     }
@@ -1814,13 +1388,16 @@ TRS_EXPORT int trs_fetch_outputs(trs_env* e, uint8_t* h_img, float* h_x, float* 
         {k.x, h_x, n * 4}, {k.y, h_y, n * 4}, {k.z, h_z, n * 4}, {k.speed, h_speed, n * 4}, {k.cte, h_cte, n * 4},
         {k.seg_idx, h_seg, n * 4}, {k.done, h_done, n},
     };
+    hipStream_t cs = e->sP;
+    if (resident_steps(e)) { int rw = trsim::resident_wait(e); if (rw) return rw; cs = trsim::resident_copy_stream(e); }
+    else { int rq = quiesce(e); if (rq) return rq; }
     size_t off = 0;
     for (const Item& it : items) {
         if (!it.dst || !it.bytes) continue;
-        HIPCHK(hipMemcpyAsync(e->pinned + off, it.src, it.bytes, hipMemcpyDeviceToHost, e->sP));
+        HIPCHK(hipMemcpyAsync(e->pinned + off, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
         off += (it.bytes + 15) & ~(size_t)15;
     }
-    HIPCHK(hipStreamSynchronize(e->sP));
+    HIPCHK(hipStreamSynchronize(cs));
     off = 0;
     for (const Item& it : items) {
         if (!it.dst || !it.bytes) continue;
@@ -1854,6 +1431,7 @@ TRS_EXPORT int trs_locate(trs_env* e, const double* h_xyz, int nq, int32_t* h_id
     if (nq < 0 || (nq && (!h_xyz || !h_idx))) return fail(TRS_ERR_ARG, "bad query");
     if (nq == 0) return TRS_OK;
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }
     if (nq > e->loc_cap) {
         HIPCHK(hipStreamSynchronize(e->sP));
         (void)hipFree(e->loc_q); (void)hipFree(e->loc_out); e->loc_q = nullptr; e->loc_out = nullptr; e->loc_cap = 0;
@@ -1952,7 +1530,7 @@ int upload_palette(trs_env* e)
     if (e->has_frame_filter && !e->filter_dynamic)             // dynamic brightness: the kernel filters a per-env palette itself
         for (auto& c : pal) c = filter_colour(e->frame_filter, c);
     e->rp.uni_rows = leading_uniform_rows(pal, e->H);
-    HIPCHK(hipStreamSynchronize(e->sP));                       // frames in flight keep the palette they were launched with
+    { int rq = sync_all(e); if (rq) return rq; }               // frames in flight keep the palette they were launched with
     HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
     return TRS_OK;
 }
@@ -1968,6 +1546,19 @@ int ensure_tmp(trs_env* e, size_t frames)
     HIPCHK(hipMalloc((void**)&e->tmp_out, frames * fb));
     HIPCHK(hipMalloc((void**)&e->tmp_f, frames * fb * sizeof(float)));
     e->tmp_cap = frames;
+    return TRS_OK;
+}
+
+// device scratch of the *_host control glue, owned by the handle (the N = 1 Car loop calls these every tick)
+int ensure_glue(trs_env* e, size_t bytes)
+{
+    if (bytes <= e->glue_bytes) return TRS_OK;
+    int rc = sync_all(e);
+    if (rc) return rc;
+    (void)hipFree(e->glue); e->glue = nullptr; e->glue_bytes = 0;
+    const size_t cap = std::max<size_t>(align_up(bytes, 256), 4096);
+    HIPCHK(hipMalloc((void**)&e->glue, cap));
+    e->glue_bytes = cap;
     return TRS_OK;
 }
 
@@ -2017,6 +1608,7 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
     if (rc) return rc;
     if (n_images < 0) return fail(TRS_ERR_ARG, "n_images < 0");
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }
     if (!d_src) {
         if (!latest_frame(e) || n_images != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera");
         d_src = latest_frame(e);
@@ -2084,6 +1676,7 @@ TRS_EXPORT int trs_preprocess_host(trs_env* e, const trs_pre_config* c, const ui
     if (!e || !h_src || !h_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(e->device));
     if (n_images == 0) return TRS_OK;
+    { int rq = quiesce(e); if (rq) return rq; }
     int rc = ensure_tmp(e, (size_t)n_images);
     if (rc) return rc;
     const size_t bytes = (size_t)n_images * e->H * e->W * 3;
@@ -2099,6 +1692,7 @@ TRS_EXPORT int trs_normalize(trs_env* e, const uint8_t* d_src, float* d_dst, int
 {
     if (!e || !d_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }
     if (!d_src) {
         if (!latest_frame(e) || n_images != e->n) return fail(TRS_ERR_ARG, "latest-frame source needs n_images == n_envs and a camera");
         d_src = latest_frame(e);
@@ -2116,6 +1710,7 @@ TRS_EXPORT int trs_normalize_host(trs_env* e, const uint8_t* h_src, float* h_dst
     if (!e || !h_src || !h_dst || n_images < 0) return fail(TRS_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(e->device));
     if (n_images == 0) return TRS_OK;
+    { int rq = quiesce(e); if (rq) return rq; }
     int rc = ensure_tmp(e, (size_t)n_images);
     if (rc) return rc;
     const size_t bytes = (size_t)n_images * e->H * e->W * 3;
@@ -2133,6 +1728,7 @@ TRS_EXPORT int trs_driver_assist(trs_env* e, int mode, double k, float* d_st, fl
     if (!d_sp) { if (n != e->n) return fail(TRS_ERR_ARG, "the env's own speed needs n == n_envs"); d_sp = e->pp.speed; }
     HIPCHK(hipSetDevice(e->device));
     if (n == 0) return TRS_OK;
+    { int rq = quiesce(e); if (rq) return rq; }
     hipLaunchKernelGGL(trs_driver_assist_kernel, dim3((n + 255) / 256), dim3(256), 0, e->sP, mode, k, d_st, d_th, d_br, d_sp, n);
     HIPCHK(hipGetLastError());
     return TRS_OK;
@@ -2143,19 +1739,20 @@ TRS_EXPORT int trs_driver_assist_host(trs_env* e, int mode, double k, float* h_s
     if (!e || !h_st || !h_th || !h_br || !h_sp || n < 0) return fail(TRS_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(e->device));
     if (n == 0) return TRS_OK;
-    float* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, (size_t)n * 16));
+    int rc = quiesce(e);
+    if (!rc) rc = ensure_glue(e, (size_t)n * 16);
+    if (rc) return rc;
+    float* d = e->glue;
     float *ds = d, *dt = d + n, *db = d + 2 * (size_t)n, *dp = d + 3 * (size_t)n;
     hipError_t err = hipSuccess;
     const float* srcs[4] = {h_st, h_th, h_br, h_sp};
     float* dsts[4] = {ds, dt, db, dp};
     for (int a = 0; a < 4 && err == hipSuccess; ++a) err = hipMemcpyAsync(dsts[a], srcs[a], (size_t)n * 4, hipMemcpyHostToDevice, e->sP);
-    int rc = err == hipSuccess ? trs_driver_assist(e, mode, k, ds, dt, db, dp, n) : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
+    rc = err == hipSuccess ? trs_driver_assist(e, mode, k, ds, dt, db, dp, n) : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
     float* outs[3] = {h_st, h_th, h_br};
     for (int a = 0; a < 3 && rc == TRS_OK; ++a)
         if (hipMemcpyAsync(outs[a], dsts[a], (size_t)n * 4, hipMemcpyDeviceToHost, e->sP) != hipSuccess) rc = fail(TRS_ERR_DEVICE, "copy back failed");
-    (void)hipStreamSynchronize(e->sP);
-    (void)hipFree(d);
+    if (hipStreamSynchronize(e->sP) != hipSuccess && rc == TRS_OK) rc = fail(TRS_ERR_DEVICE, "stream synchronisation failed");
     return rc;
 }
 
@@ -2170,6 +1767,7 @@ TRS_EXPORT void trs_default_mux_config(trs_mux_config* c)
 
 static int mux_state_ready(trs_env* e)
 {
+    { int rq = quiesce(e); if (rq) return rq; }
     if (e->mux_state) return TRS_OK;
     HIPCHK(hipMalloc((void**)&e->mux_state, (size_t)e->n * kMuxWords * sizeof(int32_t)));
     hipLaunchKernelGGL(trs_control_mux_init_kernel, dim3((e->n + 255) / 256), dim3(256), 0, e->sP, e->mux_state, e->n);
@@ -2182,6 +1780,7 @@ TRS_EXPORT int trs_control_mux_reset(trs_env* e)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }
     if (e->mux_state) { HIPCHK(hipFree(e->mux_state)); e->mux_state = nullptr; }
     return mux_state_ready(e);
 }
@@ -2216,20 +1815,21 @@ TRS_EXPORT int trs_control_mux_host(trs_env* e, const trs_mux_config* c, const u
     if (!e || !h_mode || !h_us || !h_ut || !h_ub || !h_as || !h_at || !h_ab || !h_os || !h_ot || !h_ob || n < 0) return fail(TRS_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(e->device));
     if (n == 0) return trs_control_mux(e, c, h_mode, h_us, h_ut, h_ub, h_as, h_at, h_ab, h_os, h_ot, h_ob, 0);
-    float* d = nullptr;
     const size_t nn = (size_t)n;
-    HIPCHK(hipMalloc((void**)&d, nn * 4 * 9 + nn));
+    int rc = quiesce(e);
+    if (!rc) rc = ensure_glue(e, nn * 4 * 9 + nn);
+    if (rc) return rc;
+    float* d = e->glue;
     uint8_t* dm = reinterpret_cast<uint8_t*>(d + 9 * nn);
     const float* srcs[9] = {h_us, h_ut, h_ub, h_as, h_at, h_ab, h_os, h_ot, h_ob};
     hipError_t err = hipMemcpyAsync(dm, h_mode, nn, hipMemcpyHostToDevice, e->sP);
     for (int a = 0; a < 9 && err == hipSuccess; ++a) err = hipMemcpyAsync(d + a * nn, srcs[a], nn * 4, hipMemcpyHostToDevice, e->sP);
-    int rc = err == hipSuccess ? trs_control_mux(e, c, dm, d, d + nn, d + 2 * nn, d + 3 * nn, d + 4 * nn, d + 5 * nn, d + 6 * nn, d + 7 * nn, d + 8 * nn, n)
-                               : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
+    rc = err == hipSuccess ? trs_control_mux(e, c, dm, d, d + nn, d + 2 * nn, d + 3 * nn, d + 4 * nn, d + 5 * nn, d + 6 * nn, d + 7 * nn, d + 8 * nn, n)
+                           : fail(TRS_ERR_DEVICE, hipGetErrorString(err));
     float* outs[3] = {h_os, h_ot, h_ob};
     for (int a = 0; a < 3 && rc == TRS_OK; ++a)
         if (hipMemcpyAsync(outs[a], d + (6 + a) * nn, nn * 4, hipMemcpyDeviceToHost, e->sP) != hipSuccess) rc = fail(TRS_ERR_DEVICE, "copy back failed");
-    (void)hipStreamSynchronize(e->sP);
-    (void)hipFree(d);
+    if (hipStreamSynchronize(e->sP) != hipSuccess && rc == TRS_OK) rc = fail(TRS_ERR_DEVICE, "stream synchronisation failed");
     return rc;
 }
 
@@ -2245,6 +1845,7 @@ TRS_EXPORT int trs_sync(trs_env* e)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(e->device));
+    if (resident_steps(e)) return trsim::resident_wait(e);      // every posted step is complete in memory; the worker stays resident
     return sync_all(e);
 }
 
@@ -2252,6 +1853,7 @@ TRS_EXPORT int trs_event_record(trs_env* e, int slot)
 {
     if (!e || slot < 0 || slot >= 8) return fail(TRS_ERR_ARG, "bad event slot");
     HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }            // an event behind a resident worker would wait for the worker to leave anyway
     HIPCHK(hipEventRecord(e->ev[slot], e->sP));
     return TRS_OK;
 }
@@ -2271,6 +1873,7 @@ TRS_EXPORT const char* trs_last_error(void) { return g_err.c_str(); }
 bool trs_internal_view(trs_env* e, TrsEnvView* v)
 {
     if (!e || !v) return false;
+    if (quiesce(e)) return false;                            // the pilot's kernels go onto the handle's stream
     v->device = e->device; v->n = e->n; v->H = e->H; v->W = e->W; v->render = e->cfg.render;
     v->stream = e->sP;
     v->latest_frame = (e->cfg.render && e->step_count > 0) ? e->img[(e->step_count + 1) & 1] : nullptr;

@@ -153,6 +153,11 @@ class BatchedEnv:
     def step_synthetic(self, n_steps=1, steps_per_launch=1):
         self.api.check(self.api.step_synthetic(self._h, int(n_steps), int(steps_per_launch)), "step_synthetic")
 
+    def set_step_mode(self, resident=True, idle_us=0):
+        """``resident=True``: a worker kernel stays on the GPU and every ``step*`` call only posts its controls
+        (``trs_set_step_mode``: no launch, no kernel boundary, no table re-staging per step); ``False``: one launch per call."""
+        self.api.check(self.api.set_step_mode(self._h, 1 if resident else 0, int(idle_us)), "set_step_mode")
+
     def sync(self):
         self.api.check(self.api.sync(self._h), "sync")
 
