@@ -157,3 +157,33 @@ def test_resident_sequence_and_mode_errors(make_env, hip_api):
     with pytest.raises(RuntimeError):
         p.set_step_mode(True)                                    # no camera: refused
     assert hip_api.set_step_mode(g._h, 7, 0) != 0
+
+
+def test_resident_worker_generations_under_load(make_env, monkeypatch):
+    """The worker leaves on its own when its lifetime is spent, even while posts keep coming; the host restarts it from the
+    first step it did not take.  With a 1.5 ms lifetime a 4,000-step run crosses that seam dozens of times."""
+    monkeypatch.setenv("TRS_RESIDENT_LIFE_US", "1500")
+    n = 128
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    for chunk in (1500, 1, 2499):
+        for env in (g, o):
+            env.step_synthetic(chunk, 1)
+        assert_state_equal(g, o, f"after a chunk of {chunk}")
+        assert_frames_equal(g, o, f"after a chunk of {chunk}")
+    assert int(g.fetch("stats")[2]) == 0
+
+
+def test_resident_after_reloading_the_track(make_env):
+    """trs_load_track restarts the step counter: tags and completion flags of the earlier steps must not be taken for new ones."""
+    from conftest import track_points
+    n = 40
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(True)
+    for env in (g, o):
+        env.step_synthetic(21, 1)
+        env.load_track(track_points("mountain"))
+    for env in (g, o):
+        env.step_synthetic(10, 1)
+    assert_state_equal(g, o, "after a track reload")
+    assert_frames_equal(g, o, "after a track reload")

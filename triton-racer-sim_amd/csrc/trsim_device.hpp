@@ -262,7 +262,8 @@ __device__ __forceinline__ void store_out(T* ptr, T v)
 // One wave advances one env by one step on registers (include/trsim_spec.h, "one env step"): every lane computes the same
 // scalars, the track scan is lane-parallel.  Controls are this step's (already fetched; generated here when `synth`); `rin` =
 // the user's reset request.  Side effects: last_return[e] on a reset, nothing else.
-template <bool WT>
+// STORE_LR: store last_return[e] here on a reset (the resident worker stores it itself, with its other outputs).
+template <bool WT, bool STORE_LR = true>
 __device__ __forceinline__ void env_advance(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int synth,
                                             float steer, float thr, float brk, uint8_t rin, int lane, StepOut& o)
 {
@@ -310,18 +311,12 @@ __device__ __forceinline__ void env_advance(const PParams& p, const unsigned cha
     wave_nearest(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
 
     const float y1 = (float)lpy[idx];
-    // the tangent sits in LDS or (long tracks) in global memory: two typed loads — one load through a selected pointer is a flat
-    // load, which waits on both memory counters
-    typedef __attribute__((address_space(3))) const float2* lds_f2p;
-    typedef __attribute__((address_space(1))) const float2* glb_f2p;
-    float2 tg;
-    if (p.tan_in_lds) tg = *(lds_f2p)(uintptr_t)((unsigned)(uintptr_t)ltan + ((unsigned)idx << 3));
-    else tg = *(glb_f2p)(uintptr_t)(p.tangent_g + 2 * (size_t)idx);
+    const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
     const float cte = (x1 - (float)lpx[idx]) * tg.y - (z1 - (float)lpz[idx]) * tg.x;
     const bool lost = bestd >= TRS_LOST_L1;
     const int is_done = (fabsf(cte) > p.offtrack_cte) || lost;
     if (do_reset) {
-        if (lane == 0) store_out<WT>(&p.last_return[e], epr);
+        if constexpr (STORE_LR) { if (lane == 0) store_out<WT>(&p.last_return[e], epr); }
         epr = 0.0f; epl = 0;
     } else {
         int d = idx - prev_idx;

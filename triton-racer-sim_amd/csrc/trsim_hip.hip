@@ -259,6 +259,12 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
     uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
     float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
+    // rows with four equal class colours need no map lookup and no pose: every env's are written FIRST, so that in a
+    // single-step call (the raster team waits for this step's poses) 41 % of the frame bytes of ALL the workgroup's envs are
+    // on their way to HBM while the physics team integrates — env by env the team stalled behind the first env's pose with
+    // one env's uniform rows in flight
+    if constexpr (!DYN)
+        for (int e = e_begin; e < e_end; ++e) raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e));
     for (int e = e_begin; e < e_end; ++e) {
         if constexpr (DYN) {
             // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
@@ -419,11 +425,8 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             }
             continue;
         }
-        // rows with four equal class colours need no map lookup and no pose: they are written first, and in a single-step
-        // call while the physics team still integrates
         const FrameDesc fd = frame_desc<DEPTH>(p, img, dep, e);
-        raster_uniform_rows<DEPTH>(p, rth, fd);
-        // -- rows that see the track
+        // -- rows that see the track (the rows that need no pose were written above, for every env of the workgroup)
         float4 cam;
         const int j = e - e_begin;
         if (sidx < 0) {

@@ -30,6 +30,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -46,15 +47,17 @@ namespace trsim {
 constexpr int kSlots = 8;       // posts in flight: ring entries, arrival counters, done flags
 constexpr int kCamDepth = 4;    // steps the physics team may run ahead of the raster team
 
-struct WEntry {                 // one posted step (64 B)
+struct WEntry {                 // one posted step: ONE 64-B line, so the dispatcher learns of a post and gets it in one PCIe read
     const float* steer; const float* thr; const float* brk; const uint8_t* reset;
-    uint32_t synth, pad0; uint64_t pad1[3];
+    uint32_t synth, pad0;
+    uint64_t seq;               // step index + 1, written LAST by the host: the line is valid for step s iff seq == s + 1
+    uint64_t pad1[2];
 };
 static_assert(sizeof(WEntry) == 64, "one entry per 64-B line");
 
 struct Mailbox {                // pinned host memory the device reads and writes over PCIe
-    alignas(64) uint64_t posted;            // host -> device: steps [0, posted) have been posted (absolute step indices)
-    uint32_t close, pad0;                   // host -> device: leave once everything posted is done
+    alignas(64) uint64_t close;             // host -> device: leave once everything posted is done
+    uint64_t posted;                        // host bookkeeping: steps [0, posted) have been posted (the device reads the entries' tags)
     alignas(64) uint64_t exited;            // device -> host: the dispatcher has decided to leave
     uint64_t consumed;                      //   ... and every step below this index is processed by the time the kernel ends
     uint64_t error;                         //   non-zero: a bounded wait gave up (code << 32 | block)
@@ -102,7 +105,6 @@ using namespace trsim;
 using u64 = unsigned long long;
 
 constexpr u64 kExitBit = 1ull << 63, kAbortBit = 1ull << 62, kCountMask = kAbortBit - 1;
-constexpr int kWaves = kBlock / 64;
 
 // ---- scoped accesses ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 sys_load64(const void* p) { return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -119,6 +121,18 @@ __device__ __forceinline__ void drain_lds() { asm volatile("s_waitcnt lgkmcnt(0)
 
 // a control value from an array the host named in a post: a GLOBAL (never flat) system-scope load, so that neither this CU's L1
 // nor this XCD's L2 can answer with what an earlier step read from the same address
+// wait until at most n of this wave's vector-memory operations are outstanding (n wave-uniform; the instruction takes an
+// immediate).  A raster wave issues only stores in its steady state and stores are acknowledged in issue order, so behind M
+// newer stores vmcnt(M) says "everything older has reached memory" without waiting for the newer ones.
+__device__ __forceinline__ void wait_vmcnt_le(int n)
+{
+    switch (__builtin_amdgcn_readfirstlane(n < 0 ? 0 : (n > 63 ? 63 : n))) {
+#define W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18) W(19) W(20) W(21) W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31) W(32) W(33) W(34) W(35) W(36) W(37) W(38) W(39) W(40) W(41) W(42) W(43) W(44) W(45) W(46) W(47) W(48) W(49) W(50) W(51) W(52) W(53) W(54) W(55) W(56) W(57) W(58) W(59) W(60) W(61) W(62) W(63)
+#undef W
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ T sys_load_val(const T* p)
 {
@@ -126,32 +140,35 @@ __device__ __forceinline__ T sys_load_val(const T* p)
 }
 
 // what a workgroup shares in LDS (behind the tables)
+constexpr int kSlotWords = 20;  // one hand-off slot: camera parameters (4) | x y z yaw v speed cte seg epr epl sf last_return (12) | done | 3 spare
 struct WLds {
     u64* word;          // posted count | flags as last seen by this workgroup's leader
-    int* arrive;        // [kSlots] waves that have finished step s (stores drained)
+    u64* fwd;           // steps this workgroup has completely passed on (the forwarder's count; the dispatcher's idle clock reads it)
+    int* arrive;        // [kSlots] raster waves whose stores of step s are in memory
     int* pprog;         // [epw] steps the physics team has finished per env (relative to the launch's first step)
-    int* rread;         // [epw] raster-wave reads of camera slots per env (back-pressure)
-    float4* lcam;       // [kCamDepth][epw]
-    float* lst;         // [epw][16] env state
+    int* rread;         // [epw] raster-wave reads of hand-off slots per env (back-pressure)
+    float* slot;        // [kCamDepth][epw][kSlotWords] physics -> raster: the pose to render AND the telemetry to write out
+    float* lst;         // [epw][16] env state carried from step to step
 };
+
+__host__ __device__ inline size_t wlds_slot_off(int epw) { return (64 + (size_t)epw * 8 + 15) & ~(size_t)15; }
 
 __device__ __forceinline__ WLds wlds_of(unsigned char* base, int epw)
 {
     WLds l;
     l.word = reinterpret_cast<u64*>(base);
+    l.fwd = reinterpret_cast<u64*>(base + 8);
     l.arrive = reinterpret_cast<int*>(base + 16);
     l.pprog = reinterpret_cast<int*>(base + 64);
     l.rread = l.pprog + epw;
-    const size_t cam_off = (64 + (size_t)epw * 8 + 15) & ~(size_t)15;
-    l.lcam = reinterpret_cast<float4*>(base + cam_off);
-    l.lst = reinterpret_cast<float*>(base + cam_off + (size_t)kCamDepth * epw * 16);
+    l.slot = reinterpret_cast<float*>(base + wlds_slot_off(epw));
+    l.lst = l.slot + (size_t)kCamDepth * epw * kSlotWords;
     return l;
 }
 
 __host__ __device__ inline size_t wlds_bytes(int epw)
 {
-    const size_t cam_off = (64 + (size_t)epw * 8 + 15) & ~(size_t)15;
-    return cam_off + (size_t)kCamDepth * epw * 16 + (size_t)epw * 64;
+    return wlds_slot_off(epw) + (size_t)kCamDepth * epw * kSlotWords * 4 + (size_t)epw * 64;
 }
 
 // a bounded wait gave up: tell the host, every workgroup (device word) and this workgroup (LDS word)
@@ -164,49 +181,119 @@ __device__ __forceinline__ void worker_abort(const WParams& wp, const WLds& l, u
 
 struct Leader { u64 known, t_last, t_start; };
 
-// dispatcher (workgroup 0's leader): copy newly posted entries host -> device, then republish the count
-__device__ __forceinline__ void dispatcher_publish(const WParams& wp, const WLds& l, Leader& L, u64 hp, bool leaving, int lane)
+// dispatcher = physics wave 0 of workgroup 0, and nothing else (that workgroup's envs go to its other three physics waves): a
+// poll is a PCIe round trip of several microseconds, which must not sit in front of any env's integration.  One poll = two
+// wave instructions in flight together: the 64 lanes read the WHOLE ring (8 lines of 64 B; lane k = word k % 8 of slot k / 8),
+// then the close word.  Every slot whose tag continues the sequence is a post: the lines go on to the device ring (sc1),
+// then the count is republished (device word for the other workgroups' leaders, LDS word for this workgroup).
+__device__ __forceinline__ u64 lane_u64(u64 v, int k)
 {
-    for (u64 q = L.known; q < hp; ++q) {
-        const u64* src = reinterpret_cast<const u64*>(&wp.mb->ring[q & (kSlots - 1)]);
-        u64* dst = reinterpret_cast<u64*>(&wp.dc->ring[q & (kSlots - 1)]);
-        if (lane < 8) agent_store64(dst + lane, sys_load64(src + lane));
-    }
-    drain_vmem();
-    const u64 w = hp | (leaving ? kExitBit : 0ull);
-    if (lane == 0) { agent_store64(&wp.dc->word, w); lds_store64(l.word, w); }
-    drain_vmem();
-    L.known = hp;
+    return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), k) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, k);
 }
 
-__device__ __forceinline__ void dispatcher_poll(const WParams& wp, const WLds& l, Leader& L, int lane)
+__device__ __forceinline__ int dispatcher_take(const WParams& wp, const WLds& l, Leader& L, int lane, bool& close_req)
 {
-    const u64 now = (u64)wall_clock64();
-    const u64 hp = sys_load64(&wp.mb->posted);
-    if (hp > L.known) { dispatcher_publish(wp, l, L, hp, false, lane); L.t_last = now; return; }
-    const unsigned hc = sys_load32(&wp.mb->close);
-    if (hc != 0u || now - L.t_last > wp.idle_ticks || now - L.t_start > wp.life_ticks) {
+    const u64 v = sys_load64(reinterpret_cast<const u64*>(&wp.mb->ring[0]) + lane);
+    const u64 c = sys_load64(&wp.mb->close);
+    close_req = c != 0ull;
+    int fresh = 0;
+    for (; fresh < kSlots; ++fresh) {
+        const int slot = (int)((L.known + (u64)fresh) & (kSlots - 1));
+        const int src = slot * 8 + 5;                        // u64 word 5 of a line = its tag
+        const u64 tag = ((u64)(unsigned)__shfl((int)(v >> 32), src, 64) << 32) | (u64)(unsigned)__shfl((int)v, src, 64);
+        if (tag != L.known + (u64)fresh + 1) break;
+    }
+    if (fresh == 0) return 0;
+    const int rel = (int)(((u64)(lane >> 3) - L.known) & (kSlots - 1));   // this lane's slot is the rel-th behind `known`
+    if (rel < fresh) agent_store64(reinterpret_cast<u64*>(&wp.dc->ring[0]) + lane, v);
+    drain_vmem();                                            // the entries are in the device ring before the count says so
+    L.known += (u64)fresh;
+    if (lane == 0) {                                         // max, not store: an abort bit another workgroup has set stays
+        __hip_atomic_fetch_max(&wp.dc->word, L.known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_store64(l.word, L.known);
+    }
+    return fresh;
+}
+
+// The dispatcher's whole life.  It leaves — and with it, after the steps below the final count, every wave of the launch — when
+// the host asks (close), when nothing was posted for idle_us although everything published is rendered, or when the launch's
+// lifetime is spent (the host starts a new worker at its next post).
+__device__ __forceinline__ void dispatcher_run(const WParams& wp, const WLds& l, int lane)
+{
+    Leader L{wp.start, (u64)wall_clock64(), (u64)wall_clock64()};
+    for (;;) {
+        if ((lds_load64(l.word) | agent_load64(&wp.dc->word)) & kAbortBit) {   // some wave gave up: this workgroup learns of it here
+            if (lane == 0) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        const u64 now = (u64)wall_clock64();
+        bool close_req = false;
+        const int fresh = dispatcher_take(wp, l, L, lane, close_req);
+        const bool busy = (u64)lds_load64(l.fwd) < L.known;           // this workgroup has not finished everything published
+        if (fresh || busy) L.t_last = now;
+        const bool leave = (!fresh && (close_req || now - L.t_last > wp.idle_ticks)) || now - L.t_start > wp.life_ticks;
+        if (!leave) { if (!fresh) __builtin_amdgcn_s_sleep(16); continue; }
         if (lane == 0) sys_store64(&wp.mb->exited, 1ull);
-        drain_vmem();                                        // `exited` is in host memory before the last look at `posted`
-        const u64 hp2 = sys_load64(&wp.mb->posted);
-        if (lane == 0) sys_store64(&wp.mb->consumed, hp2);
-        dispatcher_publish(wp, l, L, hp2, true, lane);
+        drain_vmem();                                        // `exited` is in host memory before the last look at the ring
+        (void)dispatcher_take(wp, l, L, lane, close_req);    // whatever was posted before that look is still served by this launch
+        if (lane == 0) {
+            sys_store64(&wp.mb->consumed, L.known);
+            const u64 w = L.known | kExitBit;                // the EXIT bit goes out once, with the FINAL count
+            __hip_atomic_fetch_max(&wp.dc->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds_store64(l.word, w);
+        }
+        drain_vmem();
         return;
     }
-    __builtin_amdgcn_s_sleep(8);
 }
 
-// 1 = step s is posted (go), 0 = leave.  Leaders refresh the workgroup's LDS word; the others only read it.
-__device__ __forceinline__ int wait_posted(const WParams& wp, const WLds& l, bool leader, Leader& L, u64 s, int lane)
+// A raster wave whose stores of step s are in memory says so in LDS — and nothing more: a returning global atomic would make
+// it wait for ALL its outstanding stores, the newer steps' too.
+__device__ __forceinline__ void raster_arrive(const WLds& l, u64 s, int lane)
+{
+    if (lane == 0) __hip_atomic_fetch_add(&l.arrive[s & (kSlots - 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The forwarder (the workgroup's last physics wave: it never stores to global memory, so it has nothing to drain) watches the
+// LDS counters in its idle moments.  All eight raster waves in: it arrives for the workgroup on a device counter sharded by
+// blockIdx % 8; the last workgroup of a shard arrives on the top counter; the last shard tells the host.
+__device__ __forceinline__ void forward_arrivals(const WParams& wp, const WLds& l, u64& fwd, int lane)
+{
+    const int slot = (int)(fwd & (kSlots - 1));
+    if (lds_load32(&l.arrive[slot]) != kRasterThreads / 64) return;
+    if (lane == 0) {
+        lds_store32(&l.arrive[slot], 0);
+        const int shard = (int)(blockIdx.x & 7u), nshards = min(8, wp.n_blocks);
+        const unsigned members = (unsigned)((wp.n_blocks - shard + 7) / 8);
+        unsigned* a = &wp.dc->arrive[slot][shard][0];
+        if (__hip_atomic_fetch_add(a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            __hip_atomic_store(a, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned* t = &wp.dc->top[slot][0];
+            if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nshards - 1u) {
+                __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                drain_vmem();                                // the counters are back at zero before the host can post step fwd + 8
+                sys_store64(&wp.mb->done[slot], fwd + 1);
+            }
+        }
+    }
+    fwd += 1;
+    if (lane == 0) lds_store64(l.fwd, fwd);
+}
+
+// What a waiting physics wave does on the side: the leader keeps the workgroup's LDS word fresh (workgroup 0's also talks to
+// the host), the forwarder passes completed steps on.
+struct Duties { bool leader, forwarder; u64 fwd; };
+
+// 1 = step s is posted (go), 0 = leave.
+__device__ __forceinline__ int wait_posted(const WParams& wp, const WLds& l, Duties& D, u64 s, int lane)
 {
     u64 t0 = 0;
     for (unsigned spins = 0;; ++spins) {
+        if (D.forwarder) forward_arrivals(wp, l, D.fwd, lane);
         const u64 w = lds_load64(l.word);
         if (w & kAbortBit) return 0;
         if ((w & kCountMask) > s) return 1;
         if (w & kExitBit) return 0;
-        if (leader) {
-            if (blockIdx.x == 0) { dispatcher_poll(wp, l, L, lane); continue; }
+        if (D.leader) {                                      // (workgroup 0 has no leader: its dispatcher writes the LDS word itself)
             const u64 g = agent_load64(&wp.dc->word);
             if (g != w) { if (lane == 0) lds_store64(l.word, g); drain_lds(); continue; }
         }
@@ -220,11 +307,12 @@ __device__ __forceinline__ int wait_posted(const WParams& wp, const WLds& l, boo
 }
 
 // bounded wait on an LDS counter; 0 = gave up / aborted
-__device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, const int* ctr, int want, unsigned code)
+__device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, Duties* D, const int* ctr, int want, unsigned code, int lane)
 {
     u64 t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         if (lds_load32(ctr) >= want) return 1;
+        if (D && D->forwarder) forward_arrivals(wp, l, D->fwd, lane);
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 1023u) == 1023u) {
             if (lds_load64(l.word) & kAbortBit) return 0;
@@ -235,34 +323,13 @@ __device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, con
     }
 }
 
-// this wave has finished step s: drain its stores, arrive; the last wave of the workgroup arrives for the workgroup, the last
-// workgroup of a shard for the shard, the last shard tells the host
-__device__ __forceinline__ void wave_arrive(const WParams& wp, const WLds& l, u64 s, int lane)
-{
-    drain_vmem();
-    if (lane != 0) return;
-    const int slot = (int)(s & (kSlots - 1));
-    const int old = __hip_atomic_fetch_add(&l.arrive[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (old != kWaves - 1) return;
-    lds_store32(&l.arrive[slot], 0);
-    const int shard = (int)(blockIdx.x & 7u), nshards = min(8, wp.n_blocks);
-    const unsigned members = (unsigned)((wp.n_blocks - shard + 7) / 8);
-    unsigned* a = &wp.dc->arrive[slot][shard][0];
-    if (__hip_atomic_fetch_add(a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1u) return;
-    __hip_atomic_store(a, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned* t = &wp.dc->top[slot][0];
-    if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nshards - 1u) return;
-    __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    drain_vmem();                                            // the counters are back at zero before the host can post step s + 8
-    sys_store64(&wp.mb->done[slot], s + 1);
-}
-
 template <bool DEPTH>
 __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool raster_team = tid < kRasterThreads;
     const RParams& p = wp.ra;
+    const PParams& P = wp.ph;
     const int epw = p.envs_per_wg;
     const WLds l = wlds_of(smem + wp.lds_off_ctl, epw);
     const int e_begin = blockIdx.x * epw;
@@ -279,46 +346,48 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     }
     // ---- once per launch: tables by LDS-DMA, control block, env state ----
     if (raster_team) stage_lds_dma(p.blob, p.blob_bytes, 0u, wave, kRasterThreads / 64, lane);
-    else stage_lds_dma(wp.ph.blob, wp.ph.blob_bytes, (unsigned)wp.lds_off_phys, pw, kPhysWaves, lane);
-    if (tid == 0) lds_store64(l.word, wp.start);
+    else stage_lds_dma(P.blob, P.blob_bytes, (unsigned)wp.lds_off_phys, pw, kPhysWaves, lane);
+    if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
     if (tid < kSlots) l.arrive[tid] = 0;
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
     if (!raster_team)
         for (int j = pw; j < n_loc; j += kPhysWaves) {
             EnvRegs st;
-            env_load(wp.ph, e_begin + j, st);
+            env_load(P, e_begin + j, st);
+            const float lr = coherent_load(&P.last_return[e_begin + j]);
             if (lane == 0) {
                 float* q = l.lst + (size_t)j * 16;
                 q[0] = st.x; q[1] = st.y; q[2] = st.z; q[3] = st.yaw; q[4] = st.v; q[5] = st.sf; q[6] = st.epr;
                 q[7] = __int_as_float(st.seg); q[8] = __int_as_float(st.epl); q[9] = __int_as_float(st.done); q[10] = __int_as_float(st.pend);
+                q[11] = lr;
             }
         }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
     if (!raster_team) {
-        // ---- physics team ----
-        Leader L{wp.start, (u64)wall_clock64(), (u64)wall_clock64()};
-        const bool leader = pw == 0;
+        // ---- physics team: LDS in, LDS out.  It reads its controls (system-scope loads) and hands the new pose AND the step's
+        // telemetry to the raster team through the slot ring; it never stores to global memory, so no step of it ever waits for
+        // a store acknowledgement and it can run ahead of the raster team as far as posts and the ring allow. ----
+        const int first = blockIdx.x == 0 ? 1 : 0, nphys = kPhysWaves - first;   // workgroup 0: wave 0 is the dispatcher, three waves share the envs
+        if (pw < first) { dispatcher_run(wp, l, lane); return; }
+        Duties D{blockIdx.x != 0 && pw == 0, pw == kPhysWaves - 1, wp.start};
         const unsigned char* const lphys = smem + wp.lds_off_phys;
-        const PParams& P = wp.ph;
-        for (u64 s = wp.start;; ++s) {
+        u64 s = wp.start;
+        for (;; ++s) {
             const int r = (int)(s - wp.start);
-            if (!wait_posted(wp, l, leader, L, s, lane)) return;
+            if (!wait_posted(wp, l, D, s, lane)) break;
             const u64* en = reinterpret_cast<const u64*>(&wp.dc->ring[s & (kSlots - 1)]);
             const u64 ev = lane < 5 ? agent_load64(en + lane) : 0ull;
-            auto bcast = [&](int k) -> u64 {
-                return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(ev >> 32), k) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)ev, k);
-            };
-            const float* const c_st = reinterpret_cast<const float*>(bcast(0));
-            const float* const c_th = reinterpret_cast<const float*>(bcast(1));
-            const float* const c_br = reinterpret_cast<const float*>(bcast(2));
-            const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(bcast(3));
-            const int synth = (int)(unsigned)bcast(4);
-            for (int j = pw; j < n_loc; j += kPhysWaves) {
+            const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 0));
+            const float* const c_th = reinterpret_cast<const float*>(lane_u64(ev, 1));
+            const float* const c_br = reinterpret_cast<const float*>(lane_u64(ev, 2));
+            const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(lane_u64(ev, 3));
+            const int synth = (int)(unsigned)lane_u64(ev, 4);
+            for (int j = pw - first; j < n_loc; j += nphys) {
                 const int e = e_begin + j;
-                // back-pressure: camera slot r % kCamDepth is free once every raster wave has read step r - kCamDepth of this env
-                if (r >= kCamDepth && !wait_lds_ge(wp, l, &l.rread[j], (r - kCamDepth + 1) * (kRasterThreads / 64), 2u)) return;
+                // back-pressure: slot r % kCamDepth is free once every raster wave has read step r - kCamDepth of this env
+                if (r >= kCamDepth && !wait_lds_ge(wp, l, &D, &l.rread[j], (r - kCamDepth + 1) * (kRasterThreads / 64), 2u, lane)) return;
                 float steer = 0.f, thr = 0.f, brk = 0.f;
                 uint8_t rin = 0;
                 if (!synth) {
@@ -331,46 +400,114 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                 st.x = q[0]; st.y = q[1]; st.z = q[2]; st.yaw = q[3]; st.v = q[4]; st.sf = q[5]; st.epr = q[6];
                 st.seg = __float_as_int(q[7]); st.epl = __float_as_int(q[8]); st.done = __float_as_int(q[9]); st.pend = __float_as_int(q[10]);
                 st.speed = 0.f; st.cte = 0.f;
+                float lr = q[11];
+                const float epr_before = st.epr;
                 StepOut o;
-                env_advance<true>(P, lphys, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o);
+                env_advance<true, false>(P, lphys, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o);
+                if (o.do_reset) lr = epr_before;
                 if (lane == 0) {
                     q[0] = st.x; q[1] = st.y; q[2] = st.z; q[3] = st.yaw; q[4] = st.v; q[5] = st.sf; q[6] = st.epr;
                     q[7] = __int_as_float(st.seg); q[8] = __int_as_float(st.epl); q[9] = __int_as_float(st.done); q[10] = __int_as_float(st.pend);
-                    l.lcam[(size_t)(r & (kCamDepth - 1)) * epw + j] = o.cam;
-                    store_out<true>(&P.x[e], st.x); store_out<true>(&P.y[e], st.y); store_out<true>(&P.z[e], st.z);
-                    store_out<true>(&P.yaw[e], st.yaw); store_out<true>(&P.v[e], st.v); store_out<true>(&P.speed[e], st.speed);
-                    store_out<true>(&P.cte[e], st.cte); store_out<true>(&P.seg_idx[e], (int32_t)st.seg);
-                    store_out<true>(&P.done[e], (uint8_t)st.done); store_out<true>(&P.ep_return[e], st.epr);
-                    store_out<true>(&P.ep_len[e], (int32_t)st.epl); store_out<true>(&P.steer_filt[e], st.sf);
-                    store_out<true>(&P.pending[e], (uint8_t)0);
+                    q[11] = lr;
+                    float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
+                    *reinterpret_cast<float4*>(sl) = o.cam;
+                    sl[4] = st.x; sl[5] = st.y; sl[6] = st.z; sl[7] = st.yaw; sl[8] = st.v; sl[9] = st.speed; sl[10] = st.cte;
+                    sl[11] = __int_as_float(st.seg); sl[12] = st.epr; sl[13] = __int_as_float(st.epl); sl[14] = st.sf; sl[15] = lr;
+                    sl[16] = __int_as_float(st.done);
                     if (o.is_done) atomicAdd(&P.stats[0], 1ull);
                     if (o.do_reset) atomicAdd(&P.stats[1], 1ull);
-                    drain_lds();                              // state and camera parameters are in LDS before the counter moves
+                    drain_lds();                              // the slot is in LDS before the counter moves
                     lds_store32(&l.pprog[j], r + 1);
                 }
             }
-            wave_arrive(wp, l, s, lane);
         }
+        // leaving: the forwarder stays until every step this launch took (s of them) has been passed on
+        if (D.forwarder) {
+            u64 t0 = 0;
+            for (unsigned spins = 0; D.fwd < s; ++spins) {
+                forward_arrivals(wp, l, D.fwd, lane);
+                if (lds_load64(l.word) & kAbortBit) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((spins & 1023u) == 1023u) {
+                    const u64 now = (u64)wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > wp.safety_ticks) { worker_abort(wp, l, 4u); break; }
+                }
+            }
+        }
+        return;
     }
 
     // ---- raster team ----
+    // A wave's stores of step s must be in memory before it arrives for s, and a store takes microseconds to be acknowledged —
+    // about as long as a whole step of a small shard.  A wave that waited for its acknowledgements at the end of every step
+    // would issue nothing meanwhile (all eight waves drain together: the CU's store path runs dry once per step).  So arrivals
+    // LAG: with K steps of lag the wave arrives for step s - K after issuing step s's uniform rows, behind a counted wait
+    // (vmcnt(N), N = the store instructions it has issued since the end of step s - K; a raster wave issues only stores and
+    // they are acknowledged in order) — what it waits for was issued K steps ago.  K is as large as the 6-bit counter allows
+    // (N <= 63), at most 3, and never more than the posts queued behind this step allow: a consumer that keeps two steps in
+    // flight gets step s's completion after step s + 1's uniform rows, a lock-step consumer at once (drain, arrive).
     const RasterThread rth = raster_thread(p, smem, tid);
-    Leader none{0, 0, 0};
+    int nu = 0, ng = 0;
+    for (int v = rth.vstart; v < p.uni_rows; v += p.rows_per_pass) ++nu;
+    for (int v = rth.vground; v < p.H; v += p.rows_per_pass) ++ng;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { nu = max(nu, __shfl_xor(nu, off, 64)); ng = max(ng, __shfl_xor(ng, off, 64)); }   // instructions the WAVE issues per env
+    nu *= DEPTH ? 2 : 1; ng *= DEPTH ? 2 : 1;
+    int own = 0;                                              // envs whose telemetry this wave writes out (2 store instructions each)
+    for (int j = wave; j < n_loc; j += kRasterThreads / 64) ++own;
+    const int nuni = nu * n_loc, nstep = (nu + ng) * n_loc + 2 * own;
+    const int lag = (2 * nstep + nuni <= 63) ? 3 : ((nstep + nuni <= 63) ? 2 : 1);
+    // this lane's telemetry array (lanes 0..11: 4-byte arrays in slot-word order, lanes 12, 13: the byte arrays done, pending)
+    unsigned char* optr = nullptr;
+    {
+        unsigned char* const tab[14] = {(unsigned char*)P.x, (unsigned char*)P.y, (unsigned char*)P.z, (unsigned char*)P.yaw, (unsigned char*)P.v,
+                                        (unsigned char*)P.speed, (unsigned char*)P.cte, (unsigned char*)P.seg_idx, (unsigned char*)P.ep_return,
+                                        (unsigned char*)P.ep_len, (unsigned char*)P.steer_filt, (unsigned char*)P.last_return,
+                                        (unsigned char*)P.done, (unsigned char*)P.pending};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) optr = lane == k ? tab[k] : optr;
+    }
+    Duties none{false, false, 0};
+    u64 owed = wp.start;                                      // oldest step this wave has not arrived for
     for (u64 s = wp.start;; ++s) {
         const int r = (int)(s - wp.start);
-        if (!wait_posted(wp, l, false, none, s, lane)) return;
+        if (owed < s && (lds_load64(l.word) & kCountMask) <= s) {   // nothing further posted: do not make the host wait
+            drain_vmem();
+            for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+        }
+        if (!wait_posted(wp, l, none, s, lane)) {
+            drain_vmem();
+            for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+            return;
+        }
         uint8_t* const img = (s & 1ull) ? wp.img1 : wp.img0;
         float* const dep = (s & 1ull) ? wp.dep1 : wp.dep0;
         for (int j = 0; j < n_loc; ++j)                      // rows that need no pose: every env's first, while the physics team integrates
             raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j));
+        // the lag shrinks with the queue: with only `ahead` steps posted beyond this one the consumer is waiting for frames
+        const u64 ahead = (lds_load64(l.word) & kCountMask) - 1 - s;
+        const u64 keep = ahead + 1 < (u64)lag ? ahead + 1 : (u64)lag;
+        while (s - owed >= keep) {
+            wait_vmcnt_le((int)(s - owed - 1) * nstep + nuni);
+            raster_arrive(l, owed++, lane);
+        }
         for (int j = 0; j < n_loc; ++j) {
-            if (!wait_lds_ge(wp, l, &l.pprog[j], r + 1, 3u)) return;
-            const float4 cam = l.lcam[(size_t)(r & (kCamDepth - 1)) * epw + j];
-            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w) : "memory");
+            if (!wait_lds_ge(wp, l, nullptr, &l.pprog[j], r + 1, 3u, lane)) return;
+            const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
+            const float4 cam = *reinterpret_cast<const float4*>(sl);
+            const bool mine = (j % (kRasterThreads / 64)) == wave;
+            unsigned tel = 0;
+            if (mine) tel = __float_as_uint(sl[4 + min(lane, 12)]);      // lanes 0..11 their word, lane 12 `done`
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel) : "memory");
             if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             raster_ground_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j), cam);
+            if (mine) {                                       // the step's telemetry of env j: two wave instructions, written through
+                const size_t e = (size_t)(e_begin + j);
+                if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
-        wave_arrive(wp, l, s, lane);
     }
 }
 
@@ -398,8 +535,11 @@ int worker_launch(trs_env* e, uint64_t start)
 {
     Resident* R = e->res;
     Mailbox* mb = R->mb;
+    R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables of the track that is loaded NOW
+    R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
+    if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
     host_store(&mb->exited, 0); host_store(&mb->consumed, start); host_store(&mb->error, 0);
-    __atomic_store_n(&mb->close, 0u, __ATOMIC_RELEASE);
+    host_store(&mb->close, 0);
     WParams wp{};
     wp.ph = e->pp; wp.ph.synth = 0; wp.ph.write_cam = 0; wp.ph.n_steps = 0; wp.ph.step_off = 0; wp.ph.ctl_stride = 0;
     wp.ra = e->rp;
@@ -407,7 +547,11 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.mb = mb; wp.dc = R->dc;
     wp.start = start;
     wp.idle_ticks = (unsigned long long)R->idle_us * 100ull;
-    wp.life_ticks = 50000000ull;                            // 0.5 s: then the dispatcher leaves at the next lull and the host relaunches
+    wp.life_ticks = 50000000ull;                            // 0.5 s: then the dispatcher leaves and the host starts a new worker at its next post
+    if (const char* lf = std::getenv("TRS_RESIDENT_LIFE_US")) {   // tests: force many worker generations in a short run
+        const long v = std::atol(lf);
+        if (v > 0) wp.life_ticks = (unsigned long long)v * 100ull;
+    }
     wp.safety_ticks = 200000000ull;                         // 2 s
     wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl;
     const int grid = (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg;
@@ -494,12 +638,15 @@ int resident_post(trs_env* e, const float* st, const float* th, const float* br,
     Mailbox* mb = R->mb;
     for (int k = 0; k < n; ++k) {
         const uint64_t s = e->step_count;
+        if (!R->running) R->base = R->seen_done = s;           // no worker: nothing is in flight (the step counter may have moved or restarted since)
         if (s >= R->base + kSlots) { int rc = wait_done(e, s - kSlots); if (rc) return rc; }   // ring slot, counters and done flag of s % 8 are free
         WEntry en{};
         const size_t off = (size_t)k * stride;
         en.steer = st ? st + off : nullptr; en.thr = th ? th + off : nullptr; en.brk = br ? br + off : nullptr;
         en.reset = k == 0 ? rs : nullptr; en.synth = synth ? 1u : 0u;
-        std::memcpy(&mb->ring[s & (kSlots - 1)], &en, sizeof en);
+        WEntry* slot = &mb->ring[s & (kSlots - 1)];
+        slot->steer = en.steer; slot->thr = en.thr; slot->brk = en.brk; slot->reset = en.reset; slot->synth = en.synth;
+        host_store(&slot->seq, s + 1);                            // the tag last (x86 keeps the store order): the line is now a valid post
         host_store(&mb->posted, s + 1);
         std::atomic_thread_fence(std::memory_order_seq_cst);     // the post is visible before `exited` is read
         e->step_count = s + 1;
@@ -522,12 +669,14 @@ int resident_quiesce(trs_env* e)
     if (!R || !R->mb) return TRS_OK;
     int rc = TRS_OK;
     for (int guard = 0; R->running && guard < 4; ++guard) {
-        __atomic_store_n(&R->mb->close, 1u, __ATOMIC_RELEASE);
+        host_store(&R->mb->close, 1);
         rc = handle_exit(e);                                 // waits for the kernel; relaunches (with `close` cleared) if posts raced
         if (rc) break;
     }
     if (!rc && R->running) rc = trs_internal_fail(TRS_ERR_DEVICE, "resident worker did not leave");
     R->base = R->seen_done = e->step_count;
+    if (!R->running)                                         // tags and flags of the past must not match a step index that comes round again
+        for (int k = 0; k < kSlots; ++k) { host_store(&R->mb->ring[k].seq, 0); host_store(&R->mb->done[k], 0); }
     return rc;
 }
 
@@ -535,7 +684,7 @@ void resident_destroy(trs_env* e)
 {
     Resident* R = e->res;
     if (!R) return;
-    if (R->running) { __atomic_store_n(&R->mb->close, 1u, __ATOMIC_RELEASE); (void)hipStreamSynchronize(e->sP); }
+    if (R->running) { host_store(&R->mb->close, 1); (void)hipStreamSynchronize(e->sP); }
     if (R->mb) (void)hipHostFree(R->mb);
     if (R->hctl) (void)hipHostFree(R->hctl);
     (void)hipFree(R->dc);
@@ -551,6 +700,7 @@ int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const f
 {
     Resident* R = e->res;
     const uint64_t s = e->step_count;
+    if (!R->running) R->base = R->seen_done = s;
     if (s >= R->base + kSlots) { int rc = wait_done(e, s - kSlots); if (rc) return rc; }     // the staging slot is free as well
     unsigned char* slot = R->hctl + (s & (kSlots - 1)) * R->hctl_slot;
     const size_t n = (size_t)e->n;
