@@ -243,6 +243,13 @@ def main():
         env.event_record(7)
         ms_one = env.event_elapsed_ms(6, 7)
         wall_one = time.perf_counter() - t1
+        lock_steps = min(args.steps, 500)
+        env.sync()
+        t4 = time.perf_counter()
+        for _ in range(lock_steps):                               # lock-step with launches: step, wait for the frame (stream synchronisation), step
+            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.sync()
+        wall_lock_launch = time.perf_counter() - t4
         # ... the same loop in resident mode: every call only posts its control pointers to the worker kernel
         env.set_step_mode(True)
         for _ in range(min(50, args.steps)):
@@ -258,7 +265,6 @@ def main():
         # ... and lock-step: the consumer waits for every frame before it posts the next step (PCIe round trips included)
         env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
         env.sync()
-        lock_steps = min(args.steps, 500)
         t3 = time.perf_counter()
         for _ in range(lock_steps):
             env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
@@ -270,6 +276,7 @@ def main():
         frac = lambda ms: round(Bx * n * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         also = {"single_step_call": {"env_steps_per_s": rate(ms_one), "frac_of_hbm_peak": frac(ms_one), "us_per_call": round(ms_one * 1e3 / args.steps, 3),
                                      "host_wall_us_per_call": round(wall_one * 1e6 / args.steps, 3),
+                                     "lock_step_us_per_call": round(wall_lock_launch * 1e6 / lock_steps, 3),
                                      "note": "trs_step(device controls, n_steps = 1) called once per step: the consumer-paced path (one launch per call, raster waits for that step's physics); device time by HIP events"},
                 "resident_single_step_call": {"env_steps_per_s": rate(ms_res), "frac_of_hbm_peak": frac(ms_res), "us_per_call": round(ms_res * 1e3 / args.steps, 3),
                                               "host_wall_us_per_call": round(wall_res * 1e6 / args.steps, 3),

@@ -14,14 +14,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "triton-racer-sim_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-PACKED = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32)\s+(v\[\d+:\d+\]),\s*(.*)$")
+# EVERY packed op with a 64-bit destination (today the three TUs emit v_pk_{mul,add,fma}_f32 only; v_pk_mov_b32 and whatever a
+# later compiler picks are covered by the same pattern).  16-bit packed forms have 32-bit operands (one register, no pair):
+# the pattern does not match them and `test_packed_mnemonics_are_known` fails when one appears, so that it gets looked at.
+PACKED = re.compile(r"^\s*(v_pk_\w+)\s+(v\[(\d+):(\d+)\]),\s*(.*)$")
+KNOWN_PACKED = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mov_b32"}
+PAIR = re.compile(r"^v\[(\d+):(\d+)\]$")
 
 
 def cross_half_in_place(line):
+    """True for a packed op whose 64-bit destination overlaps a source pair such that a half of the result is computed from a
+    register the other half's result is written to: the same pair with a cross-half select (the form that misbehaved), or a
+    pair shifted by one register whose overlapping register is read by the half that does not write it."""
     m = PACKED.match(line)
     if not m:
         return False
-    dst, rest = m.group(2), m.group(3)
+    d_lo, d_hi, rest = int(m.group(3)), int(m.group(4)), m.group(5)
+    if d_hi != d_lo + 1:
+        return False
     ops = [o.strip() for o in rest.split(" op_sel")[0].split(" neg_")[0].split(",")]
     sel = {"op_sel": None, "op_sel_hi": None}
     for key in sel:
@@ -29,11 +39,17 @@ def cross_half_in_place(line):
         if k:
             sel[key] = [int(x) for x in k.group(1).split(",")]
     for i, op in enumerate(ops):
-        if op != dst:
+        pm = PAIR.match(op)
+        if not pm:
             continue
+        s_lo, s_hi = int(pm.group(1)), int(pm.group(2))
+        if s_hi != s_lo + 1 or s_hi < d_lo or s_lo > d_hi:
+            continue                                           # no shared register
         lo = sel["op_sel"][i] if sel["op_sel"] and i < len(sel["op_sel"]) else 0          # default: lo result reads the low register
         hi = sel["op_sel_hi"][i] if sel["op_sel_hi"] and i < len(sel["op_sel_hi"]) else 1  # default: hi result reads the high register
-        if lo != 0 or hi != 1:
+        reg_for_lo, reg_for_hi = (s_hi if lo else s_lo), (s_hi if hi else s_lo)
+        # the lo result is written to d_lo, the hi result to d_hi: each half may only read "its own" destination register
+        if reg_for_lo == d_hi or reg_for_hi == d_lo:
             return True
     return False
 
@@ -44,16 +60,52 @@ def test_the_screen_recognises_the_faulty_form():
     assert not cross_half_in_place("\tv_pk_fma_f32 v[54:55], v[54:55], v[50:51], s[26:27] op_sel_hi:[1,0,1]")
     assert not cross_half_in_place("\tv_pk_fma_f32 v[28:29], v[14:15], v[2:3], v[0:1] op_sel_hi:[0,1,1]")
     assert cross_half_in_place("\tv_pk_add_f32 v[32:33], v[32:33], v[30:31] op_sel_hi:[0,1]")
+    assert cross_half_in_place("\tv_pk_mov_b32 v[4:5], v[4:5], v[4:5] op_sel:[1,0]")          # any packed mnemonic, not only the arithmetic ones
+    assert cross_half_in_place("\tv_pk_mul_f32 v[14:15], v[13:14], v[20:21]")                  # shifted pair: the hi result reads v14, which the lo result overwrites
+    assert cross_half_in_place("\tv_pk_mul_f32 v[14:15], v[15:16], v[20:21] op_sel_hi:[1,1]")       # ... and the mirror image: the lo result reads v15, which the hi result overwrites
+    assert not cross_half_in_place("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]")       # no shared register
 
 
-@pytest.mark.parametrize("src", ["trsim_hip.hip", "trsim_pilot.hip"])
-def test_no_in_place_cross_half_packed_fp32(src, tmp_path):
-    if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
-        pytest.skip("hipcc not available")
-    import __graft_entry__ as g
-    flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-    out = tmp_path / (src + ".s")
-    subprocess.check_call([HIPCC] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(CSRC, src)],
-                          stderr=subprocess.DEVNULL)
-    bad = [l.strip() for l in open(out) if cross_half_in_place(l)]
-    assert not bad, f"{src}: in-place packed FP32 ops that read the overwritten register across halves: {bad[:5]}"
+_ASM = {}
+
+
+def device_asm(src, tmp_path_factory):
+    if src not in _ASM:
+        if not shutil.which(HIPCC) and not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        import __graft_entry__ as g
+        flags = [f for f in g.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+        out = tmp_path_factory.mktemp("asm") / (src + ".s")
+        subprocess.check_call([HIPCC] + flags + ["-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", str(out), os.path.join(CSRC, src)],
+                              stderr=subprocess.DEVNULL)
+        _ASM[src] = open(out).read()
+    return _ASM[src]
+
+
+SOURCES = ["trsim_hip.hip", "trsim_resident.hip", "trsim_pilot.hip"]
+
+
+@pytest.mark.parametrize("src", SOURCES)
+def test_no_in_place_cross_half_packed_op(src, tmp_path_factory):
+    bad = [l.strip() for l in device_asm(src, tmp_path_factory).splitlines() if cross_half_in_place(l)]
+    assert not bad, f"{src}: packed ops that read a register the other half's result overwrites: {bad[:5]}"
+
+
+@pytest.mark.parametrize("src", SOURCES)
+def test_packed_mnemonics_are_known(src, tmp_path_factory):
+    seen = set(re.findall(r"^\s*(v_pk_\w+)", device_asm(src, tmp_path_factory), flags=re.M))
+    assert seen <= KNOWN_PACKED, f"{src}: new packed instruction forms {sorted(seen - KNOWN_PACKED)}: extend the screen (16-bit forms have one-register operands)"
+
+
+@pytest.mark.parametrize("src,kernels", [("trsim_hip.hip", "trs_step_kernel"), ("trsim_resident.hip", "trs_worker_kernel")])
+def test_map_kernels_have_no_static_lds_and_no_scratch(src, kernels, tmp_path_factory):
+    """The rasteriser addresses the class map at LDS offset 0: the dynamic segment starts there exactly when the kernel has no
+    static __shared__ (a compile-time property: .group_segment_fixed_size).  Also: no scratch, no VGPR spills."""
+    text = device_asm(src, tmp_path_factory)
+    blocks = re.findall(r"- \.agpr_count:.*?\.wavefront_size:\s*\d+", text, flags=re.S)
+    mine = [b for b in blocks if kernels in b]
+    assert mine, f"no metadata for {kernels}"
+    for b in mine:
+        assert re.search(r"\.group_segment_fixed_size:\s*0\b", b), b[:400]
+        assert re.search(r"\.private_segment_fixed_size:\s*0\b", b), b[:400]
+        assert re.search(r"\.vgpr_spill_count:\s*0\b", b), b[:400]

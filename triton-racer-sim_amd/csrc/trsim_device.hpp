@@ -28,6 +28,7 @@ struct PParams {                        // physics kernel
     const float* start_yaw;             // [np]
     const float* tangent_g;             // [np][2] global copy, used when the table does not fit in LDS
     unsigned long long* stats;          // [0] off-track events, [1] resets, [2] layout faults, [8..] diagnostics
+    unsigned long long* fault;          // pinned host word: non-zero = a kernel refused to run (layout fault); checked at every synchronisation
     int n_envs, env_id_base, envs_per_wg, np;
     int off_py, off_pz, off_tan, blob_bytes, off_scratch, tan_in_lds;
     int off_gstart, off_gpts, grid_nx, grid_nz;   // nearest-point accelerator: uint16 cell starts / point lists in the LDS image
@@ -43,6 +44,7 @@ struct PParams {                        // physics kernel
 struct RParams {                        // raster side of the step kernel
     const unsigned char* blob;          // raster LDS image: map (pitched rows) @0 | rowtab | palette
     unsigned long long* stats;
+    unsigned long long* fault;          // see PParams
     int n_envs, envs_per_wg;
     int H, W, gpr, gpe, rows_per_pass;  // gpr/gpe: 4-pixel groups per row / per env
     int map_w, map_h, map_pitch_b;

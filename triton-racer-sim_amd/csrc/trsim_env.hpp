@@ -49,6 +49,7 @@ struct trs_env {
     int seq_stride = 0;                  // trs_step_sequence: n_envs while a sequence call is running, else 0
     int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
+    unsigned long long* fault = nullptr; // pinned host word the kernels set when they refuse to run (dynamic LDS not at offset 0)
     float* glue = nullptr; size_t glue_bytes = 0;   // device scratch of the *_host control glue (trs_driver_assist_host, trs_control_mux_host)
     trsim::Resident* res = nullptr;      // trsim_resident.hip: the resident worker (trs_set_step_mode), nullptr = never used
 };
@@ -64,4 +65,5 @@ hipStream_t resident_copy_stream(trs_env* e);             // a stream that is no
 int resident_wait(trs_env* e);                            // every posted step complete (the worker stays resident)
 int resident_quiesce(trs_env* e);                         // ... and the worker has left the GPU: the stream is free again
 void resident_destroy(trs_env* e);
+int check_fault(trs_env* e);                               // TRS_ERR_DEVICE (sticky) once a kernel has reported a layout fault
 }  // namespace trsim

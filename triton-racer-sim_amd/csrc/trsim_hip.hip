@@ -166,8 +166,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const bool raster_team = tid < kRasterThreads;
     const RParams& p = sp.ra;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;        // LDS byte address of the dynamic segment
-    if (lds0 != 0u) {                                       // the map addressing below assumes LDS offset 0
-        if (tid == 0 && blockIdx.x == 0) atomicAdd(&p.stats[2], 1ull);
+    if (lds0 != 0u) {                                       // the map addressing below assumes LDS offset 0 (no static __shared__ in this kernel:
+        if (tid == 0 && blockIdx.x == 0) {                  // tests/test_build_lint.py checks .group_segment_fixed_size == 0); refusing is LOUD:
+            atomicAdd(&p.stats[2], 1ull);                   // every later synchronisation of the handle fails (trsim::check_fault)
+            __hip_atomic_store(p.fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     STAMP(0);
@@ -870,7 +873,7 @@ int sync_all(trs_env* e)
 {
     if (e->res) { int rc = trsim::resident_quiesce(e); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->sP));
-    return TRS_OK;
+    return trsim::check_fault(e);
 }
 
 // anything about to be queued on the handle's stream must not end up behind a resident worker
@@ -1000,18 +1003,10 @@ TRS_EXPORT int trs_device_count(int* out)
     return TRS_OK;
 }
 
-TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
+namespace {
+// everything trs_create builds; on a failure the caller destroys the half-built handle
+int create_impl(const trs_config* cfg, int device, trs_env* e)
 {
-    if (!cfg || !out) return fail(TRS_ERR_ARG, "null argument");
-    if (cfg->struct_size != sizeof(trs_config)) return fail(TRS_ERR_ARG, "trs_config.struct_size mismatch");
-    if (cfg->n_envs < 1 || cfg->img_h < 2 || cfg->img_w < 4 || (cfg->img_w & 3) || cfg->env_id_base < 0)
-        return fail(TRS_ERR_ARG, "bad n_envs / image size (img_w must be a multiple of 4)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRS_ERR_DEVICE, "no HIP device visible (libtrsim has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(TRS_ERR_ARG, "device index out of range");
-    HIPCHK(hipSetDevice(device));
-    trs_env* e = new (std::nothrow) trs_env();
-    if (!e) return fail(TRS_ERR_NOMEM, "out of memory");
     e->cfg = *cfg; e->device = device; e->n = cfg->n_envs; e->H = cfg->img_h; e->W = cfg->img_w;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -1059,10 +1054,38 @@ TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
     k.drag_lin = cfg->drag_lin; k.roll_res = cfg->roll_res; k.brake_max = cfg->brake_max; k.v_max = cfg->v_max;
     k.v_rev_max = cfg->v_rev_max; k.offtrack_cte = cfg->offtrack_cte; k.offtrack_penalty = cfg->offtrack_penalty;
     k.cam_fwd = cfg->cam_fwd; k.auto_reset = cfg->auto_reset; k.seed = cfg->seed;
-    if (r.gpr > kBlock) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup"); }
-    if (r.gpr > kRasterThreads) { trs_destroy(e); return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than raster threads"); }
+    if (r.gpr > kBlock) return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than threads per workgroup");
+    if (r.gpr > kRasterThreads) return fail(TRS_ERR_LIMIT, "img_w too large: more 4-pixel groups per row than raster threads");
     r.rows_per_pass = kRasterThreads / r.gpr;   // raster threads beyond rows_per_pass * gpr idle (32 of 512 at W = 160)
+    HIPCHK(hipHostMalloc((void**)&e->fault, 64, hipHostMallocMapped | hipHostMallocCoherent));   // kernels report a layout fault here (checked at every synchronisation)
+    *e->fault = 0ull;
+    k.fault = e->fault; r.fault = e->fault;
     HIPCHK(hipStreamSynchronize(e->sP));
+    return TRS_OK;
+}
+
+
+}  // namespace
+
+TRS_EXPORT int trs_create(const trs_config* cfg, int device, trs_env** out)
+{
+    if (!cfg || !out) return fail(TRS_ERR_ARG, "null argument");
+    if (cfg->struct_size != sizeof(trs_config)) return fail(TRS_ERR_ARG, "trs_config.struct_size mismatch");
+    if (cfg->n_envs < 1 || cfg->img_h < 2 || cfg->img_w < 4 || (cfg->img_w & 3) || cfg->env_id_base < 0)
+        return fail(TRS_ERR_ARG, "bad n_envs / image size (img_w must be a multiple of 4)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(TRS_ERR_DEVICE, "no HIP device visible (libtrsim has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TRS_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    trs_env* e = new (std::nothrow) trs_env();
+    if (!e) return fail(TRS_ERR_NOMEM, "out of memory");
+    e->device = device;
+    const int rc = create_impl(cfg, device, e);
+    if (rc) {                                                // keep the message of the failure, not of the clean-up
+        const std::string why = g_err;
+        (void)trs_destroy(e);
+        return fail(rc, why);
+    }
     *out = e;
     return TRS_OK;
 }
@@ -1079,6 +1102,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf); (void)hipFree(e->glue);
     if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->fault) (void)hipHostFree(e->fault);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->sP) (void)hipStreamDestroy(e->sP);
@@ -1094,19 +1118,27 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipSetDevice(e->device));
     int rc0 = sync_all(e);
     if (rc0) return rc0;
+    // Transactional: everything is built into copies (tables, parameter blocks, layout numbers, device buffers) and
+    // committed only after every check, allocation and copy has succeeded — a failed reload leaves the handle with the
+    // track it had (or with none), never with new offsets against old blobs.
     std::string err;
-    int rc = trsim::build_tables(e->cfg, h_xyz, n_points, e->tab, err);
+    trsim::TrackTables T;
+    int rc = trsim::build_tables(e->cfg, h_xyz, n_points, T, err);
     if (rc) return fail(rc, err);
-    const trsim::TrackTables& T = e->tab;
-    PParams& k = e->pp;
-    RParams& r = e->rp;
+    PParams k = e->pp;
+    RParams r = e->rp;
+    struct Staged {                                          // device buffers of the new track; freed unless committed
+        unsigned char *blob_p = nullptr, *blob_r = nullptr; float *tangent = nullptr, *start_yaw = nullptr;
+        ~Staged() { (void)hipFree(blob_p); (void)hipFree(blob_r); (void)hipFree(tangent); (void)hipFree(start_yaw); }
+    } nb;
+    int n_lds_r = 0, n_lds_p = 0, n_lds_step = 0, n_lds_off_phys = 0, n_pts_bytes = 0, n_max_spl = 1, n_max_dyn = 0;
 
     // ---- physics LDS image: px | py | pz | tangent (when it fits) + scratch ----
     const size_t pts = align_up((size_t)n_points * 8, 16);
     const size_t scratch = (size_t)(kPhysBlock / 64) * (16 + 4) + 16;     // physics-only kernel: per-wave sinks
     size_t off = 0;
     k.off_py = (int)(off += pts); k.off_pz = (int)(off += pts); off += pts;
-    e->pts_bytes = (int)off;
+    n_pts_bytes = (int)off;
     k.off_tan = (int)off;
     const size_t tan_bytes = align_up((size_t)n_points * 8, 16);
     // ---- raster LDS image: map (rows pitched to an odd number of words) @0 | rowtab | palette ----
@@ -1119,13 +1151,13 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     r.off_pal = (int)roff; roff += (size_t)e->H * 16;
     r.off_depth = (int)roff; roff += align_up((size_t)e->H * 4, 16);
     r.blob_bytes = (int)roff;
-    e->lds_r = (int)align_up(roff, 16);
+    n_lds_r = (int)align_up(roff, 16);
     if ((size_t)r.blob_bytes > (size_t)100 * 1024)
         return fail(TRS_ERR_LIMIT, "map + camera tables exceed the step kernel's LDS staging capacity");
     // tangents ride in LDS when the fused kernel's image (raster tables + points + tangents) still fits a CU's 160 KiB
-    e->lds_off_phys = e->lds_r;
+    n_lds_off_phys = n_lds_r;
     const size_t grid_bytes = align_up(T.grid_start.size() * 2, 16) + align_up(T.grid_pts.size() * 2, 16);
-    k.tan_in_lds = ((size_t)e->lds_off_phys + off + grid_bytes + tan_bytes <= 160 * 1024) ? 1 : 0;
+    k.tan_in_lds = ((size_t)n_lds_off_phys + off + grid_bytes + tan_bytes <= 160 * 1024) ? 1 : 0;
     if (k.tan_in_lds) off += tan_bytes;
     // nearest-point accelerator tables ride behind the points (uint16 cell starts + point lists)
     k.grid_nx = T.grid_nx; k.grid_nz = T.grid_nz; k.grid_x0 = T.grid_x0; k.grid_z0 = T.grid_z0;
@@ -1133,9 +1165,9 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     k.off_gpts = (int)off; off += align_up(T.grid_pts.size() * 2, 16);
     k.blob_bytes = (int)off;
     k.off_scratch = (int)off;
-    e->lds_p = (int)align_up(off + scratch, 16);
-    e->lds_step = (int)align_up((size_t)e->lds_off_phys + off, 16);
-    if (e->lds_p > 160 * 1024 || (e->cfg.render && e->lds_step > 160 * 1024))
+    n_lds_p = (int)align_up(off + scratch, 16);
+    n_lds_step = (int)align_up((size_t)n_lds_off_phys + off, 16);
+    if (n_lds_p > 160 * 1024 || (e->cfg.render && n_lds_step > 160 * 1024))
         return fail(TRS_ERR_LIMIT, "track too long for the LDS-resident nearest-point search");
     std::vector<unsigned char> hp(off, 0);
     std::memcpy(hp.data(), T.px.data(), (size_t)n_points * 8);
@@ -1152,27 +1184,25 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     std::memcpy(hr.data() + r.off_pal, T.palette.data(), (size_t)e->H * 16);
     std::memcpy(hr.data() + r.off_depth, T.rowdepth.data(), (size_t)e->H * 4);
 
-    (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
-    e->blob_p = e->blob_r = nullptr; e->tangent = nullptr; e->start_yaw = nullptr;
-    HIPCHK(hipMalloc((void**)&e->blob_p, off));
-    HIPCHK(hipMalloc((void**)&e->blob_r, roff));
-    HIPCHK(hipMalloc((void**)&e->tangent, (size_t)n_points * 8));
-    HIPCHK(hipMalloc((void**)&e->start_yaw, (size_t)n_points * 4));
-    HIPCHK(hipMemcpy(e->blob_p, hp.data(), off, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->blob_r, hr.data(), roff, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->tangent, T.tangent.data(), (size_t)n_points * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->start_yaw, T.start_yaw.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
-    k.blob = e->blob_p; k.start_yaw = e->start_yaw; k.tangent_g = e->tangent;
-    r.blob = e->blob_r;
+    HIPCHK(hipMalloc((void**)&nb.blob_p, off));
+    HIPCHK(hipMalloc((void**)&nb.blob_r, roff));
+    HIPCHK(hipMalloc((void**)&nb.tangent, (size_t)n_points * 8));
+    HIPCHK(hipMalloc((void**)&nb.start_yaw, (size_t)n_points * 4));
+    HIPCHK(hipMemcpy(nb.blob_p, hp.data(), off, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(nb.blob_r, hr.data(), roff, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(nb.tangent, T.tangent.data(), (size_t)n_points * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(nb.start_yaw, T.start_yaw.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
+    k.blob = nb.blob_p; k.start_yaw = nb.start_yaw; k.tangent_g = nb.tangent;
+    r.blob = nb.blob_r;
     k.np = n_points; r.map_w = T.info.map_w; r.map_h = T.info.map_h;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_p));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, n_lds_p));
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
-        const int free_b = 160 * 1024 - e->lds_step - epw * 4 - 16 - epw * 16;
-        e->max_steps_per_launch = std::max(1, std::min(16, free_b / (epw * 16)));
+        const int free_b = 160 * 1024 - n_lds_step - epw * 4 - 16 - epw * 16;
+        n_max_spl = std::max(1, std::min(16, free_b / (epw * 16)));
         const int free_dyn = free_b - (4 * e->H * 16 + 160);
-        e->max_steps_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
+        n_max_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1182,6 +1212,16 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, k.blob_bytes));
+    // ---- commit: nothing above has touched the handle ----
+    e->track_loaded = false;                                 // (until the state arrays below are in place)
+    (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
+    e->blob_p = nb.blob_p; e->blob_r = nb.blob_r; e->tangent = nb.tangent; e->start_yaw = nb.start_yaw;
+    nb = Staged{};
+    e->tab = std::move(T);
+    e->pp = k; e->rp = r;
+    e->lds_r = n_lds_r; e->lds_p = n_lds_p; e->lds_step = n_lds_step; e->lds_off_phys = n_lds_off_phys; e->pts_bytes = n_pts_bytes;
+    e->max_steps_per_launch = n_max_spl; e->max_steps_dyn = n_max_dyn;
+    const trsim::TrackTables& TT = e->tab;
     // start poses (host mirror of the reset branch so that telemetry is meaningful before the first step)
     const size_t n = (size_t)e->n;
     std::vector<float> sx(n), sy(n), sz(n), syaw(n);
@@ -1189,7 +1229,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     for (size_t i = 0; i < n; ++i) {
         const int gid = e->cfg.env_id_base + (int)i;
         const int si = (int)(((long long)TRS_START_STRIDE * gid) % n_points);
-        sx[i] = (float)T.px[si]; sy[i] = (float)T.py[si]; sz[i] = (float)T.pz[si]; syaw[i] = T.start_yaw[si]; sidx[i] = si;
+        sx[i] = (float)TT.px[si]; sy[i] = (float)TT.py[si]; sz[i] = (float)TT.pz[si]; syaw[i] = TT.start_yaw[si]; sidx[i] = si;
     }
     HIPCHK(hipMemcpy(k.x, sx.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(k.y, sy.data(), n * 4, hipMemcpyHostToDevice));
@@ -1361,7 +1401,7 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
         hipStream_t sc = trsim::resident_copy_stream(e);
         HIPCHK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, sc));
         HIPCHK(hipStreamSynchronize(sc));
-        return TRS_OK;
+        return trsim::check_fault(e);
     }
     int rc = sync_all(e);
     if (rc) return rc;
@@ -1401,6 +1441,7 @@ TRS_EXPORT int trs_fetch_outputs(trs_env* e, uint8_t* h_img, float* h_x, float* 
         off += (it.bytes + 15) & ~(size_t)15;
     }
     HIPCHK(hipStreamSynchronize(cs));
+    { int rf = trsim::check_fault(e); if (rf) return rf; }
     off = 0;
     for (const Item& it : items) {
         if (!it.dst || !it.bytes) continue;
@@ -1848,7 +1889,7 @@ TRS_EXPORT int trs_sync(trs_env* e)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(e->device));
-    if (resident_steps(e)) return trsim::resident_wait(e);      // every posted step is complete in memory; the worker stays resident
+    if (resident_steps(e)) { int rw = trsim::resident_wait(e); return rw ? rw : trsim::check_fault(e); }   // posted steps complete; the worker stays
     return sync_all(e);
 }
 
@@ -1887,6 +1928,12 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
+int trsim::check_fault(trs_env* e)
+{
+    if (e->fault && __atomic_load_n(e->fault, __ATOMIC_ACQUIRE) != 0ull)
+        return fail(TRS_ERR_DEVICE, "a step kernel found its dynamic LDS segment at a non-zero offset and refused to run: frames and state are stale");
+    return TRS_OK;
+}
 
 #ifdef TRS_DEBUG_PROBES
 // Debug build only (scripts/det_probe.py; never part of libtrsim.so): fill the whole LDS of every CU with a pattern on the

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/trsim.h"
@@ -1182,7 +1183,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     HIPCHK(hipSetDevice(v.device));
     void** slot = trs_internal_pilot_slot(e);
     if (*slot) { HIPCHK(hipStreamSynchronize(v.stream)); free_ctx(static_cast<PilotCtx*>(*slot)); *slot = nullptr; }
-    PilotCtx* c = new PilotCtx();
+    // the context under construction is freed on EVERY early return below (HIPCHK included); released into the handle at the end
+    std::unique_ptr<PilotCtx, void (*)(PilotCtx*)> guard(new PilotCtx(), free_ctx);
+    PilotCtx* const c = guard.get();
     c->n_cap = v.n; c->H = v.H; c->W = v.W;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, v.device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     static const int spec[7][4] = {{5, 2, 3, 24}, {5, 2, 24, 32}, {5, 2, 32, 64}, {3, 1, 64, 64}, {3, 1, 64, 64}, {3, 1, 64, 128}, {3, 1, 128, 128}};
@@ -1192,7 +1195,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         if (i < 7) { l.KH = l.KW = spec[i][0]; l.S = spec[i][1]; l.CIN = spec[i][2]; l.COUT = spec[i][3]; l.IH = ih; l.IW = iw; }
         else { l.KH = l.KW = 1; l.S = 1; l.CIN = ih * iw * 128; l.COUT = 100; l.IH = 1; l.IW = 1; }     // dense1 over the NHWC flatten
         l.OH = (l.IH - l.KH) / l.S + 1; l.OW = (l.IW - l.KW) / l.S + 1;
-        if (l.OH < 1 || l.OW < 1) { free_ctx(c); return trs_internal_fail(TRS_ERR_LIMIT, "image too small for Keras_2D_CNN"); }
+        if (l.OH < 1 || l.OW < 1) { return trs_internal_fail(TRS_ERR_LIMIT, "image too small for Keras_2D_CNN"); }
         l.COUT_PAD = (l.COUT + 31) / 32 * 32;
         l.u8in = (i == 0); l.relu = true; l.out_f32 = (i == 7);
         // granules: a kernel row is one contiguous run of KW * CIN / 8 granules in NHWC; runs are padded to whole trips of 4
@@ -1279,7 +1282,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         std::vector<u4v> wv(wp.size() / 8);
         std::memcpy(wv.data(), wp.data(), wp.size() * 2);
         int rc = upload(&l.w, wv); if (!rc) rc = upload(&l.bias, bias); if (!rc) rc = upload(&l.goff, goff);
-        if (rc) { free_ctx(c); return rc; }
+        if (rc) return rc;
         c->act_elems[i] = (size_t)l.OH * l.OW * l.COUT;
         HIPCHK(hipMalloc(&c->act[i], (size_t)c->n_cap * c->act_elems[i] * (l.out_f32 ? 4 : 2) + 64));
         ih = l.OH; iw = l.OW;
@@ -1288,7 +1291,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     int rc = up(&c->w2, arr[16], 100 * 50); if (!rc) rc = up(&c->b2, arr[17], 50);
     if (!rc) rc = up(&c->w3, arr[18], 50 * 25); if (!rc) rc = up(&c->b3, arr[19], 25);
     if (!rc) rc = up(&c->w4, arr[20], 25 * 2); if (!rc) rc = up(&c->b4, arr[21], 2);
-    if (rc) { free_ctx(c); return rc; }
+    if (rc) return rc;
     {   // conv1 -> conv2 fusion: needs the 5x5/2 + 5x5/2 head of Keras_2D_CNN and an LDS tile of 2 R2 + 3 conv1 rows
         const ConvLayer& l0 = c->L[0]; const ConvLayer& l1 = c->L[1];
         Fuse12Params& q = c->fuse;
@@ -1335,7 +1338,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                        : nb == 2 ? (const void*)trs_conv_mfma_kernel<2, false> : (const void*)trs_conv_mfma_kernel<4, false>;
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
-    *slot = c;
+    *slot = guard.release();
     return TRS_OK;
 }
 

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     if ((unsigned)(uintptr_t)smem != 0u) {                   // the map addressing assumes LDS offset 0
         if (tid == 0) {
             atomicAdd(&p.stats[2], 1ull);
+            sys_store64(p.fault, 1ull);
             sys_store64(&wp.mb->error, (9ull << 32) | (u64)blockIdx.x);
             __hip_atomic_fetch_or(&wp.dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (blockIdx.x == 0) { sys_store64(&wp.mb->consumed, wp.start); sys_store64(&wp.mb->exited, 1ull); }
@@ -444,8 +445,8 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     // would issue nothing meanwhile (all eight waves drain together: the CU's store path runs dry once per step).  So arrivals
     // LAG: with K steps of lag the wave arrives for step s - K after issuing step s's uniform rows, behind a counted wait
     // (vmcnt(N), N = the store instructions it has issued since the end of step s - K; a raster wave issues only stores and
-    // they are acknowledged in order) — what it waits for was issued K steps ago.  K is as large as the 6-bit counter allows
-    // (N <= 63), at most 3, and never more than the posts queued behind this step allow: a consumer that keeps two steps in
+    // they are acknowledged in order) — what it waits for was issued K steps ago.  K = 2, or 3 for very short steps, and never
+    // more than the posts queued behind this step allow: a consumer that keeps two steps in
     // flight gets step s's completion after step s + 1's uniform rows, a lock-step consumer at once (drain, arrive).
     const RasterThread rth = raster_thread(p, smem, tid);
     int nu = 0, ng = 0;
@@ -457,7 +458,10 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     int own = 0;                                              // envs whose telemetry this wave writes out (2 store instructions each)
     for (int j = wave; j < n_loc; j += kRasterThreads / 64) ++own;
     const int nuni = nu * n_loc, nstep = (nu + ng) * n_loc + 2 * own;
-    const int lag = (2 * nstep + nuni <= 63) ? 3 : ((nstep + nuni <= 63) ? 2 : 1);
+    // two steps of lag always: what the wave then waits for was issued a whole step ago (a count beyond 63 is clamped, which only
+    // asks for what the 6-bit counter enforces anyway); three where a step is so short that even that is younger than a store's
+    // round trip (small shards: 2 * nstep + nuni still fits the counter)
+    const int lag = (2 * nstep + nuni <= 63) ? 3 : 2;
     // this lane's telemetry array (lanes 0..11: 4-byte arrays in slot-word order, lanes 12, 13: the byte arrays done, pending)
     unsigned char* optr = nullptr;
     {
