@@ -325,6 +325,32 @@ int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats
  * then one env step with those controls.  Before the first frame exists the controls are (0, 0, 0) (keras_pilot.py:46-47). */
 int trs_step_pilot(trs_env* env, const trs_pilot_config* cfg, int n_steps);
 
+/* ---- multi-GPU: the one exchange (north_star: "a single RCCL all-gather over xGMI of episode returns") ----
+ * One process (or thread) per GPU owns one handle = one shard of envs; shards never exchange state.  The reference has no
+ * distributed layer at all; this replaces what a user would otherwise script around N copies of manage.py.
+ * Rank 0 obtains a 128-byte id and hands it to the other ranks over any host channel (file, environment, socket,
+ * torch.distributed store); every rank then calls trs_comm_init (collective).  world == 1 needs no id (with one, the RCCL path
+ * itself runs).  RCCL is bound at run time: libtrsim.so does not link against it. */
+#define TRS_COMM_ID_BYTES 128
+int trs_comm_get_unique_id(void* id_out_128);
+int trs_comm_init(trs_env* env, int rank, int world, const void* unique_id_128_or_null);
+int trs_comm_destroy(trs_env* env);
+/* All ranks receive 'ep_return' of every env of every shard, ordered by rank (= by global env id when shards own contiguous
+ * ranges): ncclAllGather of n_envs floats per rank on the handle's stream, behind the steps queued so far.  *d_out_all (may be
+ * NULL) receives the handle-owned device buffer float[world * n_envs]; h_out_all (may be NULL) is filled and the call then
+ * synchronises.  Latency-bound (4 B per env): issue it per reporting interval, never per step. */
+int trs_allgather_returns(trs_env* env, const float** d_out_all, float* h_out_all);
+
+/* ---- ordering against the caller's own HIP streams ----
+ * The handle works on its own non-blocking stream.  trs_stream_wait_external: work queued on the handle after this call waits
+ * for everything queued so far on `hip_stream` (the producer of device-resident controls, e.g. a policy on torch's stream).
+ * trs_stream_signal_external: everything queued on `hip_stream` after this call waits for the handle's work so far (a consumer
+ * of device-resident frames / telemetry).  Launch mode: event waits, no host synchronisation.  Resident mode: the host waits
+ * (steps are posted by the host; completion is a flag in host memory).  Note that 'cam/img' alternates between two buffers:
+ * the frame of step s stays intact while step s + 1 renders, and is overwritten by step s + 2. */
+int trs_stream_wait_external(trs_env* env, void* hip_stream);
+int trs_stream_signal_external(trs_env* env, void* hip_stream);
+
 /* stream control + device-side timing (HIP events on the handle's stream) */
 int trs_sync(trs_env* env);
 int trs_event_record(trs_env* env, int slot);                 /* slot 0..7 */

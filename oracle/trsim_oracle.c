@@ -64,6 +64,7 @@ struct trs_env {
     int mux_tick;
     uint64_t step_count;
     uint64_t stats[64];        /* [0] off-track events, [1] resets */
+    int comm_ready;            /* trso_comm_init was called (one rank) */
 };
 
 /* ------------------------------------------------------------------ spec pieces */
@@ -587,6 +588,22 @@ EXPORT int trso_map_info_get(trs_env* e, trs_map_info* o)
 }
 
 EXPORT int trso_sync(trs_env* e) { (void)e; return TRS_OK; }
+/* the multi-GPU exchange (include/trsim.h): the oracle has no transport, so its "communicator" is the one-rank case, where the
+ * all-gather is a copy; more ranks are gathered by the tests' own channel (gloo) */
+EXPORT int trso_comm_get_unique_id(void* id) { if (!id) return TRS_ERR_ARG; memset(id, 0, 128); return TRS_OK; }
+EXPORT int trso_comm_init(trs_env* e, int rank, int world, const void* id) { (void)id; if (!e || world != 1 || rank != 0) return TRS_ERR_ARG; e->comm_ready = 1; return TRS_OK; }
+EXPORT int trso_comm_destroy(trs_env* e) { if (!e) return TRS_ERR_ARG; e->comm_ready = 0; return TRS_OK; }
+EXPORT int trso_allgather_returns(trs_env* e, const float** d_out, float* h_out)
+{
+    if (!e) return TRS_ERR_ARG;
+    if (!e->comm_ready) return TRS_ERR_STATE;
+    if (d_out) *d_out = e->ep_return;
+    if (h_out) memcpy(h_out, e->ep_return, (size_t)e->n * sizeof(float));
+    return TRS_OK;
+}
+/* there are no streams on the CPU */
+EXPORT int trso_stream_wait_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }
+EXPORT int trso_stream_signal_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }
 /* how steps reach the GPU (include/trsim.h: trs_set_step_mode) changes no result: accepted and ignored here */
 EXPORT int trso_set_step_mode(trs_env* e, int mode, int idle_us) { (void)idle_us; if (!e) return TRS_ERR_ARG; return (mode == 0 || mode == 1) ? TRS_OK : TRS_ERR_ARG; }
 EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return TRS_OK; }

@@ -76,6 +76,7 @@ SYMBOLS = [
     "default_pre_config", "preprocess", "preprocess_host", "set_frame_filter", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
     "default_mux_config", "control_mux", "control_mux_host", "control_mux_reset",
+    "comm_get_unique_id", "comm_init", "comm_destroy", "allgather_returns", "stream_wait_external", "stream_signal_external",
 ]
 
 
@@ -95,6 +96,8 @@ class TrsPilotConfig(C.Structure):
         ("model_type", C.c_int32),
     ]
 
+
+COMM_ID_BYTES = 128                                                    # TRS_COMM_ID_BYTES
 
 PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1}          # TRS_PILOT_*; ModelType values of components/keras_train.py
 
@@ -144,6 +147,12 @@ class Api:
             "control_mux": (i32, [vp, C.POINTER(TrsMuxConfig), vp] + [vp] * 9 + [i32]),
             "control_mux_host": (i32, [vp, C.POINTER(TrsMuxConfig), vp] + [vp] * 9 + [i32]),
             "control_mux_reset": (i32, [vp]),
+            "comm_get_unique_id": (i32, [vp]),
+            "comm_init": (i32, [vp, i32, i32, vp]),
+            "comm_destroy": (i32, [vp]),
+            "allgather_returns": (i32, [vp, C.POINTER(vp), vp]),
+            "stream_wait_external": (i32, [vp, vp]),
+            "stream_signal_external": (i32, [vp, vp]),
         }
         pilot = {
             "default_pilot_config": (None, [C.POINTER(TrsPilotConfig)]),

@@ -105,7 +105,10 @@ class BatchedGymInterface(Component):
         names = ["img", "pos_x", "pos_y", "pos_z", "speed", "cte", "seg_idx", "done"]
         if self.to_host:
             return self.env.fetch_outputs()
-        return tuple(self.env.device_array(n) for n in names)
+        # device handles: the step ran on the env's own stream, so order it before anyone looks (one wait for the tuple).
+        # 'cam/img' alternates between two buffers: a handle stays valid while the NEXT step renders, not beyond.
+        self.env.sync()
+        return tuple(self.env.device_array(n, sync=False) for n in names)
 
     def onShutdown(self):
         self.env.close()

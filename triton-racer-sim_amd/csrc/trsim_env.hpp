@@ -10,7 +10,7 @@
 #include "trsim_device.hpp"
 #include "trsim_tables.hpp"
 
-namespace trsim { struct Resident; }
+namespace trsim { struct Resident; struct Comm; }
 
 struct trs_env {
     trs_config cfg{};
@@ -51,6 +51,8 @@ struct trs_env {
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
     unsigned long long* fault = nullptr; // pinned host word the kernels set when they refuse to run (dynamic LDS not at offset 0)
     float* glue = nullptr; size_t glue_bytes = 0;   // device scratch of the *_host control glue (trs_driver_assist_host, trs_control_mux_host)
+    trsim::Comm* comm = nullptr;         // trsim_comm.hip: the RCCL communicator of trs_comm_init, nullptr = none
+    hipEvent_t ev_order = nullptr;       // trs_stream_wait_external / trs_stream_signal_external
     trsim::Resident* res = nullptr;      // trsim_resident.hip: the resident worker (trs_set_step_mode), nullptr = never used
 };
 
@@ -65,5 +67,9 @@ hipStream_t resident_copy_stream(trs_env* e);             // a stream that is no
 int resident_wait(trs_env* e);                            // every posted step complete (the worker stays resident)
 int resident_quiesce(trs_env* e);                         // ... and the worker has left the GPU: the stream is free again
 void resident_destroy(trs_env* e);
+int sync_handle(trs_env* e);                               // the handle's stream is idle (a resident worker is asked to leave first)
+int quiesce_handle(trs_env* e);                            // a resident worker has left; queued work may still be running
+void comm_destroy(trs_env* e);
+bool resident_running(const trs_env* e);
 int check_fault(trs_env* e);                               // TRS_ERR_DEVICE (sticky) once a kernel has reported a layout fault
 }  // namespace trsim

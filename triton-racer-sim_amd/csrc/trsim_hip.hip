@@ -1013,6 +1013,7 @@ int create_impl(const trs_config* cfg, int device, trs_env* e)
     e->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&e->sP, hipStreamNonBlocking));
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming));
 
     // one slab for all per-env arrays: 10 float + 2 int32 state arrays, 3 float + 1 byte control arrays, 2 byte flags
     const size_t n = (size_t)e->n, fa = align_up(n * 4, 256), ba = align_up(n, 256);
@@ -1096,6 +1097,8 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipSetDevice(e->device);
     trsim::resident_destroy(e);
     if (e->sP) (void)hipStreamSynchronize(e->sP);
+    trsim::comm_destroy(e);
+    if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
@@ -1928,6 +1931,8 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
+int trsim::sync_handle(trs_env* e) { return sync_all(e); }
+int trsim::quiesce_handle(trs_env* e) { return quiesce(e); }
 int trsim::check_fault(trs_env* e)
 {
     if (e->fault && __atomic_load_n(e->fault, __ATOMIC_ACQUIRE) != 0ull)

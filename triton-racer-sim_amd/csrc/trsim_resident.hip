@@ -635,6 +635,7 @@ int ensure_resident(trs_env* e)
 namespace trsim {
 
 bool resident_on(const trs_env* e) { return e && e->res && e->res->enabled; }
+bool resident_running(const trs_env* e) { return e && e->res && e->res->running; }
 
 int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride)
 {

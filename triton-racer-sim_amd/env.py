@@ -47,13 +47,24 @@ def resolve_track(track):
 
 
 class _DevicePtr:
-    """Zero-copy view of a device array for torch / cupy (``__cuda_array_interface__`` v2)."""
+    """Zero-copy view of a device array for torch / cupy (``__cuda_array_interface__``).  The producing work has been
+    ordered before the view is handed out (``BatchedEnv.device_array``: a host synchronisation, or a wait queued on the
+    consumer's stream), so the interface carries no stream of its own."""
 
     def __init__(self, ptr, shape, dtype, owner):
         self._owner = owner
         self.__cuda_array_interface__ = {
             "shape": tuple(shape), "typestr": np.dtype(dtype).str, "data": (int(ptr), False), "version": 2, "strides": None,
         }
+
+
+def _stream_ptr(stream):
+    """A HIP stream as an integer: accepts ``torch.cuda.Stream`` (``.cuda_stream``), cupy streams (``.ptr``) or the raw
+    pointer value; ``0`` is the legacy default stream."""
+    for attr in ("cuda_stream", "ptr"):
+        if hasattr(stream, attr):
+            return int(getattr(stream, attr))
+    return int(stream)
 
 
 class BatchedEnv:
@@ -128,8 +139,13 @@ class BatchedEnv:
         self.api.check(self.api.step_host(self._h, st.ctypes.data, th.ctypes.data, None if br is None else br.ctypes.data,
                                           None if rs is None else rs.ctypes.data, int(n_steps)), "step_host")
 
-    def step_device(self, d_steering, d_throttle, d_brake=0, d_reset=0, n_steps=1):
-        """Raw device pointers (ints), e.g. ``tensor.data_ptr()`` of float32 / uint8 CUDA tensors."""
+    def step_device(self, d_steering, d_throttle, d_brake=0, d_reset=0, n_steps=1, stream=None):
+        """Raw device pointers (ints), e.g. ``tensor.data_ptr()`` of float32 / uint8 CUDA tensors.  The env works on its own
+        stream: pass ``stream=`` (the stream that PRODUCES the control tensors, e.g. ``torch.cuda.current_stream()``) and the
+        step is ordered behind that stream's work (``trs_stream_wait_external``: an event wait, no host synchronisation in
+        launch mode); without it the caller must have synchronised the producer."""
+        if stream is not None:
+            self.api.check(self.api.stream_wait_external(self._h, _stream_ptr(stream) or None), "stream_wait_external")
         self.api.check(self.api.step(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
                                      int(n_steps)), "step")
 
@@ -192,9 +208,16 @@ class BatchedEnv:
         self.api.check(self.api.get_state(self._h, C.byref(sv)), "get_state")
         return sv
 
-    def device_array(self, name):
+    def device_array(self, name, stream=None, sync=True):
         """Zero-copy handle (``__cuda_array_interface__``) on a device-resident output; use
-        ``torch.as_tensor(env.device_array('ep_return'), device='cuda')``."""
+        ``torch.as_tensor(env.device_array('ep_return'), device='cuda')``.  The env's steps run on the env's own stream, so
+        the view is ordered first: with ``stream=`` (the CONSUMER's stream) that stream is made to wait for the env's work
+        queued so far (``trs_stream_signal_external``), otherwise the host waits (``sync=False`` skips even that: the caller
+        orders).  ``'img'`` / ``'depth'`` alternate between two buffers: the frame of step s is overwritten by step s + 2."""
+        if stream is not None:
+            self.api.check(self.api.stream_signal_external(self._h, _stream_ptr(stream) or None), "stream_signal_external")
+        elif sync:
+            self.sync()
         sv = self.state_view()
         ptr = getattr(sv, name)
         if not ptr:
@@ -376,6 +399,36 @@ class BatchedEnv:
         """Closed loop: controls = KerasPilot.step(previous frame, speed), then one env step; all on the device."""
         pc = cfg if isinstance(cfg, _ffi.TrsPilotConfig) else self.pilot_config(cfg)
         self.api.check(self.api.step_pilot(self._h, C.byref(pc), int(n_steps)), "step_pilot")
+
+    # -- the one exchange of the multi-GPU path (trs_comm_* / trs_allgather_returns: RCCL behind the C ABI) ----------------
+    def comm_unique_id(self):
+        """Rank 0: the 128-byte id every rank passes to ``comm_init`` (hand it over by any host channel)."""
+        buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
+        self.api.check(self.api.comm_get_unique_id(buf), "comm_get_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id=None):
+        uid = None if unique_id is None else C.create_string_buffer(bytes(unique_id), _ffi.COMM_ID_BYTES)
+        self.api.check(self.api.comm_init(self._h, int(rank), int(world), uid), "comm_init")
+        self._comm_world = int(world)
+
+    def comm_destroy(self):
+        self.api.check(self.api.comm_destroy(self._h), "comm_destroy")
+        self._comm_world = 0
+
+    def allgather_returns(self):
+        """``ep_return`` of every env of every shard, ordered by rank, as a fresh ``float32[world * n_envs]`` host array."""
+        out = np.empty(self._comm_world * self.n, np.float32)
+        self.api.check(self.api.allgather_returns(self._h, None, out.ctypes.data), "allgather_returns")
+        return out
+
+    def allgather_returns_device(self):
+        """Same, device resident: a zero-copy handle on the handle-owned buffer (the gather is queued on the env's stream;
+        the handle is handed out after a host synchronisation)."""
+        ptr = C.c_void_p()
+        self.api.check(self.api.allgather_returns(self._h, C.byref(ptr), None), "allgather_returns")
+        self.sync()
+        return _DevicePtr(ptr.value, (self._comm_world * self.n,), np.float32, self)
 
     # -- timing (HIP events on the handle's stream) -------------------------------------------
     def event_record(self, slot):

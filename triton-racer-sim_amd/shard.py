@@ -27,15 +27,29 @@ class ShardedEnvs:
     def step_synthetic(self, n_steps=1, steps_per_launch=1):
         self.env.step_synthetic(n_steps, steps_per_launch)
 
+    def comm_init(self, unique_id=None, exchange=None):
+        """Build the C-ABI communicator (``trs_comm_init``: RCCL without torch).  ``unique_id``: rank 0's 128 bytes, already
+        distributed by the caller; or ``exchange``: a callable ``bytes_or_None -> bytes`` that broadcasts rank 0's id (rank 0
+        passes the id, the others ``None``) — e.g. a file, an environment variable or a ``torch.distributed`` store."""
+        if self.world > 1 and unique_id is None:
+            if exchange is None:
+                raise ValueError("world > 1: pass rank 0's unique id or an exchange callable")
+            unique_id = exchange(self.env.comm_unique_id() if self.rank == 0 else None)
+        elif self.world == 1 and unique_id is None and exchange is not None:
+            unique_id = exchange(self.env.comm_unique_id())
+        self.env.comm_init(self.rank, self.world, unique_id)
+        self._c_comm = True
+
     def allgather(self, name="ep_return"):
         """All ranks receive the full ``[n_total]`` vector of a per-env float32 field, ordered by global env id."""
         import torch
         import torch.distributed as dist
+        if getattr(self, "_c_comm", False) and name == "ep_return":           # RCCL behind the C ABI: no torch process group needed
+            return torch.from_numpy(self.env.allgather_returns())
         if not dist.is_initialized():
             return torch.from_numpy(self.env.fetch(name))
         if dist.get_backend() == "nccl":                       # device-resident, zero copy: RCCL all-gather over xGMI
-            self.env.sync()
-            local = torch.as_tensor(self.env.device_array(name), device="cuda")
+            local = torch.as_tensor(self.env.device_array(name), device="cuda")      # (device_array waits for the env's stream)
             out = torch.empty(self.n_total, dtype=local.dtype, device="cuda")
         else:                                                  # gloo (CPU tests)
             local = torch.from_numpy(np.ascontiguousarray(self.env.fetch(name)))
