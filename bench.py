@@ -8,6 +8,9 @@
 A "step" = one pass of the hot path over every env of every shard: bicycle-model integration, binary64
 nearest-point index, cte/done/return, and one 120x160 RGB frame per env written to HBM (inputs and
 outputs device-resident; controls from the counter-based generator of include/trsim_spec.h).
+Steps reach the GPU the consumer-paced way by default (--step-mode resident): every step is posted on its own to the resident
+worker kernel (trs_set_step_mode), the way Car.start calls GymInterface.step once per tick; --step-mode launch is one kernel
+launch per step.
 Workload at N = 1: BASELINE.json configs[2] (1024 envs, physics + 120x160 RGB pinhole rasteriser, one MI355X).
 Workload at N > 1: BASELINE.json configs[3] (4096 envs in total, sharded over the N GPUs = 512 per GPU at N = 8,
 one RCCL all-gather of the episode returns closing the job).  --envs-per-gpu / --total-envs override either.
@@ -112,7 +115,10 @@ def main():
     ap.add_argument("--img-h", type=int, default=120)
     ap.add_argument("--img-w", type=int, default=160)
     ap.add_argument("--steps-per-launch", type=int, default=1)
-    ap.add_argument("--resident", action="store_true", help="resident step mode (trs_set_step_mode): a worker kernel stays on the GPU, every step is POSTED (no launch per step)")
+    ap.add_argument("--step-mode", choices=("resident", "launch"), default="resident",
+                    help="resident (default): trs_set_step_mode(TRS_STEP_RESIDENT) - a worker kernel stays on the GPU and every step is POSTED on its own "
+                         "(consumer-paced, no launch per step); launch: one kernel launch per step (--steps-per-launch K: K steps per launch)")
+    ap.add_argument("--resident", action="store_true", help="same as --step-mode resident")
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
     ap.add_argument("--pilot", action="store_true", help="closed loop with cnn_2d_speed_control inference on the device frame each step (BASELINE configs[4] shape)")
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
@@ -182,7 +188,8 @@ def main():
         run = lambda k_: env.step_pilot(k_)
     else:
         run = lambda k_: env.step_synthetic(k_, spl)
-    resident = bool(args.resident and render and not args.pilot)
+    # the resident worker renders; physics-only envs and the pilot loop go through launches (the pilot's kernels need the CUs' LDS)
+    resident = bool((args.resident or args.step_mode == "resident") and render and not args.pilot and spl == 1)
     if resident:
         env.set_step_mode(True)
 
@@ -213,7 +220,13 @@ def main():
     # informational only (never part of `value`): the same workload with 8 steps per launch, timed separately
     also = None
     if render and not args.pilot and spl == 1 and world == 1 and not args.no_also:
+        env.set_step_mode(False)
         env.sync()
+        # ... one kernel launch per step, controls from the in-kernel generator (round 1's headline path)
+        env.event_record(2)
+        env.step_synthetic(args.steps, 1)
+        env.event_record(3)
+        ms1 = env.event_elapsed_ms(2, 3)
         env.event_record(2)
         env.step_synthetic(args.steps, 8)
         env.event_record(3)
@@ -228,8 +241,6 @@ def main():
         ms_seq = env.event_elapsed_ms(4, 5)
         # ... and the consumer-paced call: ONE trs_step per tick with that tick's (device-resident) controls, n_steps = 1 per call,
         # the way Car.start drives GymInterface.step (core/car.py:45-53)
-        if resident:
-            env.set_step_mode(False)
         one_steer = (torch.rand(n, device="cuda") * 2 - 1) * 0.3
         one_thr = torch.rand(n, device="cuda") * 0.6 + 0.2
         torch.cuda.synchronize()
@@ -274,7 +285,9 @@ def main():
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
         frac = lambda ms: round(Bx * n * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-        also = {"single_step_call": {"env_steps_per_s": rate(ms_one), "frac_of_hbm_peak": frac(ms_one), "us_per_call": round(ms_one * 1e3 / args.steps, 3),
+        also = {"launch_per_step": {"env_steps_per_s": rate(ms1), "frac_of_hbm_peak": frac(ms1), "us_per_step": round(ms1 * 1e3 / args.steps, 3),
+                                    "note": "trs_step_synthetic(steps, 1) in launch mode: one trs_step_kernel launch per step, physics of step t overlapping the raster of t - 1 across launches (open loop); device time by HIP events"},
+                "single_step_call": {"env_steps_per_s": rate(ms_one), "frac_of_hbm_peak": frac(ms_one), "us_per_call": round(ms_one * 1e3 / args.steps, 3),
                                      "host_wall_us_per_call": round(wall_one * 1e6 / args.steps, 3),
                                      "lock_step_us_per_call": round(wall_lock_launch * 1e6 / lock_steps, 3),
                                      "note": "trs_step(device controls, n_steps = 1) called once per step: the consumer-paced path (one launch per call, raster waits for that step's physics); device time by HIP events"},
@@ -305,12 +318,15 @@ def main():
         achieved = B * per_launch / avg_launch_s / 1e9                 # GB/s of algorithmic bytes, dominant (only) kernel
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        traffic_key = f"{n}x{args.img_h}x{args.img_w}" + ("+depth" if args.depth else "") + (":resident" if resident else f":spl{spl}")
         if os.path.exists(pmc):
             try:
-                # scripts/summarize_profile.py writes {"<envs>x<H>x<W>x<steps per launch>[+depth]": HBM bytes per launch, ...} from the
-                # WRITE_SIZE / FETCH_SIZE passes of scripts/profile.sh (unit + gfx950 corrections of MI355X_MICROARCH.md applied)
+                # scripts/summarize_profile.py writes {"per_env_step": {"<envs>x<H>x<W>[+depth]:<resident|splK>": HBM bytes per env-step}} from the
+                # WRITE_SIZE / FETCH_SIZE passes of scripts/profile.sh (unit + gfx950 corrections of MI355X_MICROARCH.md applied); per launch = x the
+                # env-steps one launch completes, like `achieved`
                 with open(pmc) as f:
-                    traffic = json.load(f).get("per_launch", {}).get(f"{n}x{args.img_h}x{args.img_w}x{spl}" + ("+depth" if args.depth else ""))
+                    per_step = json.load(f).get("per_env_step", {}).get(traffic_key)
+                traffic = None if per_step is None else per_step * per_launch
             except Exception:
                 traffic = None
         line = {
@@ -328,7 +344,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_key": traffic_key,
                 "frac_by_wall_clock": round(B * n * args.steps / wall / 1e9 / HBM_PEAK_GBS, 5),
                 "kernel": "trs_worker_kernel" if resident else ("trs_step_kernel" if render else "trs_physics_kernel"), "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,

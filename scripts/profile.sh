@@ -3,7 +3,9 @@
 # usage: bash scripts/profile.sh <tag> [bench args...]
 set -e
 TAG=${1:-r01}; shift || true
-ARGS="--steps 300 --warmup 30 --no-cpu-baseline --no-also $@"
+# resident mode (the default): one worker launch per timed region, so warm-up and timed region get the SAME number of steps —
+# the kernel-stats average over the two trs_worker_kernel dispatches is then the figure bench.py reports
+ARGS="--steps 1000 --warmup 1000 --no-cpu-baseline --no-also $@"
 cd "$(dirname "$0")/.."
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
