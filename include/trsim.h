@@ -318,6 +318,15 @@ int trs_pilot_forward_host(trs_env* env, const uint8_t* h_frames, int n_images, 
  * [n][OH][OW][C], 7 = dense1 [n][100]. */
 int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats);
 
+/* KerasPilot.step (keras_pilot.py:45-95,139-153) for n cars on DEVICE arrays — the part of a device-resident pilot -> mux -> sim
+ * graph (car_templates/manage.py:46-75): model(d_frames), then the model type's post-processing, written to d_steering /
+ * d_throttle / d_breaking (float[n]: 'ai/steering', 'ai/throttle', 'ai/breaking').  d_frames NULL = the env's latest frames
+ * (n == n_envs; no frame yet -> zeros, keras_pilot.py:46-47); d_speed NULL = the env's own 'gym/speed'; d_mode (uint8[n],
+ * TRS_MODE_*) NULL = every car in an AI mode, else cars outside AI / AI_STEERING get (0, 0, 0) (:139).  Asynchronous on the
+ * handle's stream; frames never leave the device. */
+int trs_pilot_act(trs_env* env, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const uint8_t* d_mode,
+                  float* d_steering, float* d_throttle, float* d_breaking, int n);
+
 /* Closed loop for n_steps (the reference's tick order, car_templates/manage.py:46-75: the pilot acts on the frame the
  * sim stored on the previous tick): controls = KerasPilot.step(frame, speed) for ModelType.CNN_2D_SPD_CTL
  * (keras_pilot.py:78-95: cap steering, predicted speed x 20, calcThrottle / calcBreak of utils/mapping.py:23-35) or for
@@ -350,6 +359,15 @@ int trs_allgather_returns(trs_env* env, const float** d_out_all, float* h_out_al
  * the frame of step s stays intact while step s + 1 renders, and is overwritten by step s + 2. */
 int trs_stream_wait_external(trs_env* env, void* hip_stream);
 int trs_stream_signal_external(trs_env* env, void* hip_stream);
+
+/* ---- device-resident part graphs: buffers and small uploads without a framework ----
+ * trs_scratch: a handle-owned device buffer per slot (0..31), grown on demand (contents undefined after growth), freed by
+ * trs_destroy — where a host-side part keeps 'ai/steering' etc. between parts.  trs_upload: host -> device on the handle's
+ * stream (per-car modes, joystick values); returns once the source may be reused.  trs_counters: bytes the library itself has
+ * copied device -> host [0] and host -> device [1] since trs_create (tests assert that a device-resident loop copies no frames). */
+int trs_scratch(trs_env* env, int slot, size_t bytes, void** d_out);
+int trs_upload(trs_env* env, void* d_dst, const void* h_src, size_t bytes);
+int trs_counters(trs_env* env, uint64_t out[4]);
 
 /* stream control + device-side timing (HIP events on the handle's stream) */
 int trs_sync(trs_env* env);

@@ -65,6 +65,7 @@ struct trs_env {
     uint64_t step_count;
     uint64_t stats[64];        /* [0] off-track events, [1] resets */
     int comm_ready;            /* trso_comm_init was called (one rank) */
+    void* scratch[32]; size_t scratch_bytes[32];   /* trso_scratch */
 };
 
 /* ------------------------------------------------------------------ spec pieces */
@@ -399,6 +400,7 @@ EXPORT int trso_destroy(trs_env* e)
     free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal); free(e->rowdepth); free(e->depth);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
     free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre); free(e->mux);
+    for (int k = 0; k < 32; ++k) free(e->scratch[k]);
     free(e);
     return TRS_OK;
 }
@@ -601,6 +603,21 @@ EXPORT int trso_allgather_returns(trs_env* e, const float** d_out, float* h_out)
     if (h_out) memcpy(h_out, e->ep_return, (size_t)e->n * sizeof(float));
     return TRS_OK;
 }
+/* "device" buffers of a CPU env are host buffers */
+EXPORT int trso_scratch(trs_env* e, int slot, size_t bytes, void** out)
+{
+    if (!e || !out || slot < 0 || slot >= 32) return TRS_ERR_ARG;
+    if (bytes > e->scratch_bytes[slot]) {
+        free(e->scratch[slot]);
+        e->scratch[slot] = calloc(1, bytes < 256 ? 256 : bytes);
+        if (!e->scratch[slot]) { e->scratch_bytes[slot] = 0; return TRS_ERR_NOMEM; }
+        e->scratch_bytes[slot] = bytes < 256 ? 256 : bytes;
+    }
+    *out = e->scratch[slot];
+    return TRS_OK;
+}
+EXPORT int trso_upload(trs_env* e, void* dst, const void* src, size_t bytes) { if (!e || (bytes && (!dst || !src))) return TRS_ERR_ARG; memcpy(dst, src, bytes); return TRS_OK; }
+EXPORT int trso_counters(trs_env* e, uint64_t out[4]) { if (!e || !out) return TRS_ERR_ARG; out[0] = out[1] = out[3] = 0; out[2] = e->step_count; return TRS_OK; }
 /* there are no streams on the CPU */
 EXPORT int trso_stream_wait_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }
 EXPORT int trso_stream_signal_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }

@@ -117,3 +117,51 @@ def test_sim_latency_is_a_delay_line(oracle_api):
     for k in range(3, 8):
         assert np.array_equal(seen_late[k][0], seen_now[k - 3][0]) and seen_late[k][1:] == seen_now[k - 3][1:]
     now.onShutdown(); late.onShutdown()
+
+
+@pytest.mark.gpu
+def test_device_resident_part_graph_equals_step_pilot_and_copies_no_frames():
+    """pilot -> mux -> sim as SEPARATE parts of the reference's Car loop (car_templates/manage.py:46-75: KerasPilot, joystick,
+    ControlMultiplexer, GymInterface, in that order), 256 cars, every inter-part value a device handle: equals the monolithic
+    trs_step_pilot tick for tick, and after the first tick (no frame yet: the pilot answers (0, 0, 0) on the host, like
+    keras_pilot.py:46-47) the library copies NO byte device -> host."""
+    from test_pilot import make_weights
+    from triton_racer_sim_amd.components import BatchedControlMultiplexer, BatchedGymInterface, HipKerasPilot
+    from triton_racer_sim_amd.core import Car, Component
+    from triton_racer_sim_amd.env import BatchedEnv
+
+    class Joystick(Component):                                       # stands in for the joystick part: everybody in AI mode
+        def __init__(self):
+            Component.__init__(self, inputs=[], outputs=["usr/mode", "usr/steering", "usr/throttle", "usr/breaking", "usr/reset"])
+
+        def step(self, *args):
+            return "ai", 0.0, 0.0, 0.0, None
+
+        def getName(self):
+            return "Joystick"
+
+    n, ticks = 256, 7
+    ws = make_weights(120, 160, seed=21)
+    cfg = {"spd_ctl_threshold": 1.1, "spd_ctl_reverse_multiplier": 1.0}
+    gym = BatchedGymInterface(n, auto_reset=False, sync=False)
+    pilot = HipKerasPilot(cfg, weights=ws, env=gym.env)
+    mux = BatchedControlMultiplexer({}, n_cars=n, env=gym.env)
+    car = Car(loop_hz=1e9, verbose=False)
+    for part in (pilot, Joystick(), mux, gym):
+        car.addComponent(part)
+    car.tick()                                                        # tick 1: no frame yet
+    before = gym.env.counters()
+    for _ in range(ticks - 1):
+        car.tick()
+    after = gym.env.counters()
+    assert after[0] == before[0], f"{after[0] - before[0]} bytes were copied device -> host inside the loop"
+    assert after[1] - before[1] <= (ticks - 1) * n * 16, "more than modes + joystick values went host -> device"
+    assert hasattr(car.pool.get_value("cam/img"), "__cuda_array_interface__") and hasattr(car.pool.get_value("ai/steering"), "__cuda_array_interface__")
+    ref = BatchedEnv(n_envs=n, auto_reset=False)
+    ref.pilot_load(ws)
+    ref.step_pilot(ticks, cfg)
+    for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img"):
+        assert np.array_equal(gym.env.fetch(name), ref.fetch(name)), name
+    assert gym.env.fetch("speed").max() > 0.0
+    ref.close()
+    car.stop()

@@ -77,6 +77,7 @@ SYMBOLS = [
     "driver_assist", "driver_assist_host",
     "default_mux_config", "control_mux", "control_mux_host", "control_mux_reset",
     "comm_get_unique_id", "comm_init", "comm_destroy", "allgather_returns", "stream_wait_external", "stream_signal_external",
+    "scratch", "upload", "counters",
 ]
 
 
@@ -103,7 +104,7 @@ PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1}          # TRS_PILO
 
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
-PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_debug_layer", "step_pilot"]
+PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_debug_layer", "pilot_act", "step_pilot"]
 
 
 class Api:
@@ -153,6 +154,9 @@ class Api:
             "allgather_returns": (i32, [vp, C.POINTER(vp), vp]),
             "stream_wait_external": (i32, [vp, vp]),
             "stream_signal_external": (i32, [vp, vp]),
+            "scratch": (i32, [vp, i32, C.c_size_t, C.POINTER(vp)]),
+            "upload": (i32, [vp, vp, vp, C.c_size_t]),
+            "counters": (i32, [vp, C.POINTER(C.c_uint64 * 4)]),
         }
         pilot = {
             "default_pilot_config": (None, [C.POINTER(TrsPilotConfig)]),
@@ -160,6 +164,7 @@ class Api:
             "pilot_forward": (i32, [vp, vp, i32, vp]),
             "pilot_forward_host": (i32, [vp, vp, i32, vp]),
             "pilot_debug_layer": (i32, [vp, i32, vp, C.c_size_t]),
+            "pilot_act": (i32, [vp, C.POINTER(TrsPilotConfig), vp, vp, vp, vp, vp, vp, i32]),
             "step_pilot": (i32, [vp, C.POINTER(TrsPilotConfig), i32]),
         }
         for name, (res, args) in sigs.items():

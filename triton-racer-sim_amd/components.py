@@ -13,7 +13,7 @@ Swap in ``car_templates/manage.py:72-75``::
 import numpy as np
 
 from .core import Component
-from .env import BatchedEnv
+from .env import SLOT_MODE, SLOT_USR, BatchedEnv, device_ptr, is_device_array
 
 GYM_INPUTS = ["mux/steering", "mux/throttle", "mux/breaking", "usr/reset"]       # gyminterface.py:52
 GYM_OUTPUTS = ["cam/img", "gym/x", "gym/y", "gym/z", "gym/speed", "gym/cte"]     # gyminterface.py:52
@@ -88,11 +88,14 @@ class BatchedGymInterface(Component):
     """N cars per tick: the same ports carry arrays (controls: float32[N] or scalars; outputs stay on the
     device — ``cam/img`` etc. are ``__cuda_array_interface__`` handles unless ``to_host=True``)."""
 
-    def __init__(self, n_envs, gym_config=None, to_host=False, auto_reset=True, env_id_base=0, _api=None):
+    def __init__(self, n_envs, gym_config=None, to_host=False, auto_reset=True, env_id_base=0, sync=True, _api=None):
         self.gym_config = dict(DEFAULT_GYM_CONFIG)
         self.gym_config.update(gym_config or {})
         Component.__init__(self, inputs=list(GYM_INPUTS), outputs=list(GYM_OUTPUTS) + ["loc/index", "gym/done"], threaded=False)
         self.to_host = to_host
+        # sync=False: hand the device handles out without waiting — for a part graph whose other parts work on THIS env's
+        # stream (HipKerasPilot(env=...), BatchedControlMultiplexer(env=...)): the stream orders them, the host never waits
+        self.sync = sync
         self.env = BatchedEnv(n_envs=n_envs, track=_track_for(self.gym_config), device=self.gym_config.get("hip_device", 0),
                               img_h=int(self.gym_config["img_h"]), img_w=int(self.gym_config["img_w"]), render=True,
                               auto_reset=auto_reset, env_id_base=env_id_base, _api=_api)
@@ -101,13 +104,22 @@ class BatchedGymInterface(Component):
         steering, throttle, breaking, reset = args
         if steering is None or throttle is None:
             steering, throttle = 0.0, 0.0
-        self.env.step(steering, throttle, breaking, reset=None if reset is None else reset)
+        if is_device_array(steering):                          # 'mux/*' as device handles: no host copy of the controls either
+            rs = None
+            if reset is not None and is_device_array(reset):
+                rs = device_ptr(reset)
+            elif reset is not None and np.any(reset):
+                self.env.reset(np.broadcast_to(np.asarray(reset).astype(bool), (self.env.n,)))
+            self.env.step_device(device_ptr(steering), device_ptr(throttle), device_ptr(breaking) or 0, rs or 0)
+        else:
+            self.env.step(steering, throttle, breaking, reset=None if reset is None else reset)
         names = ["img", "pos_x", "pos_y", "pos_z", "speed", "cte", "seg_idx", "done"]
         if self.to_host:
             return self.env.fetch_outputs()
         # device handles: the step ran on the env's own stream, so order it before anyone looks (one wait for the tuple).
         # 'cam/img' alternates between two buffers: a handle stays valid while the NEXT step renders, not beyond.
-        self.env.sync()
+        if self.sync:
+            self.env.sync()
         return tuple(self.env.device_array(n, sync=False) for n in names)
 
     def onShutdown(self):
@@ -205,6 +217,28 @@ class BatchedControlMultiplexer(Component):
             mode = [mode] * self.n
         clean = lambda a: 0.0 if a is None else a
         usr, ai = tuple(clean(a) for a in args[1:4]), tuple(clean(a) for a in args[4:7])
+        if any(is_device_array(a) for a in ai):
+            # device-resident: 'ai/*' arrive as device handles (HipKerasPilot on the same env) and 'mux/*' leave as device handles;
+            # only the per-car modes and the joystick values (a few bytes per car) are uploaded
+            d_mode = self.env.scratch(SLOT_MODE, (self.n,), np.uint8)
+            self.env.upload(d_mode, self.env.encode_modes(mode))
+            d_usr = []
+            for slot, a in zip(SLOT_USR, usr):
+                if is_device_array(a):
+                    d_usr.append(a)
+                else:
+                    buf = self.env.scratch(slot, (self.n,))
+                    self.env.upload(buf, a)
+                    d_usr.append(buf)
+            d_ai = []
+            for k, a in enumerate(ai):
+                if is_device_array(a):
+                    d_ai.append(a)
+                else:                                          # e.g. a pilot that answered (0.0, 0.0, 0.0) on the host
+                    buf = self.env.scratch(10 + k, (self.n,))
+                    self.env.upload(buf, a)
+                    d_ai.append(buf)
+            return self.env.control_mux_device(d_mode, d_usr, d_ai, cfg=self.mux, n=self.n)
         self.last = self.env.control_mux_host(mode, usr, ai, keep=self.last, cfg=self.mux)
         return self.last
 
@@ -257,7 +291,7 @@ class HipKerasPilot(Component):
     ``.h5`` itself where h5py is installed (``load_keras_weights``).  Ports may carry one frame (N = 1, the
     reference's use) or a batch ``uint8[N,H,W,3]`` with per-car speeds; the outputs are then arrays."""
 
-    def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0):
+    def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0, env=None):
         mt = getattr(model_type, "value", model_type)
         if mt not in ("cnn_2d_speed_control", "cnn_2d"):
             raise ValueError("HipKerasPilot implements ModelType.CNN_2D_SPD_CTL ('cnn_2d_speed_control') and ModelType.CNN_2D ('cnn_2d'): "
@@ -269,8 +303,11 @@ class HipKerasPilot(Component):
             if model_path is None:
                 raise ValueError("weights or model_path (.npz of model.get_weights(), or the Keras .h5) is required")
             weights = load_keras_weights(model_path)
-        self.env = BatchedEnv(n_envs=int(n_cars), track=None, device=device, render=False,
-                              img_h=int(self.cfg.get("img_h", 120)), img_w=int(self.cfg.get("img_w", 160)))
+        # env=: run on an existing env's handle (and stream) — the device-resident graph pilot -> mux -> sim of N cars, where
+        # 'cam/img' arrives as a device handle and 'ai/*' leave as device handles (frames never visit the host)
+        self._own_env = env is None
+        self.env = env if env is not None else BatchedEnv(n_envs=int(n_cars), track=None, device=device, render=False,
+                                                          img_h=int(self.cfg.get("img_h", 120)), img_w=int(self.cfg.get("img_w", 160)))
         self.env.pilot_load(weights)
         self.speed_control_threshold = float(self.cfg.get("spd_ctl_threshold", 1.1))
         self.speed_control_break = bool(self.cfg.get("spd_ctl_break", False))
@@ -283,6 +320,16 @@ class HipKerasPilot(Component):
     def step(self, *args):
         from . import control
         img, mode = args[0], getattr(args[-1], "value", args[-1])
+        if is_device_array(img):
+            # device-resident batch: model + post-processing on the device frames (trs_pilot_act); per-car modes are uploaded as codes
+            d_mode = None
+            if not (np.isscalar(mode) or isinstance(mode, str)) or mode not in ("ai", "ai_steering"):
+                modes = [mode] * self.env.n if (np.isscalar(mode) or isinstance(mode, str) or mode is None) else mode
+                d_mode = self.env.scratch(SLOT_MODE, (self.env.n,), np.uint8)
+                self.env.upload(d_mode, self.env.encode_modes(modes))
+            pc = dict(self.cfg); pc["model_type"] = self.model_type
+            speed = args[1] if is_device_array(args[1]) else None
+            return self.env.pilot_act_device(frames=img, speed=speed, mode=d_mode, cfg=pc)
         if img is None or mode not in ("ai", "ai_steering"):               # keras_pilot.py:46-48,139
             return 0.0, 0.0, 0.0
         img = np.asarray(img, dtype=np.uint8)
@@ -317,7 +364,8 @@ class HipKerasPilot(Component):
 
     def onShutdown(self):
         self.on = False
-        self.env.close()
+        if self._own_env:
+            self.env.close()
 
     def getName(self):
         return "Keras Pilot"

@@ -51,6 +51,8 @@ struct trs_env {
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
     unsigned long long* fault = nullptr; // pinned host word the kernels set when they refuse to run (dynamic LDS not at offset 0)
     float* glue = nullptr; size_t glue_bytes = 0;   // device scratch of the *_host control glue (trs_driver_assist_host, trs_control_mux_host)
+    void* scratch[32] = {}; size_t scratch_bytes[32] = {};   // trs_scratch
+    uint64_t d2h_bytes = 0, h2d_bytes = 0;                  // trs_counters: what the library itself copied
     trsim::Comm* comm = nullptr;         // trsim_comm.hip: the RCCL communicator of trs_comm_init, nullptr = none
     hipEvent_t ev_order = nullptr;       // trs_stream_wait_external / trs_stream_signal_external
     trsim::Resident* res = nullptr;      // trsim_resident.hip: the resident worker (trs_set_step_mode), nullptr = never used

@@ -1104,6 +1104,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf); (void)hipFree(e->glue);
+    for (void* sc : e->scratch) (void)hipFree(sc);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->fault) (void)hipHostFree(e->fault);
     (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
@@ -1290,6 +1291,7 @@ TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, c
     if (resident_steps(e)) return trsim::resident_post_host(e, h_st, h_th, h_br, h_rs, n_steps);
     { int rq = quiesce(e); if (rq) return rq; }
     const size_t n = (size_t)e->n;
+    e->h2d_bytes += n * 8 + (h_br ? n * 4 : 0) + (h_rs ? n : 0);
     HIPCHK(hipMemcpyAsync(e->ctl_steer, h_st, n * 4, hipMemcpyHostToDevice, e->sP));
     HIPCHK(hipMemcpyAsync(e->ctl_thr, h_th, n * 4, hipMemcpyHostToDevice, e->sP));
     if (h_br) HIPCHK(hipMemcpyAsync(e->ctl_brk, h_br, n * 4, hipMemcpyHostToDevice, e->sP));
@@ -1404,11 +1406,13 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
         hipStream_t sc = trsim::resident_copy_stream(e);
         HIPCHK(hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, sc));
         HIPCHK(hipStreamSynchronize(sc));
+        e->d2h_bytes += need;
         return trsim::check_fault(e);
     }
     int rc = sync_all(e);
     if (rc) return rc;
     HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    e->d2h_bytes += need;
     if (which == TRS_F_STATS && static_cast<unsigned long long*>(dst)[2] != 0)
         return fail(TRS_ERR_DEVICE, "raster kernel found its dynamic LDS segment at a non-zero offset");
     return TRS_OK;
@@ -1441,6 +1445,7 @@ TRS_EXPORT int trs_fetch_outputs(trs_env* e, uint8_t* h_img, float* h_x, float* 
     for (const Item& it : items) {
         if (!it.dst || !it.bytes) continue;
         HIPCHK(hipMemcpyAsync(e->pinned + off, it.src, it.bytes, hipMemcpyDeviceToHost, cs));
+        e->d2h_bytes += it.bytes;
         off += (it.bytes + 15) & ~(size_t)15;
     }
     HIPCHK(hipStreamSynchronize(cs));
@@ -1731,6 +1736,7 @@ TRS_EXPORT int trs_preprocess_host(trs_env* e, const trs_pre_config* c, const ui
     rc = trs_preprocess(e, c, e->tmp_in, e->tmp_out, n_images, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h_dst, e->tmp_out, bytes, hipMemcpyDeviceToHost, e->sP));
+    e->d2h_bytes += bytes; e->h2d_bytes += bytes;
     HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
 }
@@ -1765,6 +1771,7 @@ TRS_EXPORT int trs_normalize_host(trs_env* e, const uint8_t* h_src, float* h_dst
     rc = trs_normalize(e, e->tmp_in, e->tmp_f, n_images);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h_dst, e->tmp_f, bytes * sizeof(float), hipMemcpyDeviceToHost, e->sP));
+    e->d2h_bytes += bytes * sizeof(float); e->h2d_bytes += bytes;
     HIPCHK(hipStreamSynchronize(e->sP));
     return TRS_OK;
 }
@@ -1914,6 +1921,41 @@ TRS_EXPORT int trs_event_elapsed_ms(trs_env* e, int a, int b, float* ms)
     return TRS_OK;
 }
 
+TRS_EXPORT int trs_scratch(trs_env* e, int slot, size_t bytes, void** d_out)
+{
+    if (!e || !d_out || slot < 0 || slot >= 32) return fail(TRS_ERR_ARG, "bad scratch slot (0..31) / null argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (bytes > e->scratch_bytes[slot]) {
+        int rc = sync_all(e);                                // nothing in flight may still use the old buffer
+        if (rc) return rc;
+        (void)hipFree(e->scratch[slot]); e->scratch[slot] = nullptr; e->scratch_bytes[slot] = 0;
+        const size_t cap = align_up(std::max<size_t>(bytes, 256), 256);
+        HIPCHK(hipMalloc(&e->scratch[slot], cap));
+        HIPCHK(hipMemset(e->scratch[slot], 0, cap));
+        e->scratch_bytes[slot] = cap;
+    }
+    *d_out = e->scratch[slot];
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_upload(trs_env* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) return fail(TRS_ERR_ARG, "null argument");
+    if (!bytes) return TRS_OK;
+    HIPCHK(hipSetDevice(e->device));
+    { int rq = quiesce(e); if (rq) return rq; }
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->sP));   // pageable source: staged before the call returns
+    e->h2d_bytes += bytes;
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_counters(trs_env* e, uint64_t out[4])
+{
+    if (!e || !out) return fail(TRS_ERR_ARG, "null argument");
+    out[0] = e->d2h_bytes; out[1] = e->h2d_bytes; out[2] = e->step_count; out[3] = 0;
+    return TRS_OK;
+}
+
 TRS_EXPORT const char* trs_last_error(void) { return g_err.c_str(); }
 
 // ---- internal accessors for trsim_pilot.hip (not exported) ----------------------------------------------
@@ -1931,6 +1973,7 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
+void trs_internal_count(trs_env* e, uint64_t d2h, uint64_t h2d) { if (e) { e->d2h_bytes += d2h; e->h2d_bytes += h2d; } }
 int trsim::sync_handle(trs_env* e) { return sync_all(e); }
 int trsim::quiesce_handle(trs_env* e) { return quiesce(e); }
 int trsim::check_fault(trs_env* e)

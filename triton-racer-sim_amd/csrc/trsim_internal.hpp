@@ -19,4 +19,5 @@ struct TrsEnvView {
 bool trs_internal_view(trs_env* e, TrsEnvView* out);
 void** trs_internal_pilot_slot(trs_env* e);
 int trs_internal_fail(int code, const std::string& msg);
+void trs_internal_count(trs_env* e, uint64_t d2h_bytes, uint64_t h2d_bytes);   // trs_counters bookkeeping for copies made outside trsim_hip.hip
 void trs_pilot_free(void* ctx);       // defined in trsim_pilot.hip, called by trs_destroy

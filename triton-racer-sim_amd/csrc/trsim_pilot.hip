@@ -885,6 +885,7 @@ struct TailParams {
     const float *w2, *b2, *w3, *b3, *w4, *b4;    // Keras layouts [IN][OUT]
     float* raw_out;            // [n][2] or nullptr
     const float* speed;        // 'gym/speed' or nullptr (no post-processing)
+    const uint8_t* mode;       // 'usr/mode' per car (TRS_MODE_*) or nullptr: a car outside AI / AI_STEERING gets (0, 0, 0) (keras_pilot.py:139)
     float *steer, *thr, *brk;  // next controls
     int n, act;
     float threshold, rev_mult, brk_mult, smooth_thr;
@@ -934,6 +935,7 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     const float out[2] = {s4[wv][0], s4[wv][1]};
     if (p.raw_out) { p.raw_out[2 * i] = out[0]; p.raw_out[2 * i + 1] = out[1]; }
     if (!p.act) return;
+    if (p.mode && p.mode[i] != TRS_MODE_AI && p.mode[i] != TRS_MODE_AI_STEERING) { p.steer[i] = 0.0f; p.thr[i] = 0.0f; p.brk[i] = 0.0f; return; }
     float steering = out[0] < -1.0f ? -1.0f : (out[0] > 1.0f ? 1.0f : out[0]);     // __cap (keras_pilot.py:142-145)
     const float predicted = out[1] * 20.0f;                                         // :83
     const float real = p.speed[i];
@@ -1144,7 +1146,9 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
     return TRS_OK;
 }
 
-int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act)
+struct ActIo { const float* speed; const uint8_t* mode; float *steer, *thr, *brk; };   // where KerasPilot.step's inputs / outputs live (device)
+
+int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act, const ActIo* io = nullptr)
 {
     TailParams t{};
     t.h1 = static_cast<const float*>(c->slab); t.h1_slices = c->last_slices; t.h1_stride = (size_t)n * c->act_elems[7];
@@ -1152,6 +1156,7 @@ int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_
     t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
     if (act) {
         t.speed = v.speed; t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
+        if (io) { t.speed = io->speed ? io->speed : v.speed; t.mode = io->mode; t.steer = io->steer; t.thr = io->thr; t.brk = io->brk; }
         t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
         t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
         t.direct = cfg->model_type == TRS_PILOT_CNN_2D;
@@ -1378,6 +1383,7 @@ TRS_EXPORT int trs_pilot_forward_host(trs_env* e, const uint8_t* h_frames, int n
     int rc = trs_pilot_forward(e, c->tmp_frames, n_images, c->raw);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(h_out, c->raw, (size_t)n_images * 2 * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+    trs_internal_count(e, (uint64_t)n_images * 2 * sizeof(float), (uint64_t)n_images * c->H * c->W * 3);
     HIPCHK(hipStreamSynchronize(v.stream));
     return TRS_OK;
 }
@@ -1412,6 +1418,34 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     HIPCHK(hipMemcpy(tmp.data(), c->act[layer], total * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < total; ++i) { uint32_t u = (uint32_t)tmp[i] << 16; std::memcpy(&h_dst[i], &u, 4); }
     return TRS_OK;
+}
+
+TRS_EXPORT int trs_pilot_act(trs_env* e, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const uint8_t* d_mode,
+                             float* d_steer, float* d_thr, float* d_brk, int n)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (!cfg || cfg->struct_size != sizeof(trs_pilot_config)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.struct_size mismatch");
+    if (cfg->model_type != TRS_PILOT_SPD_CTL && cfg->model_type != TRS_PILOT_CNN_2D) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type: cnn_2d_speed_control or cnn_2d");
+    if (!d_steer || !d_thr || !d_brk || n < 0 || n > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "null output or n out of range (n <= n_envs)");
+    if (!d_speed && n != v.n) return trs_internal_fail(TRS_ERR_ARG, "the env's own speed needs n == n_envs");
+    HIPCHK(hipSetDevice(v.device));
+    if (n == 0) return TRS_OK;
+    if (!d_frames) {
+        if (n != v.n) return trs_internal_fail(TRS_ERR_ARG, "latest-frame source needs n == n_envs");
+        d_frames = v.latest_frame;
+    }
+    if (!d_frames) {                                // args[0] is None -> (0.0, 0.0, 0.0) (keras_pilot.py:46-47)
+        hipLaunchKernelGGL(trs_zero_controls_kernel, dim3((n + 255) / 256), dim3(256), 0, v.stream, d_steer, d_thr, d_brk, n);
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
+    }
+    int rc = forward(c, v, d_frames, n);
+    if (rc) return rc;
+    const ActIo io{d_speed, d_mode, d_steer, d_thr, d_brk};
+    return run_tail(c, v, n, c->raw, cfg, true, &io);
 }
 
 TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_steps)

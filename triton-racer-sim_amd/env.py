@@ -58,6 +58,27 @@ class _DevicePtr:
         }
 
 
+def device_ptr(x):
+    """Device address of a zero-copy handle: anything with ``__cuda_array_interface__`` (this module's handles, torch / cupy
+    arrays), or an integer; ``None`` / ``0`` stay ``None``."""
+    if x is None:
+        return None
+    if hasattr(x, "__cuda_array_interface__"):
+        return int(x.__cuda_array_interface__["data"][0]) or None
+    return int(x) or None
+
+
+def is_device_array(x):
+    return hasattr(x, "__cuda_array_interface__")
+
+
+# handle-owned scratch slots (trs_scratch) the device-resident parts use for the values that travel between them
+SLOT_AI = (0, 1, 2)            # 'ai/steering', 'ai/throttle', 'ai/breaking'    (HipKerasPilot)
+SLOT_MODE = 3                  # 'usr/mode' as uint8 codes                         (BatchedControlMultiplexer, HipKerasPilot)
+SLOT_USR = (4, 5, 6)           # 'usr/steering', 'usr/throttle', 'usr/breaking'   (uploaded joystick values)
+SLOT_MUX = (7, 8, 9)           # 'mux/steering', 'mux/throttle', 'mux/breaking'   (BatchedControlMultiplexer)
+
+
 def _stream_ptr(stream):
     """A HIP stream as an integer: accepts ``torch.cuda.Stream`` (``.cuda_stream``), cupy streams (``.ptr``) or the raw
     pointer value; ``0`` is the legacy default stream."""
@@ -399,6 +420,48 @@ class BatchedEnv:
         """Closed loop: controls = KerasPilot.step(previous frame, speed), then one env step; all on the device."""
         pc = cfg if isinstance(cfg, _ffi.TrsPilotConfig) else self.pilot_config(cfg)
         self.api.check(self.api.step_pilot(self._h, C.byref(pc), int(n_steps)), "step_pilot")
+
+    # -- device-resident part graphs (pilot -> mux -> sim without host copies of frames; car_templates/manage.py:46-75) ------
+    def scratch(self, slot, shape, dtype=np.float32):
+        """A handle-owned device buffer (``trs_scratch``) as a zero-copy handle; the same slot returns the same memory."""
+        shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        self.api.check(self.api.scratch(self._h, int(slot), nbytes, C.byref(ptr)), "scratch")
+        return _DevicePtr(ptr.value, shape, dtype, self)
+
+    def upload(self, dst, values):
+        """Host values into a device buffer on the env's stream (``trs_upload``); ``values`` is broadcast to the buffer's shape."""
+        cai = dst.__cuda_array_interface__
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.dtype(cai["typestr"])), cai["shape"]))
+        self.api.check(self.api.upload(self._h, device_ptr(dst), arr.ctypes.data, arr.nbytes), "upload")
+
+    def counters(self):
+        """``(device->host bytes, host->device bytes, steps)`` the library itself has copied / taken since creation."""
+        out = (C.c_uint64 * 4)()
+        self.api.check(self.api.counters(self._h, C.byref(out)), "counters")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def pilot_act_device(self, frames=None, speed=None, mode=None, cfg=None, n=None):
+        """``KerasPilot.step`` for n cars on the device (``trs_pilot_act``): frames / speed / mode are device handles (``None`` =
+        the env's latest frames / own speed / all cars in an AI mode); returns the three ``ai/*`` handles (scratch slots)."""
+        n = self.n if n is None else int(n)
+        pc = cfg if isinstance(cfg, _ffi.TrsPilotConfig) else self.pilot_config(cfg)
+        outs = [self.scratch(sl, (n,)) for sl in SLOT_AI]
+        self.api.check(self.api.pilot_act(self._h, C.byref(pc), device_ptr(frames), device_ptr(speed), device_ptr(mode),
+                                          *[device_ptr(o) for o in outs], n), "pilot_act")
+        return tuple(outs)
+
+    def control_mux_device(self, mode, usr, ai, cfg=None, loop_hz=20, n=None):
+        """One tick of ``ControlMultiplexer.step`` on device arrays (``trs_control_mux``).  ``mode``: uint8 device handle;
+        ``usr`` / ``ai``: three device handles each; returns the three ``mux/*`` handles (scratch slots, values of cars with an
+        unknown mode are kept from the previous tick)."""
+        n = self.n if n is None else int(n)
+        mc = cfg if isinstance(cfg, _ffi.TrsMuxConfig) else self.mux_config(cfg, loop_hz)
+        outs = [self.scratch(sl, (n,)) for sl in SLOT_MUX]
+        self.api.check(self.api.control_mux(self._h, C.byref(mc), device_ptr(mode), *[device_ptr(a) for a in usr], *[device_ptr(a) for a in ai],
+                                            *[device_ptr(o) for o in outs], n), "control_mux")
+        return tuple(outs)
 
     # -- the one exchange of the multi-GPU path (trs_comm_* / trs_allgather_returns: RCCL behind the C ABI) ----------------
     def comm_unique_id(self):
