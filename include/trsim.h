@@ -298,7 +298,11 @@ typedef struct trs_pilot_config {
 
 enum {
     TRS_PILOT_SPD_CTL = 0,  /* ModelType.CNN_2D_SPD_CTL: outputs (steering, speed / 20) + the speed controller (keras_pilot.py:78-95) */
-    TRS_PILOT_CNN_2D = 1    /* ModelType.CNN_2D: outputs (steering, throttle), both capped to [-1, 1], breaking 0 (keras_pilot.py:56-64) */
+    TRS_PILOT_CNN_2D = 1,   /* ModelType.CNN_2D: outputs (steering, throttle), both capped to [-1, 1], breaking 0 (keras_pilot.py:56-64) */
+    TRS_PILOT_SPD_FTR = 2,  /* ModelType.CNN_2D_SPD_FTR: Keras_2D_CNN.get_model(num_feature_vectors = 1) (keras_train.py:127-174,390-392); the model also
+                               reads speed / 20; outputs (steering, throttle) capped, breaking 0 (keras_pilot.py:67-76) */
+    TRS_PILOT_FULL_HOUSE = 3 /* ModelType.CNN_2D_FULL_HOUSE: Keras_2D_FULL_HOUSE.get_model (keras_train.py:184-245,396-398); inputs frame, speed / 20,
+                               'loc/segment'; outputs (steering, speed / 20) + the speed controller (keras_pilot.py:97-118) */
 };
 
 void trs_default_pilot_config(trs_pilot_config* cfg);
@@ -308,11 +312,23 @@ void trs_default_pilot_config(trs_pilot_config* cfg);
  * h_arrays[2*i] = kernel in Keras layout ([KH][KW][CIN][COUT] / [IN][OUT], float32), h_arrays[2*i+1] = bias.  Replaces
  * load_model(model_path) (components/keras_pilot.py:26); weights are rounded to bfloat16 for the MFMA convolutions. */
 int trs_pilot_load(trs_env* env, const float* const* h_arrays, int n_arrays);
+/* n_arrays selects the architecture (kernel, bias per layer, Keras layouts; BY LAYER NAME, in this order — the order of
+ * model.get_weights() of a functional model with several inputs depends on Keras's layer sorting, so bind by name):
+ *   22  conv1..conv7, dense1, dense2, dense3, output_layer                           cnn_2d_speed_control, cnn_2d
+ *   28  ... as above (dense1 has 16 more input rows), feature1, feature2, feature3     cnn_2d_speed_as_feature
+ *   42  conv1..conv7, dense1 (+64 rows), dense2, dense3, output_speed, feature1..3, current_spd_1..3,
+ *       dense4 (+128 rows), dense5, dense6, out_steering                              cnn_2d_full_house
+ * The rows of dense1 / dense4 over the flattened conv7 output run on the matrix cores (bf16 weights); the small branches and
+ * everything behind them are fp32. */
 
 /* model(img_arr) of KerasPilot.step (keras_pilot.py:49-55,81): uint8 frames -> raw outputs float[n_images][2]
  * (steering, speed/20).  d_frames NULL = the env's latest frames (n_images == n_envs). */
 int trs_pilot_forward(trs_env* env, const uint8_t* d_frames, int n_images, float* d_out);
 int trs_pilot_forward_host(trs_env* env, const uint8_t* h_frames, int n_images, float* h_out);
+/* ... for the model types with more inputs (keras_pilot.py:67-71,97-104): speed is divided by 20 inside, segment is 'loc/segment';
+ * NULL = the env's own (n_images == n_envs). */
+int trs_pilot_forward_ex(trs_env* env, const uint8_t* d_frames, const float* d_speed, const float* d_segment, int n_images, float* d_out);
+int trs_pilot_forward_host_ex(trs_env* env, const uint8_t* h_frames, const float* h_speed, const float* h_segment, int n_images, float* h_out);
 
 /* Activations of one layer of the last forward pass as float32 (tests): layer 0..6 = conv1..conv7 output
  * [n][OH][OW][C], 7 = dense1 [n][100]. */
@@ -321,11 +337,12 @@ int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats
 /* KerasPilot.step (keras_pilot.py:45-95,139-153) for n cars on DEVICE arrays — the part of a device-resident pilot -> mux -> sim
  * graph (car_templates/manage.py:46-75): model(d_frames), then the model type's post-processing, written to d_steering /
  * d_throttle / d_breaking (float[n]: 'ai/steering', 'ai/throttle', 'ai/breaking').  d_frames NULL = the env's latest frames
- * (n == n_envs; no frame yet -> zeros, keras_pilot.py:46-47); d_speed NULL = the env's own 'gym/speed'; d_mode (uint8[n],
+ * (n == n_envs; no frame yet -> zeros, keras_pilot.py:46-47); d_speed NULL = the env's own 'gym/speed'; d_segment ('loc/segment',
+ * read by cnn_2d_full_house only) NULL = from the env's own tracker index; d_mode (uint8[n],
  * TRS_MODE_*) NULL = every car in an AI mode, else cars outside AI / AI_STEERING get (0, 0, 0) (:139).  Asynchronous on the
  * handle's stream; frames never leave the device. */
-int trs_pilot_act(trs_env* env, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const uint8_t* d_mode,
-                  float* d_steering, float* d_throttle, float* d_breaking, int n);
+int trs_pilot_act(trs_env* env, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const float* d_segment,
+                  const uint8_t* d_mode, float* d_steering, float* d_throttle, float* d_breaking, int n);
 
 /* Closed loop for n_steps (the reference's tick order, car_templates/manage.py:46-75: the pilot acts on the frame the
  * sim stored on the previous tick): controls = KerasPilot.step(frame, speed) for ModelType.CNN_2D_SPD_CTL

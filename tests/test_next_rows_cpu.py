@@ -147,3 +147,33 @@ def test_keras_weight_files(tmp_path):
     except ImportError:
         with pytest.raises(RuntimeError, match="h5py"):
             load_keras_weights(str(tmp_path / "m.h5"))
+
+
+def test_track_data_processor_turns_a_tub_into_a_track(tmp_path, oracle_api):
+    """components/track_data_process.py:9-39: records 1..k-1 (record_0 skipped, stop at the first gap) -> [[x, y, z], ...] JSON,
+    which loads as a track (the reference's LocationTracker reads exactly this file format)."""
+    import json
+    from triton_racer_sim_amd.env import BatchedEnv
+    from triton_racer_sim_amd.recorder import DataStorage, TrackDataProcessor
+    tub = tmp_path / "records_1"
+    store = DataStorage(storage_path=str(tub))
+    env = BatchedEnv(n_envs=1, render=False, _api=oracle_api)
+    xs = []
+    for k in range(12):
+        env.step(0.1, 0.8)
+        x, y, z = (float(env.fetch(n)[0]) for n in ("pos_x", "pos_y", "pos_z"))
+        xs.append([x, y, z])
+        vals = {"cam/img": None, "mux/throttle": 0.8, "mux/steering": 0.1, "mux/break": 0.0, "gym/speed": 1.0, "loc/segment": 0.0,
+                "gym/x": x, "gym/y": y, "gym/z": z, "gym/cte": 0.0}
+        store.step(*[vals[n] for n in store.step_inputs[:-2]], False, True)
+    store.onShutdown()
+    (tub / "record_9.json").unlink()                                   # a gap ends the walk (track_data_process.py:30-31)
+    out = tmp_path / "line.json"
+    line = TrackDataProcessor(str(tub), str(out)).process(verbose=False)
+    assert line == xs[1:9]                                             # record_0 is never read, record_9 is missing
+    assert json.load(open(out)) == line
+    env.load_track(np.asarray(line))                                   # ... and it is a loadable track
+    assert env.n_points == 8
+    with pytest.raises(FileNotFoundError):
+        TrackDataProcessor(str(tmp_path / "nope"), str(out))
+    env.close()

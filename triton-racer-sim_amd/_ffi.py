@@ -100,11 +100,21 @@ class TrsPilotConfig(C.Structure):
 
 COMM_ID_BYTES = 128                                                    # TRS_COMM_ID_BYTES
 
-PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1}          # TRS_PILOT_*; ModelType values of components/keras_train.py
+PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1, "cnn_2d_speed_as_feature": 2, "cnn_2d_full_house": 3}   # TRS_PILOT_*; ModelType values (utils/types.py)
+
+# layer names in the order trs_pilot_load takes their (kernel, bias) pairs (include/trsim.h), per architecture
+PILOT_LAYERS = {
+    22: ["conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "dense1", "dense2", "dense3", "output_layer"],
+    28: ["conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "dense1", "dense2", "dense3", "output_layer", "feature1", "feature2", "feature3"],
+    42: ["conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7", "dense1", "dense2", "dense3", "output_speed", "feature1", "feature2", "feature3",
+         "current_spd_1", "current_spd_2", "current_spd_3", "dense4", "dense5", "dense6", "out_steering"],
+}
+PILOT_ARRAYS_OF_TYPE = {"cnn_2d_speed_control": 22, "cnn_2d": 22, "cnn_2d_speed_as_feature": 28, "cnn_2d_full_house": 42}
 
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
-PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_debug_layer", "pilot_act", "step_pilot"]
+PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_forward_ex", "pilot_forward_host_ex",
+                 "pilot_debug_layer", "pilot_act", "step_pilot"]
 
 
 class Api:
@@ -164,7 +174,9 @@ class Api:
             "pilot_forward": (i32, [vp, vp, i32, vp]),
             "pilot_forward_host": (i32, [vp, vp, i32, vp]),
             "pilot_debug_layer": (i32, [vp, i32, vp, C.c_size_t]),
-            "pilot_act": (i32, [vp, C.POINTER(TrsPilotConfig), vp, vp, vp, vp, vp, vp, i32]),
+            "pilot_forward_ex": (i32, [vp, vp, vp, vp, i32, vp]),
+            "pilot_forward_host_ex": (i32, [vp, vp, vp, vp, i32, vp]),
+            "pilot_act": (i32, [vp, C.POINTER(TrsPilotConfig), vp, vp, vp, vp, vp, vp, vp, i32]),
             "step_pilot": (i32, [vp, C.POINTER(TrsPilotConfig), i32]),
         }
         for name, (res, args) in sigs.items():

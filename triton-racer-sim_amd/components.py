@@ -254,28 +254,38 @@ PILOT_INPUTS = ["cam/img", "gym/speed", "loc/segment", "gym/cte", "usr/mode"]   
 PILOT_OUTPUTS = ["ai/steering", "ai/throttle", "ai/breaking"]
 
 
-def load_keras_weights(path):
+def load_keras_weights(path, by_name=False):
     """The arrays of ``model.get_weights()`` from an ``.npz`` (``np.savez(path, *model.get_weights())``) or, where h5py is
     installed (it is wherever the reference's TensorFlow is; not in this image), from the Keras HDF5 file the reference
     trains and loads (``keras_train.py:407``, ``keras_pilot.py:26``): layers in ``layer_names`` order, each layer's
     arrays in ``weight_names`` order — the order ``get_weights()`` uses."""
     if str(path).endswith(".npz"):
         with np.load(path) as z:
+            if by_name:    # np.savez(path, **{f"{layer.name}/{i}": w for layer in model.layers for i, w in enumerate(layer.get_weights())})
+                layers = {}
+                for k in z.files:
+                    name, _, idx = k.rpartition("/")
+                    layers.setdefault(name, {})[int(idx)] = z[k]
+                return {name: (d[0], d[1]) for name, d in layers.items() if len(d) == 2}
             return [z[k] for k in z.files]
     try:
         import h5py
     except ImportError as exc:
         raise RuntimeError(f"{path}: reading a Keras HDF5 model needs h5py; convert once with "
                            "np.savez('model.npz', *model.get_weights())") from exc
-    out = []
+    out, named = [], {}
     with h5py.File(path, "r") as f:
         g = f["model_weights"] if "model_weights" in f else f
         for layer in g.attrs["layer_names"]:
             layer = layer.decode() if isinstance(layer, bytes) else layer
+            arrs = []
             for name in g[layer].attrs["weight_names"]:
                 name = name.decode() if isinstance(name, bytes) else name
-                out.append(np.asarray(g[layer][name], dtype=np.float32))
-    return out
+                arrs.append(np.asarray(g[layer][name], dtype=np.float32))
+            out += arrs
+            if len(arrs) == 2:
+                named[layer] = (arrs[0], arrs[1])
+    return named if by_name else out
 
 
 class HipKerasPilot(Component):
@@ -293,16 +303,16 @@ class HipKerasPilot(Component):
 
     def __init__(self, cfg=None, model_path=None, model_type="cnn_2d_speed_control", weights=None, n_cars=1, device=0, env=None):
         mt = getattr(model_type, "value", model_type)
-        if mt not in ("cnn_2d_speed_control", "cnn_2d"):
-            raise ValueError("HipKerasPilot implements ModelType.CNN_2D_SPD_CTL ('cnn_2d_speed_control') and ModelType.CNN_2D ('cnn_2d'): "
-                             "the two types that run Keras_2D_CNN.get_model(input_shape, num_outputs=2, num_feature_vectors=0)")
+        from ._ffi import PILOT_MODEL_TYPES
+        if mt not in PILOT_MODEL_TYPES:
+            raise ValueError(f"HipKerasPilot implements the model types {sorted(PILOT_MODEL_TYPES)} (utils/types.py ModelType)")
         self.model_type = mt
         Component.__init__(self, inputs=list(PILOT_INPUTS), outputs=list(PILOT_OUTPUTS), threaded=False)
         self.cfg = dict(cfg or {})
         if weights is None:
             if model_path is None:
                 raise ValueError("weights or model_path (.npz of model.get_weights(), or the Keras .h5) is required")
-            weights = load_keras_weights(model_path)
+            weights = load_keras_weights(model_path, by_name=mt in ("cnn_2d_speed_as_feature", "cnn_2d_full_house"))
         # env=: run on an existing env's handle (and stream) — the device-resident graph pilot -> mux -> sim of N cars, where
         # 'cam/img' arrives as a device handle and 'ai/*' leave as device handles (frames never visit the host)
         self._own_env = env is None
@@ -329,14 +339,22 @@ class HipKerasPilot(Component):
                 self.env.upload(d_mode, self.env.encode_modes(modes))
             pc = dict(self.cfg); pc["model_type"] = self.model_type
             speed = args[1] if is_device_array(args[1]) else None
-            return self.env.pilot_act_device(frames=img, speed=speed, mode=d_mode, cfg=pc)
+            segment = args[2] if is_device_array(args[2]) else None     # 'loc/segment' (full house); None = from the env's own tracker index
+            return self.env.pilot_act_device(frames=img, speed=speed, mode=d_mode, cfg=pc, segment=segment)
         if img is None or mode not in ("ai", "ai_steering"):               # keras_pilot.py:46-48,139
             return 0.0, 0.0, 0.0
         img = np.asarray(img, dtype=np.uint8)
         single = img.ndim == 3
-        raw = self.env.pilot_forward_host(img[None] if single else img)    # [n, 2]: steering, speed / 20
+        nimg = 1 if single else img.shape[0]
+        if self.model_type == "cnn_2d_speed_as_feature":                   # :67-71: the model also reads speed / 20
+            raw = self.env.pilot_forward_host(img[None] if single else img, speed=np.broadcast_to(np.asarray(args[1], np.float32), (nimg,)))
+        elif self.model_type == "cnn_2d_full_house":                       # :97-104: ... and 'loc/segment'
+            raw = self.env.pilot_forward_host(img[None] if single else img, speed=np.broadcast_to(np.asarray(args[1], np.float32), (nimg,)),
+                                              segment=np.broadcast_to(np.asarray(args[2], np.float32), (nimg,)))
+        else:
+            raw = self.env.pilot_forward_host(img[None] if single else img)    # [n, 2]: steering, speed / 20
         steering = np.clip(raw[:, 0].astype(np.float64), -1.0, 1.0)        # __cap (:142-145)
-        if self.model_type == "cnn_2d":                                    # :56-64: (steering, throttle) capped, no brake
+        if self.model_type in ("cnn_2d", "cnn_2d_speed_as_feature"):       # :56-76: (steering, throttle) capped, no brake
             throttle = np.clip(raw[:, 1].astype(np.float64), -1.0, 1.0)
             if self.smooth_steering:
                 steering = np.where(steering > self.smooth_steering_threshold, 1.0,

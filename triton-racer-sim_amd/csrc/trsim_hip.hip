@@ -1966,7 +1966,7 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
     v->device = e->device; v->n = e->n; v->H = e->H; v->W = e->W; v->render = e->cfg.render;
     v->stream = e->sP;
     v->latest_frame = (e->cfg.render && e->step_count > 0) ? e->img[(e->step_count + 1) & 1] : nullptr;
-    v->speed = e->pp.speed;
+    v->speed = e->pp.speed; v->seg_idx = e->pp.seg_idx; v->n_points = e->pp.np;
     v->ctl_steer = e->ctl_steer; v->ctl_thr = e->ctl_thr; v->ctl_brk = e->ctl_brk;
     v->step_count = e->step_count;
     return true;

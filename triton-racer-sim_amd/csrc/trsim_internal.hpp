@@ -12,6 +12,7 @@ struct TrsEnvView {
     hipStream_t stream;
     const uint8_t* latest_frame;      // uint8[n][H][W][3] of the last completed step, or nullptr
     const float* speed;               // 'gym/speed'
+    const int32_t* seg_idx; int n_points;   // LocationTracker index and track length ('loc/segment' = idx / n_points * 10)
     float *ctl_steer, *ctl_thr, *ctl_brk;   // the handle's own control staging arrays (device)
     uint64_t step_count;
 };

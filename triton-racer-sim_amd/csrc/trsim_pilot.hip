@@ -957,6 +957,132 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
 }
 
+// The tail of the model types with extra inputs (components/keras_train.py): cnn_2d_speed_as_feature =
+// Keras_2D_CNN.get_model(num_feature_vectors = 1) (:127-174: speed / 20 -> Dense 4 -> 8 -> 16, concatenated behind the flatten in
+// front of dense1) and cnn_2d_full_house = Keras_2D_FULL_HOUSE.get_model (:184-245: 'loc/segment' -> 16 -> 32 -> 64 joins the
+// flatten for the speed head dense1..3 -> output_speed; speed / 20 -> 16 -> 32 -> 64 joins both for the steering head
+// dense4..6 -> out_steering; output = [steering, speed]).  The rows of dense1 / dense4 that multiply the flatten ran on the
+// matrix cores (split-K slabs, added here in slice order); the rows of the small branches and everything behind are fp32, one
+// wave per frame, a fixed summation order (k ascending) so that two runs agree bit for bit.
+enum { XO_F1W, XO_F1B, XO_F2W, XO_F2B, XO_F3W, XO_F3B, XO_W1Y, XO_W2, XO_B2, XO_W3, XO_B3, XO_W4, XO_B4,
+       XO_C1W, XO_C1B, XO_C2W, XO_C2B, XO_C3W, XO_C3B, XO_W4Y, XO_W5, XO_B5, XO_W6, XO_B6, XO_W7, XO_B7, XO_COUNT };
+
+struct TailExParams {
+    const float* h1; int h1_slices; size_t h1_stride;       // dense1: slabs of [n][100]
+    const float* h4; int h4_slices; size_t h4_stride;       // dense4 (full house) or nullptr
+    const float* blob; int xo[32];
+    int arch, f1, f2, f3;                                    // widths of the small branches (4, 8, 16 or 16, 32, 64)
+    const float* speed; const float* segment; const int32_t* seg_idx; int np;   // 'gym/speed'; 'loc/segment' given, or from the env's index
+    const uint8_t* mode;
+    float* raw_out; float *steer, *thr, *brk;
+    int n, act;
+    float threshold, rev_mult, brk_mult, smooth_thr;
+    int use_break, smooth;
+};
+
+__device__ __forceinline__ void dense_small(const float* in, int nin, const float* w, const float* b, int nout, float* out, int lane, bool relu)
+{   // out[o] = act(b[o] + sum_k in[k] * w[k][o]), lanes over o (nout <= 128)
+    for (int o = lane; o < nout; o += 64) {
+        float s = b[o];
+        for (int k = 0; k < nin; ++k) s = fmaf(in[k], w[k * nout + o], s);
+        out[o] = relu ? (s > 0.f ? s : 0.f) : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void trs_pilot_tail_ex_kernel(const TailExParams p)
+{
+    __shared__ float sy[4][3][64], ss[4][3][64], sh[4][2][100], sa[4][2][50], sb[4][2][25], so[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    if (i >= p.n) return;
+    const float* B = p.blob;
+    const float real = p.speed[i];
+    // the small branches
+    float fin = real / 20.0f;                                                      // keras_pilot.py:68,100: speed / 20
+    if (p.arch == TRS_PILOT_FULL_HOUSE)                                            // 'loc/segment' (track_data_process.py:106-107: idx / len * 10, binary64)
+        fin = p.segment ? p.segment[i] : (float)((double)p.seg_idx[i] / (double)p.np * 10.0);
+    if (lane == 0) sy[wv][2][63] = fin;
+    __builtin_amdgcn_wave_barrier();
+    dense_small(&sy[wv][2][63], 1, B + p.xo[XO_F1W], B + p.xo[XO_F1B], p.f1, sy[wv][0], lane, true);
+    __builtin_amdgcn_wave_barrier();
+    dense_small(sy[wv][0], p.f1, B + p.xo[XO_F2W], B + p.xo[XO_F2B], p.f2, sy[wv][1], lane, true);
+    __builtin_amdgcn_wave_barrier();
+    dense_small(sy[wv][1], p.f2, B + p.xo[XO_F3W], B + p.xo[XO_F3B], p.f3, sy[wv][2], lane, true);
+    if (p.arch == TRS_PILOT_FULL_HOUSE) {
+        if (lane == 0) ss[wv][2][63] = real / 20.0f;
+        __builtin_amdgcn_wave_barrier();
+        dense_small(&ss[wv][2][63], 1, B + p.xo[XO_C1W], B + p.xo[XO_C1B], p.f1, ss[wv][0], lane, true);
+        __builtin_amdgcn_wave_barrier();
+        dense_small(ss[wv][0], p.f1, B + p.xo[XO_C2W], B + p.xo[XO_C2B], p.f2, ss[wv][1], lane, true);
+        __builtin_amdgcn_wave_barrier();
+        dense_small(ss[wv][1], p.f2, B + p.xo[XO_C3W], B + p.xo[XO_C3B], p.f3, ss[wv][2], lane, true);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dense1 (and dense4): slabs in slice order, then the rows of the small branches, then ReLU
+    for (int head = 0; head < (p.arch == TRS_PILOT_FULL_HOUSE ? 2 : 1); ++head) {
+        const float* slab = head ? p.h4 : p.h1;
+        const int slices = head ? p.h4_slices : p.h1_slices;
+        const size_t stride = head ? p.h4_stride : p.h1_stride;
+        const float* wy = B + p.xo[head ? XO_W4Y : XO_W1Y];
+        for (int o = lane; o < 100; o += 64) {
+            float x = 0.0f;
+            for (int sl = 0; sl < slices; ++sl) x += slab[(size_t)sl * stride + (size_t)i * 100 + o];
+            for (int k = 0; k < p.f3; ++k) x = fmaf(sy[wv][2][k], wy[k * 100 + o], x);
+            if (head) for (int k = 0; k < p.f3; ++k) x = fmaf(ss[wv][2][k], wy[(p.f3 + k) * 100 + o], x);
+            sh[wv][head][o] = x > 0.f ? x : 0.f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nz = p.arch == TRS_PILOT_FULL_HOUSE ? 1 : 2;                         // outputs of the first head
+    dense_small(sh[wv][0], 100, B + p.xo[XO_W2], B + p.xo[XO_B2], 50, sa[wv][0], lane, true);
+    if (p.arch == TRS_PILOT_FULL_HOUSE) dense_small(sh[wv][1], 100, B + p.xo[XO_W5], B + p.xo[XO_B5], 50, sa[wv][1], lane, true);
+    __builtin_amdgcn_wave_barrier();
+    dense_small(sa[wv][0], 50, B + p.xo[XO_W3], B + p.xo[XO_B3], 25, sb[wv][0], lane, true);
+    if (p.arch == TRS_PILOT_FULL_HOUSE) dense_small(sa[wv][1], 50, B + p.xo[XO_W6], B + p.xo[XO_B6], 25, sb[wv][1], lane, true);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        auto lin = [&](const float* in, const float* w, const float* b, int nout, int o) {
+            float s = b[o];
+            for (int k = 0; k < 25; ++k) s = fmaf(in[k], w[k * nout + o], s);
+            return s;
+        };
+        if (p.arch == TRS_PILOT_FULL_HOUSE) {                                      // [out_steering, out_speed] (keras_train.py:240)
+            so[wv][0] = lin(sb[wv][1], B + p.xo[XO_W7], B + p.xo[XO_B7], 1, 0);
+            so[wv][1] = lin(sb[wv][0], B + p.xo[XO_W4], B + p.xo[XO_B4], nz, 0);
+        } else {
+            so[wv][0] = lin(sb[wv][0], B + p.xo[XO_W4], B + p.xo[XO_B4], nz, 0);
+            so[wv][1] = lin(sb[wv][0], B + p.xo[XO_W4], B + p.xo[XO_B4], nz, 1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+    const float out[2] = {so[wv][0], so[wv][1]};
+    if (p.raw_out) { p.raw_out[2 * i] = out[0]; p.raw_out[2 * i + 1] = out[1]; }
+    if (!p.act) return;
+    if (p.mode && p.mode[i] != TRS_MODE_AI && p.mode[i] != TRS_MODE_AI_STEERING) { p.steer[i] = 0.0f; p.thr[i] = 0.0f; p.brk[i] = 0.0f; return; }
+    float steering = out[0] < -1.0f ? -1.0f : (out[0] > 1.0f ? 1.0f : out[0]);
+    float throttle, breaking = 0.0f;
+    if (p.arch == TRS_PILOT_SPD_FTR) {                                             // keras_pilot.py:67-76: both outputs capped, breaking 0
+        throttle = out[1] < -1.0f ? -1.0f : (out[1] > 1.0f ? 1.0f : out[1]);
+    } else {                                                                       // full house: the speed controller (:97-118)
+        const float kHalfPi = 1.57079632679489661923f;
+        const float predicted = out[1] * 20.0f;
+        const float delta = predicted * p.threshold - real;
+        throttle = p.rev_mult * atanf(delta * 2.0f) / kHalfPi;
+        if (throttle > -0.2f && throttle < 0.0f) throttle = 0.0f;
+        if (p.use_break) {
+            throttle = (predicted - real > 0.0f) ? 1.0f : 0.0f;
+            breaking = -1.0f * p.brk_mult * atanf(delta * 1.0f) / kHalfPi;
+            if (breaking < 0.4f) breaking = 0.0f;
+        }
+    }
+    if (p.smooth) {
+        if (steering > p.smooth_thr) steering = 1.0f;
+        else if (steering < -p.smooth_thr) steering = -1.0f;
+    }
+    p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
+}
+
 __global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -983,9 +1109,14 @@ struct ConvLayer {
 
 struct PilotCtx {
     int n_cap = 0, H = 0, W = 0, cu_count = 256;
-    ConvLayer L[8];                       // conv1..7 + dense1 (1x1 "conv" over frames)
-    void* act[8] = {};                    // outputs of L[i] for n_cap frames (bf16; act[7] float)
-    size_t act_elems[8] = {};             // per frame
+    ConvLayer L[9];                       // conv1..7 + dense1 (1x1 "conv" over frames) [+ dense4: the second head of cnn_2d_full_house]
+    void* act[9] = {};                    // outputs of L[i] for n_cap frames (bf16; act[7], act[8] float)
+    size_t act_elems[9] = {};             // per frame
+    int arch = 0;                         // TRS_PILOT_SPD_CTL / CNN_2D share Keras_2D_CNN(2 outputs); TRS_PILOT_SPD_FTR (+1 feature vector); TRS_PILOT_FULL_HOUSE
+    int n_layers = 8;
+    float* xblob = nullptr;               // small fp32 weights of the extra dense branches (TailExParams offsets)
+    int xo[32] = {};                      // offsets (floats) into xblob
+    void* slab2 = nullptr; size_t slab2_bytes = 0; int last_slices2 = 1;   // dense4 partial sums
     float *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr, *w4 = nullptr, *b4 = nullptr;
     float* raw = nullptr;                 // [n_cap][2]
     uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
@@ -1009,7 +1140,7 @@ void free_ctx(PilotCtx* c)
     for (auto& l : c->L) { (void)hipFree(l.w); (void)hipFree(l.bias); (void)hipFree(l.goff); }
     for (auto& a : c->act) (void)hipFree(a);
     (void)hipFree(c->w2); (void)hipFree(c->b2); (void)hipFree(c->w3); (void)hipFree(c->b3); (void)hipFree(c->w4); (void)hipFree(c->b4);
-    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab);
+    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab); (void)hipFree(c->slab2); (void)hipFree(c->xblob);
     delete c;
 }
 
@@ -1142,14 +1273,53 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
     }
+    if (c->arch == TRS_PILOT_FULL_HOUSE) {                                 // the steering head's dense4 reads conv7's output as well
+        c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count);
+        const size_t need = (size_t)c->last_slices2 * n * c->act_elems[8] * sizeof(float);
+        if (c->slab2_bytes < need) {
+            HIPCHK(hipStreamSynchronize(v.stream));
+            (void)hipFree(c->slab2); c->slab2 = nullptr; c->slab2_bytes = 0;
+            HIPCHK(hipMalloc(&c->slab2, need));
+            c->slab2_bytes = need;
+        }
+        int rc = launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count);
+        if (rc) return rc;
+    }
     c->last_n = n;
     return TRS_OK;
 }
 
-struct ActIo { const float* speed; const uint8_t* mode; float *steer, *thr, *brk; };   // where KerasPilot.step's inputs / outputs live (device)
+struct ActIo { const float* speed; const float* segment; const uint8_t* mode; float *steer, *thr, *brk; };   // where KerasPilot.step's inputs / outputs live (device)
+
+// the model type a caller asks for must be one the loaded weights can serve
+int check_model_type(const PilotCtx* c, const trs_pilot_config* cfg)
+{
+    const int mt = cfg->model_type;
+    const bool ok = c->arch == TRS_PILOT_SPD_CTL ? (mt == TRS_PILOT_SPD_CTL || mt == TRS_PILOT_CNN_2D) : mt == c->arch;
+    if (!ok) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type does not match the loaded weights (22 arrays: cnn_2d_speed_control / cnn_2d; 28: cnn_2d_speed_as_feature; 42: cnn_2d_full_house)");
+    return TRS_OK;
+}
 
 int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act, const ActIo* io = nullptr)
 {
+    if (c->arch != TRS_PILOT_SPD_CTL) {
+        TailExParams t{};
+        t.h1 = static_cast<const float*>(c->slab); t.h1_slices = c->last_slices; t.h1_stride = (size_t)n * c->act_elems[7];
+        t.h4 = static_cast<const float*>(c->slab2); t.h4_slices = c->last_slices2; t.h4_stride = (size_t)n * c->act_elems[8];
+        t.blob = c->xblob; std::memcpy(t.xo, c->xo, sizeof t.xo);
+        t.arch = c->arch; t.f1 = c->arch == TRS_PILOT_SPD_FTR ? 4 : 16; t.f2 = 2 * t.f1; t.f3 = 4 * t.f1;
+        t.speed = (io && io->speed) ? io->speed : v.speed; t.segment = io ? io->segment : nullptr; t.seg_idx = v.seg_idx; t.np = v.n_points > 0 ? v.n_points : 1;
+        t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
+        if (act) {
+            t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
+            if (io) { t.mode = io->mode; t.steer = io->steer; t.thr = io->thr; t.brk = io->brk; }
+            t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
+            t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
+        }
+        hipLaunchKernelGGL(trs_pilot_tail_ex_kernel, dim3((n + 3) / 4), dim3(256), 0, v.stream, t);
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
+    }
     TailParams t{};
     t.h1 = static_cast<const float*>(c->slab); t.h1_slices = c->last_slices; t.h1_stride = (size_t)n * c->act_elems[7];
     t.w2 = c->w2; t.b2 = c->b2; t.w3 = c->w3; t.b3 = c->b3; t.w4 = c->w4; t.b4 = c->b4;
@@ -1183,7 +1353,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
 {
     TrsEnvView v;
     if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
-    if (!arr || n_arrays != 2 * kLayers) return trs_internal_fail(TRS_ERR_ARG, "expected 22 arrays: kernel and bias of conv1..conv7, dense1..dense3, output_layer");
+    if (!arr || (n_arrays != 2 * kLayers && n_arrays != 28 && n_arrays != 42))
+        return trs_internal_fail(TRS_ERR_ARG, "expected 22 arrays: kernel and bias of conv1..conv7, dense1..dense3, output_layer (28 with feature1..3 for cnn_2d_speed_as_feature; "
+                                              "42 for cnn_2d_full_house: ..., output_speed, feature1..3, current_spd_1..3, dense4..6, out_steering)");
     for (int i = 0; i < n_arrays; ++i) if (!arr[i]) return trs_internal_fail(TRS_ERR_ARG, "null weight array");
     HIPCHK(hipSetDevice(v.device));
     void** slot = trs_internal_pilot_slot(e);
@@ -1192,17 +1364,20 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     std::unique_ptr<PilotCtx, void (*)(PilotCtx*)> guard(new PilotCtx(), free_ctx);
     PilotCtx* const c = guard.get();
     c->n_cap = v.n; c->H = v.H; c->W = v.W;
+    c->arch = n_arrays == 28 ? TRS_PILOT_SPD_FTR : (n_arrays == 42 ? TRS_PILOT_FULL_HOUSE : TRS_PILOT_SPD_CTL);
+    c->n_layers = c->arch == TRS_PILOT_FULL_HOUSE ? 9 : 8;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, v.device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
     static const int spec[7][4] = {{5, 2, 3, 24}, {5, 2, 24, 32}, {5, 2, 32, 64}, {3, 1, 64, 64}, {3, 1, 64, 64}, {3, 1, 64, 128}, {3, 1, 128, 128}};
     int ih = v.H, iw = v.W;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < c->n_layers; ++i) {
         ConvLayer& l = c->L[i];
         if (i < 7) { l.KH = l.KW = spec[i][0]; l.S = spec[i][1]; l.CIN = spec[i][2]; l.COUT = spec[i][3]; l.IH = ih; l.IW = iw; }
-        else { l.KH = l.KW = 1; l.S = 1; l.CIN = ih * iw * 128; l.COUT = 100; l.IH = 1; l.IW = 1; }     // dense1 over the NHWC flatten
+        else { l.KH = l.KW = 1; l.S = 1; l.CIN = ih * iw * 128; l.COUT = 100; l.IH = 1; l.IW = 1; }     // dense1 (and dense4) over the NHWC flatten:
+                                                                                                          // the kernel's first CIN rows; the rows of the small branches go to the tail
         l.OH = (l.IH - l.KH) / l.S + 1; l.OW = (l.IW - l.KW) / l.S + 1;
         if (l.OH < 1 || l.OW < 1) { return trs_internal_fail(TRS_ERR_LIMIT, "image too small for Keras_2D_CNN"); }
         l.COUT_PAD = (l.COUT + 31) / 32 * 32;
-        l.u8in = (i == 0); l.relu = true; l.out_f32 = (i == 7);
+        l.u8in = (i == 0); l.relu = true; l.out_f32 = (i >= 7);
         // granules: a kernel row is one contiguous run of KW * CIN / 8 granules in NHWC; runs are padded to whole trips of 4
         // (zero weights) so that a trip is always 64 contiguous bytes (trs_conv_lt_kernel); dense1 is one long run
         const int run = l.u8in ? 2 : l.KW * l.CIN / 8, run_pad = l.u8in ? 2 : (run + 3) & ~3;
@@ -1210,7 +1385,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         l.G_pad = (l.G + 3) & ~3;
         l.gchunk = std::max(4, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~3));
         l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
-        if (i == 7) {      // dense1: few row tiles, long K -> one LDS chunk per workgroup along K (ReLU moves into the tail kernel)
+        if (i >= 7) {      // dense1: few row tiles, long K -> one LDS chunk per workgroup along K (ReLU moves into the tail kernel)
             l.gchunk = std::min(l.gchunk, 16);
             l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
             l.ksplit = (l.G_pad + l.gchunk - 1) / l.gchunk;
@@ -1256,8 +1431,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
-        const float* K = arr[2 * i];
-        const float* B = arr[2 * i + 1];
+        const int ai = i == 8 ? 34 : 2 * i;                               // dense4 of the full-house model
+        const float* K = arr[ai];
+        const float* B = arr[ai + 1];
         std::vector<unsigned short> wp((size_t)l.G_pad * l.COUT_PAD * 8, 0);
         std::vector<int> goff(l.G_pad, 0);
         for (int g = 0; g < l.G; ++g) {
@@ -1290,13 +1466,34 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         if (rc) return rc;
         c->act_elems[i] = (size_t)l.OH * l.OW * l.COUT;
         HIPCHK(hipMalloc(&c->act[i], (size_t)c->n_cap * c->act_elems[i] * (l.out_f32 ? 4 : 2) + 64));
-        ih = l.OH; iw = l.OW;
+        if (i < 7) { ih = l.OH; iw = l.OW; }
     }
     auto up = [&](float** dst, const float* src, size_t n) -> int { std::vector<float> t(src, src + n); return upload(dst, t); };
+    const int nz = c->arch == TRS_PILOT_FULL_HOUSE ? 1 : 2;                // outputs of the first head
     int rc = up(&c->w2, arr[16], 100 * 50); if (!rc) rc = up(&c->b2, arr[17], 50);
     if (!rc) rc = up(&c->w3, arr[18], 50 * 25); if (!rc) rc = up(&c->b3, arr[19], 25);
-    if (!rc) rc = up(&c->w4, arr[20], 25 * 2); if (!rc) rc = up(&c->b4, arr[21], 2);
+    if (!rc) rc = up(&c->w4, arr[20], 25 * nz); if (!rc) rc = up(&c->b4, arr[21], nz);
     if (rc) return rc;
+    if (c->arch != TRS_PILOT_SPD_CTL) {        // the small fp32 branches of the tail: one blob, offsets by XO_*
+        const int F = (int)c->L[7].CIN;
+        const int f1 = c->arch == TRS_PILOT_SPD_FTR ? 4 : 16, f2 = 2 * f1, f3 = 4 * f1;
+        std::vector<float> blob;
+        auto put = [&](int slot, const float* src, size_t n) { c->xo[slot] = (int)blob.size(); blob.insert(blob.end(), src, src + n); };
+        put(XO_F1W, arr[22], f1); put(XO_F1B, arr[23], f1); put(XO_F2W, arr[24], (size_t)f1 * f2); put(XO_F2B, arr[25], f2);
+        put(XO_F3W, arr[26], (size_t)f2 * f3); put(XO_F3B, arr[27], f3);
+        put(XO_W1Y, arr[14] + (size_t)F * 100, (size_t)f3 * 100);            // dense1's rows behind the flatten
+        put(XO_W2, arr[16], 100 * 50); put(XO_B2, arr[17], 50); put(XO_W3, arr[18], 50 * 25); put(XO_B3, arr[19], 25);
+        put(XO_W4, arr[20], 25 * nz); put(XO_B4, arr[21], nz);
+        if (c->arch == TRS_PILOT_FULL_HOUSE) {
+            put(XO_C1W, arr[28], f1); put(XO_C1B, arr[29], f1); put(XO_C2W, arr[30], (size_t)f1 * f2); put(XO_C2B, arr[31], f2);
+            put(XO_C3W, arr[32], (size_t)f2 * f3); put(XO_C3B, arr[33], f3);
+            put(XO_W4Y, arr[34] + (size_t)F * 100, (size_t)2 * f3 * 100);    // dense4's rows for [feature3 | current_spd_3]
+            put(XO_W5, arr[36], 100 * 50); put(XO_B5, arr[37], 50); put(XO_W6, arr[38], 50 * 25); put(XO_B6, arr[39], 25);
+            put(XO_W7, arr[40], 25); put(XO_B7, arr[41], 1);
+        }
+        rc = upload(&c->xblob, blob);
+        if (rc) return rc;
+    }
     {   // conv1 -> conv2 fusion: needs the 5x5/2 + 5x5/2 head of Keras_2D_CNN and an LDS tile of 2 R2 + 3 conv1 rows
         const ConvLayer& l0 = c->L[0]; const ConvLayer& l1 = c->L[1];
         Fuse12Params& q = c->fuse;
@@ -1359,9 +1556,60 @@ TRS_EXPORT int trs_pilot_forward(trs_env* e, const uint8_t* d_frames, int n_imag
         if (!v.latest_frame || n_images != v.n) return trs_internal_fail(TRS_ERR_ARG, "latest-frame source needs a rendered step and n_images == n_envs");
         d_frames = v.latest_frame;
     }
+    if (c->arch != TRS_PILOT_SPD_CTL && n_images != v.n)
+        return trs_internal_fail(TRS_ERR_ARG, "this model type also reads speed (and segment): use trs_pilot_forward_ex, or n_images == n_envs for the env's own");
     int rc = forward(c, v, d_frames, n_images);
     if (rc) return rc;
     return run_tail(c, v, n_images, d_out ? d_out : c->raw, nullptr, false);
+}
+
+TRS_EXPORT int trs_pilot_forward_ex(trs_env* e, const uint8_t* d_frames, const float* d_speed, const float* d_segment, int n_images, float* d_out)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (n_images < 1 || n_images > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "n_images must be in [1, n_envs]");
+    if ((!d_speed || (c->arch == TRS_PILOT_FULL_HOUSE && !d_segment)) && n_images != v.n) return trs_internal_fail(TRS_ERR_ARG, "the env's own speed / segment need n_images == n_envs");
+    HIPCHK(hipSetDevice(v.device));
+    if (!d_frames) {
+        if (!v.latest_frame || n_images != v.n) return trs_internal_fail(TRS_ERR_ARG, "latest-frame source needs a rendered step and n_images == n_envs");
+        d_frames = v.latest_frame;
+    }
+    int rc = forward(c, v, d_frames, n_images);
+    if (rc) return rc;
+    const ActIo io{d_speed, d_segment, nullptr, nullptr, nullptr, nullptr};
+    return run_tail(c, v, n_images, d_out ? d_out : c->raw, nullptr, false, &io);
+}
+
+TRS_EXPORT int trs_pilot_forward_host_ex(trs_env* e, const uint8_t* h_frames, const float* h_speed, const float* h_segment, int n_images, float* h_out)
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
+    if (!h_frames || !h_out || n_images < 1 || n_images > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "bad argument (n_images must be in [1, n_envs])");
+    if (c->arch != TRS_PILOT_SPD_CTL && (!h_speed || (c->arch == TRS_PILOT_FULL_HOUSE && !h_segment))) return trs_internal_fail(TRS_ERR_ARG, "this model type needs speed (and segment) arrays");
+    HIPCHK(hipSetDevice(v.device));
+    const size_t bytes = (size_t)n_images * c->H * c->W * 3, extra = (size_t)n_images * 8;
+    if (bytes + extra > c->tmp_cap) {
+        HIPCHK(hipStreamSynchronize(v.stream));
+        (void)hipFree(c->tmp_frames); c->tmp_frames = nullptr; c->tmp_cap = 0;
+        HIPCHK(hipMalloc((void**)&c->tmp_frames, bytes + extra + 128));
+        c->tmp_cap = bytes + extra;
+    }
+    float* d_spd = reinterpret_cast<float*>(c->tmp_frames + ((bytes + 63) & ~(size_t)63));
+    float* d_seg = d_spd + n_images;
+    HIPCHK(hipMemcpyAsync(c->tmp_frames, h_frames, bytes, hipMemcpyHostToDevice, v.stream));
+    if (h_speed) HIPCHK(hipMemcpyAsync(d_spd, h_speed, (size_t)n_images * 4, hipMemcpyHostToDevice, v.stream));
+    if (h_segment) HIPCHK(hipMemcpyAsync(d_seg, h_segment, (size_t)n_images * 4, hipMemcpyHostToDevice, v.stream));
+    int rc = c->arch == TRS_PILOT_SPD_CTL ? trs_pilot_forward(e, c->tmp_frames, n_images, c->raw)
+                                          : trs_pilot_forward_ex(e, c->tmp_frames, h_speed ? d_spd : nullptr, h_segment ? d_seg : nullptr, n_images, c->raw);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_out, c->raw, (size_t)n_images * 2 * sizeof(float), hipMemcpyDeviceToHost, v.stream));
+    trs_internal_count(e, (uint64_t)n_images * 2 * sizeof(float), (uint64_t)bytes);
+    HIPCHK(hipStreamSynchronize(v.stream));
+    return TRS_OK;
 }
 
 TRS_EXPORT int trs_pilot_forward_host(trs_env* e, const uint8_t* h_frames, int n_images, float* h_out)
@@ -1420,17 +1668,17 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     return TRS_OK;
 }
 
-TRS_EXPORT int trs_pilot_act(trs_env* e, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const uint8_t* d_mode,
-                             float* d_steer, float* d_thr, float* d_brk, int n)
+TRS_EXPORT int trs_pilot_act(trs_env* e, const trs_pilot_config* cfg, const uint8_t* d_frames, const float* d_speed, const float* d_segment,
+                             const uint8_t* d_mode, float* d_steer, float* d_thr, float* d_brk, int n)
 {
     TrsEnvView v;
     if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
     PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
     if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
     if (!cfg || cfg->struct_size != sizeof(trs_pilot_config)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.struct_size mismatch");
-    if (cfg->model_type != TRS_PILOT_SPD_CTL && cfg->model_type != TRS_PILOT_CNN_2D) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type: cnn_2d_speed_control or cnn_2d");
+    { int rm = check_model_type(c, cfg); if (rm) return rm; }
     if (!d_steer || !d_thr || !d_brk || n < 0 || n > c->n_cap) return trs_internal_fail(TRS_ERR_ARG, "null output or n out of range (n <= n_envs)");
-    if (!d_speed && n != v.n) return trs_internal_fail(TRS_ERR_ARG, "the env's own speed needs n == n_envs");
+    if ((!d_speed || (c->arch == TRS_PILOT_FULL_HOUSE && !d_segment)) && n != v.n) return trs_internal_fail(TRS_ERR_ARG, "the env's own speed / segment need n == n_envs");
     HIPCHK(hipSetDevice(v.device));
     if (n == 0) return TRS_OK;
     if (!d_frames) {
@@ -1444,7 +1692,7 @@ TRS_EXPORT int trs_pilot_act(trs_env* e, const trs_pilot_config* cfg, const uint
     }
     int rc = forward(c, v, d_frames, n);
     if (rc) return rc;
-    const ActIo io{d_speed, d_mode, d_steer, d_thr, d_brk};
+    const ActIo io{d_speed, d_segment, d_mode, d_steer, d_thr, d_brk};
     return run_tail(c, v, n, c->raw, cfg, true, &io);
 }
 
@@ -1456,7 +1704,7 @@ TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_ste
     if (!c) return trs_internal_fail(TRS_ERR_STATE, "no pilot loaded");
     if (!cfg || cfg->struct_size != sizeof(trs_pilot_config)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.struct_size mismatch");
     if (n_steps < 1) return trs_internal_fail(TRS_ERR_ARG, "n_steps < 1");
-    if (cfg->model_type != TRS_PILOT_SPD_CTL && cfg->model_type != TRS_PILOT_CNN_2D) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type: cnn_2d_speed_control or cnn_2d");
+    { int rm = check_model_type(c, cfg); if (rm) return rm; }
     if (!v.render) return trs_internal_fail(TRS_ERR_STATE, "the pilot needs a camera (render = 1)");
     HIPCHK(hipSetDevice(v.device));
     for (int k = 0; k < n_steps; ++k) {

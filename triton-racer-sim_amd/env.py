@@ -384,6 +384,14 @@ class BatchedEnv:
         """``weights``: 22 float32 arrays — kernel, bias of conv1..conv7, dense1..dense3, output_layer in Keras
         layouts (``[KH][KW][CIN][COUT]`` / ``[IN][OUT]``), e.g. ``model.get_weights()`` of the reference's
         ``Keras_2D_CNN.get_model(input_shape, 2)`` (``components/keras_train.py:127-174``)."""
+        if isinstance(weights, dict):
+            # by layer name: {"conv1": (kernel, bias), ...}.  For the model types with several inputs this is the safe form: the
+            # order of model.get_weights() follows Keras's layer sorting, the library's order is fixed by name (include/trsim.h)
+            names = _ffi.PILOT_LAYERS[2 * len(weights)]
+            missing = [nm for nm in names if nm not in weights]
+            if missing:
+                raise ValueError(f"weights lack the layers {missing}")
+            weights = [a for nm in names for a in weights[nm]]
         arrs = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         self.api.check(self.api.pilot_load(self._h, ptrs, len(arrs)), "pilot_load")
@@ -400,15 +408,23 @@ class BatchedEnv:
         pc.smooth_steering_threshold = float(cfg.get("smooth_steering_threshold", 0.9))
         mt = getattr(cfg.get("model_type", "cnn_2d_speed_control"), "value", cfg.get("model_type", "cnn_2d_speed_control"))
         if mt not in _ffi.PILOT_MODEL_TYPES:
-            raise ValueError(f"model_type {mt!r}: the GPU pilot runs 'cnn_2d_speed_control' and 'cnn_2d'")
+            raise ValueError(f"model_type {mt!r}: the GPU pilot runs {sorted(_ffi.PILOT_MODEL_TYPES)}")
         pc.model_type = _ffi.PILOT_MODEL_TYPES[mt]
         return pc
 
-    def pilot_forward_host(self, frames):
-        """Raw model outputs ``float32[n, 2]`` (steering, speed / 20) for host frames ``uint8[n,H,W,3]``."""
+    def pilot_forward_host(self, frames, speed=None, segment=None):
+        """Raw model outputs ``float32[n, 2]`` for host frames ``uint8[n,H,W,3]``; ``speed`` ('gym/speed', divided by 20 inside)
+        for ``cnn_2d_speed_as_feature``, ``speed`` and ``segment`` ('loc/segment') for ``cnn_2d_full_house``."""
         src = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, self.H, self.W, 3)
-        out = np.empty((src.shape[0], 2), dtype=np.float32)
-        self.api.check(self.api.pilot_forward_host(self._h, src.ctypes.data, int(src.shape[0]), out.ctypes.data), "pilot_forward_host")
+        n = int(src.shape[0])
+        out = np.empty((n, 2), dtype=np.float32)
+        if speed is None and segment is None:
+            self.api.check(self.api.pilot_forward_host(self._h, src.ctypes.data, n, out.ctypes.data), "pilot_forward_host")
+            return out
+        f = lambda a: None if a is None else np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float32), (n,)))
+        sp, sg = f(speed), f(segment)
+        self.api.check(self.api.pilot_forward_host_ex(self._h, src.ctypes.data, None if sp is None else sp.ctypes.data,
+                                                      None if sg is None else sg.ctypes.data, n, out.ctypes.data), "pilot_forward_host_ex")
         return out
 
     def pilot_layer(self, layer, shape):
@@ -442,13 +458,13 @@ class BatchedEnv:
         self.api.check(self.api.counters(self._h, C.byref(out)), "counters")
         return int(out[0]), int(out[1]), int(out[2])
 
-    def pilot_act_device(self, frames=None, speed=None, mode=None, cfg=None, n=None):
+    def pilot_act_device(self, frames=None, speed=None, mode=None, cfg=None, n=None, segment=None):
         """``KerasPilot.step`` for n cars on the device (``trs_pilot_act``): frames / speed / mode are device handles (``None`` =
         the env's latest frames / own speed / all cars in an AI mode); returns the three ``ai/*`` handles (scratch slots)."""
         n = self.n if n is None else int(n)
         pc = cfg if isinstance(cfg, _ffi.TrsPilotConfig) else self.pilot_config(cfg)
         outs = [self.scratch(sl, (n,)) for sl in SLOT_AI]
-        self.api.check(self.api.pilot_act(self._h, C.byref(pc), device_ptr(frames), device_ptr(speed), device_ptr(mode),
+        self.api.check(self.api.pilot_act(self._h, C.byref(pc), device_ptr(frames), device_ptr(speed), device_ptr(segment), device_ptr(mode),
                                           *[device_ptr(o) for o in outs], n), "pilot_act")
         return tuple(outs)
 

@@ -166,3 +166,34 @@ def load_records(paths, loader="speed_ctl"):
     if not imgs:
         return np.zeros((0, 0, 0, 3), np.float32), np.zeros((0, 0), np.float32), np.zeros((0, 2), np.float32)
     return np.stack(imgs), np.stack(feats), np.stack(labels)
+
+
+class TrackDataProcessor:
+    """Tub -> centre-line file (reference ``components/track_data_process.py:9-39``): walks ``record_1.json, record_2.json, ...``
+    (from 1 — ``record_0.json`` is skipped exactly as the reference skips it) until the first missing file, collects
+    ``[gym/x, gym/y, gym/z]`` per record and dumps the list as JSON: the format ``LocationTracker`` / ``trs_load_track`` load
+    (``car_templates/track_data/*.json``).  Closes the loop for this build: drive (``HipGymInterface``), record
+    (``DataStorage``), process, then load the result as a track."""
+
+    def __init__(self, tub_path, output_path):
+        self.tub_path = tub_path
+        self.output_path = output_path
+        if not os.path.exists(tub_path):
+            raise FileNotFoundError("Cannot find tub {}".format(tub_path))
+        self.line = []
+
+    def process(self, verbose=True):
+        i = 1
+        while True:
+            try:
+                with open(os.path.join(self.tub_path, "record_{}.json".format(i))) as f:
+                    data = json.load(f)
+            except FileNotFoundError:
+                break
+            self.line.append([data["gym/x"], data["gym/y"], data["gym/z"]])
+            i += 1
+        if verbose:
+            print(i, "points loaded, Saving to ", self.output_path)       # (the reference prints the index of the first missing record)
+        with open(self.output_path, "w") as output_file:
+            json.dump(self.line, output_file)
+        return self.line
