@@ -158,8 +158,10 @@ def test_cnn_2d_model_type_closed_loop(make_env):
     for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img", "ctl_steer", "ctl_thr", "ctl_brk"):
         assert np.array_equal(a.fetch(name), b.fetch(name)), name   # no transcendental in this post-processing: bit for bit
     assert a.fetch("speed").max() > 0.1 and np.all(a.fetch("ctl_brk") == 0.0)
+    with pytest.raises(RuntimeError, match="model_type"):
+        a.step_pilot(1, {"model_type": "cnn_2d_full_house"})         # a valid type, but not what the 22 loaded arrays can serve
     with pytest.raises(ValueError, match="model_type"):
-        a.step_pilot(1, {"model_type": "cnn_2d_full_house"})
+        a.step_pilot(1, {"model_type": "lstm"})
 
 
 def test_break_mode_and_errors(make_env):
