@@ -213,8 +213,10 @@ def test_keras_pilot_component_contract(tmp_path):
     got = direct.step(frame, 3.0, 0.0, 0.0, "ai")
     assert got == (float(np.clip(np.float64(raw[0]), -1, 1)), float(np.clip(np.float64(raw[1]), -1, 1)), 0.0)
     direct.onShutdown()
-    with pytest.raises(ValueError, match="CNN_2D_SPD_CTL"):
-        HipKerasPilot(cfg, weights=ws, model_type="cnn_2d_full_house")
+    with pytest.raises(ValueError, match="needs the 42 arrays"):
+        HipKerasPilot(cfg, weights=ws, model_type="cnn_2d_full_house")     # another architecture's weights
+    with pytest.raises(ValueError, match="model types"):
+        HipKerasPilot(cfg, weights=ws, model_type="lstm")
 
 
 def test_pilot_is_deterministic(make_env):

@@ -313,6 +313,11 @@ class HipKerasPilot(Component):
             if model_path is None:
                 raise ValueError("weights or model_path (.npz of model.get_weights(), or the Keras .h5) is required")
             weights = load_keras_weights(model_path, by_name=mt in ("cnn_2d_speed_as_feature", "cnn_2d_full_house"))
+        from ._ffi import PILOT_ARRAYS_OF_TYPE
+        n_arrays = 2 * len(weights) if isinstance(weights, dict) else len(weights)
+        if n_arrays != PILOT_ARRAYS_OF_TYPE[mt]:
+            raise ValueError(f"model_type {mt!r} needs the {PILOT_ARRAYS_OF_TYPE[mt]} arrays of its architecture (kernel, bias per layer; "
+                             f"see trs_pilot_load in include/trsim.h), got {n_arrays}")
         # env=: run on an existing env's handle (and stream) — the device-resident graph pilot -> mux -> sim of N cars, where
         # 'cam/img' arrives as a device handle and 'ai/*' leave as device handles (frames never visit the host)
         self._own_env = env is None
