@@ -26,7 +26,7 @@ for j in range(len(seq[-1])):
     d=[int(s[j]["End_Timestamp"])-int(s[j]["Start_Timestamp"]) for s in seq]
     r=seq[-1][j]
     kn=r["Kernel_Name"]
-    kind="fused" if "conv12" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
+    kind="fused" if "conv12" in kn else "frame" if "conv_frame" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
     nm=names[j] if len(seq[-1])==len(names) else (fused[j] if len(seq[-1])==len(fused) else str(j))
     tot+=sum(d)/len(d)
     print(f"  {nm:9s} {kind:8s} grid={r['Grid_Size_X']:>8s}x{r['Grid_Size_Y']} wg={r['Workgroup_Size_X']:>4s} lds={r.get('LDS_Block_Size','?'):>7s}  mean {sum(d)/len(d)/1e3:8.1f} us")

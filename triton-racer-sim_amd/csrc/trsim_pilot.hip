@@ -491,6 +491,168 @@ __global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
     }
 }
 
+// conv4 .. conv7 (3x3, stride 1): the whole input activation of a frame is 13-26 KB, so F frames of it live in LDS and the nine
+// overlapping windows of every output pixel are read from there — the quad-load kernel above fetched every input byte nine times
+// through the texture addresser.  One workgroup = F frames:
+//   staging   input granules (8 channels = 16 B) global -> LDS by LDS-DMA, XOR-swizzled within the pixel's row of granules
+//             (physical slot q = g ^ swz(pixel); the swizzle goes on the SOURCE address, the LDS side stays lane-linear) so that
+//             the 16 lanes of a ds_read_b128 group — 16 consecutive pixels, one logical granule — cover all 64 banks
+//   work item a super-tile of NT x 32 output pixels (consecutive over the workgroup's frames) x NB x 32 output channels, one wave;
+//             per k-step (16 input channels of one tap): NT ds_read_b128 (pixels, B operand), NB weight granules straight from
+//             L2 (A operand, 512 contiguous bytes per half wave, prefetched kFrameRing k-steps ahead in registers), NT x NB MFMAs.
+//             Each pixel fragment feeds NB MFMAs and each weight fragment NT: LDS and L2 each supply half of what one-to-one
+//             feeding would need (LDS 128 B/clk and L2 64 B/clk per CU are what bound a 32x32x16 MFMA stream otherwise)
+//   epilogue  bias + ReLU + bf16, 8-byte stores (these activations are small: 9-19 KB per frame)
+struct FrameConvParams {
+    const u4v* in;             // bf16 NHWC [N][IH][IW][CIN] as 16-B granules
+    const u4v* w;              // [KH*KW*cg][COUT_PAD] granules (kernel-row major, then tap, then channel granule)
+    const float* bias;
+    unsigned short* out;       // bf16 NHWC [N][OH][OW][COUT]
+    int N, IH, IW, OH, OW, COUT, COUT_PAD, KH, KW;
+    int F, cg, cgs;            // frames per workgroup; granules per pixel (8 / 16) and log2 of it
+    int relu;
+};
+// weight prefetch: a register ring of R k-steps (R x NB granules per lane), refilled slot by slot right behind the MFMAs that
+// consumed the slot: R x NT x NB x 32 MFMA clocks of lead time (>= 1,000) against an L2 round trip of 500-800.  The unrolled
+// group of R k-steps is a whole number of taps: 12 = one kernel row of 3 taps at 64 input channels (4 k-steps per tap), 8 = one
+// tap at 128 input channels.
+
+#ifndef TRS_FRAME_ABLATE
+#define TRS_FRAME_ABLATE 0   /* timing-only diagnostic builds of trs_conv_frame_kernel, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no stores, 4 = no staging */
+#endif
+__device__ __forceinline__ int frame_swz(int pix, int cgs) { return cgs == 3 ? ((pix >> 1) & 7) : (pix & 15); }
+
+template <int NT, int NB, int HALF, int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvParams p)
+{
+    // R = HALF x TAPS (deep ring, 4 waves per workgroup with the whole register file each) or R = 4 (one tap or half a tap per
+    // group: ~150 registers, 8 waves per workgroup, the second wave of a SIMD hides what the short ring does not)
+    static_assert(R >= 1 && R <= 9 * HALF, "ring depth in k-steps");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int f0 = blockIdx.x * p.F, nf = min(p.F, p.N - f0);
+    const int pix_in = p.IH * p.IW, ohw = p.OH * p.OW;
+    {   // staging
+        const int total = (nf * pix_in) << p.cgs;
+        const u4v* src0 = p.in + (((size_t)f0 * pix_in) << p.cgs);
+        const unsigned lds_base = (unsigned)(uintptr_t)psmem;
+        for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
+            const int sl = s0 + lane;
+            if (sl < total && TRS_FRAME_ABLATE != 4) {
+                const int pix = sl >> p.cgs, q = sl & (p.cg - 1);
+                const int g = q ^ frame_swz(pix, p.cgs);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + ((size_t)pix << p.cgs) + g),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
+            }
+        }
+        float* lb = reinterpret_cast<float*>(psmem + (((size_t)(p.F * pix_in) << p.cgs) * 16));
+        for (int i = tid; i < p.COUT_PAD; i += blockDim.x) lb[i] = p.bias[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const u4v* lin = reinterpret_cast<const u4v*>(psmem);
+    const float4* lbias = reinterpret_cast<const float4*>(psmem + (((size_t)(p.F * pix_in) << p.cgs) * 16));   // staged behind the activations
+    const int m_wg = nf * ohw;                                              // output pixels of this workgroup
+    const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = p.COUT_PAD / (NB * 32);
+    constexpr int ksteps = 9 * HALF;                                        // k-steps (16 input channels of one tap each) of a 3x3 kernel
+    for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
+        const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
+        const int cbase = cgrp * NB * 32;
+        int lbase[NT];                                                      // linear input-pixel index of each of this lane's windows
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = min(tile * NT * 32 + nt * 32 + r, m_wg - 1);
+            const int f = m / ohw, rem = m - f * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
+            lbase[nt] = (f * p.IH + oy) * p.IW + ox;
+        }
+        const u4v* wl = p.w + cbase + r;                                    // + (granule) * COUT_PAD + nb * 32
+        u4v ring[R][NB];
+#pragma unroll
+        for (int d = 0; d < R; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * p.COUT_PAD + nb * 32];
+        const u4v* wnext = wl + (size_t)(2 * R + h) * p.COUT_PAD;
+        [[maybe_unused]] bf16x8 xkeep[NT];
+        f32x16 acc[NT][NB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        // All ksteps k-steps are unrolled (3 x 12 or 9 x 8 ...): ONE basic block, no back edge — the compiler counts the weight
+        // loads in flight exactly (vmcnt(N) per k-step) instead of draining the queue at a loop head or behind a branch.  The pixel
+        // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
+        // that keeps "MFMAs of k, then the refill of k's ring slot" in place would otherwise also pin each k-step's LDS reads
+        // right in front of its own MFMAs: one LDS latency per 4 MFMAs).
+        auto pixels = [&](int k, bf16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
+            const int tap = k / HALF, g = 2 * (k % HALF) + h;
+            const int tap_off = (tap / 3) * p.IW + tap % 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pix = lbase[nt] + tap_off;
+#if TRS_FRAME_ABLATE == 2
+                if (k == 0) xkeep[nt] = __builtin_bit_cast(bf16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
+                x[nt] = xkeep[nt];
+#else
+                x[nt] = __builtin_bit_cast(bf16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
+#endif
+            }
+        };
+        bf16x8 xa[NT], xb[NT];
+        pixels(0, xa);
+#pragma unroll
+        for (int k = 0; k < ksteps; ++k) {
+            const int d = k % R;
+            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            if (k + 1 < ksteps) pixels(k + 1, xn);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+            if (k + R < ksteps && TRS_FRAME_ABLATE != 1) {                  // (compile-time) refill the slot with the k-step R ahead:
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];   // a running pointer — one live address, not one per k-step
+                wnext += 2 * p.COUT_PAD;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: register quad q of block nb = channels cbase + nb*32 + 8q + 4h .. +3 of pixel r.  The two lanes of a pixel
+        // (h = 0, 1) hold the two halves of every 8-channel group: they swap half of their quads (one cross-half shuffle per
+        // dword) so that each lane ends with whole 16-byte groups — lane h = 0 stores groups q = 0, 1, lane h = 1 groups 2, 3
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = tile * NT * 32 + nt * 32 + r;
+            unsigned short* o = p.out + ((size_t)f0 * ohw + min(m, m_wg - 1)) * p.COUT + cbase;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                uint2 w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
+                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    if (p.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f; }
+                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores
+                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
+                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
+                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};
+                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};
+#if TRS_FRAME_ABLATE == 3
+                asm volatile("" :: "v"(g0), "v"(g1)); (void)o;
+#else
+                if (m < m_wg) {
+                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;       // channels nb*32 + 16h .. + 7
+                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;   // ... + 8 .. + 15
+                }
+#endif
+            }
+        }
+    }
+}
+
 // conv2 / conv3 (stride-2 5x5): overlapping windows make the kernel above fetch every input byte ~2.5x, and the texture
 // addresser (about one lookup per clock) is what bounds these layers.  Here a wave stages, per kernel row, the CONTIGUOUS
 // input span its 32-pixel tile needs (a tile crosses output rows, so the span is 1..4 segments, one per output row touched)
@@ -1103,6 +1265,7 @@ struct ConvLayer {
     bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
     bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
+    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -1183,6 +1346,23 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > (nt_mb << 20)) ? nt_kind : 0;
     }
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
+    if (l.frame) {
+        FrameConvParams q{};
+        q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
+        q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.COUT = l.COUT; q.COUT_PAD = l.COUT_PAD; q.KH = l.KH; q.KW = l.KW;
+        q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
+        const int grid = (n_img + q.F - 1) / q.F;
+#define LAUNCH_FRAME(HALF_, R_, BLOCK_)                                                                                       \
+    do {                                                                                                                      \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<2, 2, HALF_, R_, BLOCK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((trs_conv_frame_kernel<2, 2, HALF_, R_, BLOCK_>), dim3(grid), dim3(BLOCK_), l.frame_lds, s, q);    \
+    } while (0)
+        if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(4, 12, 512); else LAUNCH_FRAME(4, 4, 512); }
+        else { if (l.frame_deep) LAUNCH_FRAME(8, 8, 512); else LAUNCH_FRAME(8, 4, 512); }
+#undef LAUNCH_FRAME
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
+    }
     if (l.resident) {
         const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
         const int grid_x = std::max(1, std::min((ntiles + waves - 1) / waves, cu_count * l.res_wg_per_cu));
@@ -1428,6 +1608,21 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 const int wv = std::max(4, std::min(32, std::atoi(e)));
                 const int w2 = std::max(1, std::min(16, wv / l.res_wg_per_cu));
                 if (l.res_wg_per_cu * (lds_for(l.res_nb, w2) + 512) <= 160 * 1024) { l.res_block = 64 * w2; l.res_lds = lds_for(l.res_nb, w2); }
+            }
+        }
+        if (i >= 3 && i < 7) {   // conv4..7: frames in LDS when they fit (240x320: conv7's 167 KB frame does not: the quad-load kernel stays)
+            int mask = 0x78;                                                  // bit i = conv(i+1)
+            if (const char* e = std::getenv("TRS_PILOT_FRAME_LAYERS")) mask = std::atoi(e);
+            const int cg = l.CIN / 8;
+            const size_t frame_bytes = (size_t)l.IH * l.IW * l.CIN * 2;
+            const bool shape_ok = l.S == 1 && l.KH == 3 && l.KW == 3 && (cg == 8 || cg == 16) && l.COUT_PAD % 64 == 0 && l.COUT == l.COUT_PAD && run_pad == l.KW * cg;
+            if (((mask >> i) & 1) && shape_ok && frame_bytes <= 150 * 1024) {
+                // frames per workgroup: as many as keep two workgroups per CU (<= 78 KB) and at least ~2 workgroups per CU in the grid
+                int f = (int)std::max<size_t>(1, std::min<size_t>(8, (78 * 1024) / frame_bytes));
+                if (const char* e = std::getenv("TRS_PILOT_FRAME_F")) f = std::max(1, std::atoi(e));
+                while (f > 1 && (c->n_cap + f - 1) / f < c->cu_count) --f;
+                l.frame_deep = std::getenv("TRS_PILOT_FRAME_DEEP") != nullptr;
+                l.frame = true; l.frame_f = f; l.frame_lds = (int)(f * frame_bytes) + l.COUT_PAD * 4;
             }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
