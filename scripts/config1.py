@@ -15,10 +15,10 @@ class Const(Component):
         return 0.05, 0.5, None, False
 
 
-def run(loop_hz, ticks):
+def run(loop_hz, ticks, resident=False, tracker=True):
     car = Car(loop_hz=loop_hz, verbose=False)
-    gym = HipGymInterface(gym_config={"scene_name": "generated_track"})
-    for part in (Const(), gym, LocationTracker("track_data/generated_track.json")):
+    gym = HipGymInterface(gym_config={"scene_name": "generated_track", "hip_resident": resident, "hip_resident_idle_us": 100000})
+    for part in (Const(), gym) + ((LocationTracker("track_data/generated_track.json"),) if tracker else ()):
         car.addComponent(part)
     car.tick()
     t0 = time.perf_counter()
@@ -32,5 +32,10 @@ def run(loop_hz, ticks):
 r, shape, ty = run(1e9, 5000)
 print(f"config 1, sleep disabled: {r:.0f} ticks/s (frame {shape} uint8 to host + 6 Python {ty}s + loc/segment per tick)")
 print(f"  PCIe-inclusive image rate: {r * 57600 / 1e6:.1f} MB/s (latency-bound: ctypes + hipMemcpy round trips, not the 63 GB/s link)")
+for res in (False, True):
+    r2, _, _ = run(1e9, 5000, resident=res, tracker=False)
+    print(f"config 1 without the LocationTracker part (its index already comes with the step), {'resident worker' if res else 'launch per tick'}: {r2:.0f} ticks/s")
+r3, _, _ = run(1e9, 5000, resident=True)
+print(f"config 1 as above with all three parts, resident worker: {r3:.0f} ticks/s")
 r20, _, _ = run(20, 60)
 print(f"config 1, 20 Hz pacing (car_templates/manage.py:38): {r20:.2f} ticks/s")

@@ -1,0 +1,8 @@
+#!/bin/bash
+set -o pipefail
+cd "$(dirname "$0")/.."
+O=gpurun_out/r02_pilot4
+mkdir -p $O
+echo "== pilot tests" && timeout -k 10 500 python -m pytest tests/test_pilot.py tests/test_pilot_types.py tests/test_configs_gpu.py -x -q > $O/tests.log 2>&1; rc=$?; tail -5 $O/tests.log; [ $rc -eq 0 ] || exit $rc
+PL_TAG=b1 timeout -k 10 300 bash scripts/pilot_layers.sh 2>&1 | tee $O/layers_120.txt
+PL_TAG=b5 timeout -k 10 300 bash scripts/pilot_layers.sh --envs-per-gpu 512 --img-h 240 --img-w 320 --depth 2>&1 | tee $O/layers_240.txt

@@ -22,6 +22,7 @@ GYM_OUTPUTS = ["cam/img", "gym/x", "gym/y", "gym/z", "gym/speed", "gym/cte"]    
 DEFAULT_GYM_CONFIG = {
     "img_w": 160, "img_h": 120, "scene_name": "generated_track", "sim_latency": 0,
     "track_data_file": "track_data/generated_track.json", "hip_device": 0,
+    "hip_resident": False,      # True: trs_set_step_mode(TRS_STEP_RESIDENT) - the per-tick step is POSTED to a worker kernel that stays on the GPU
 }
 
 _SCENE_TRACKS = {"generated_track": "generated_track.json", "mountain_track": "mountain_track.json"}
@@ -49,6 +50,8 @@ class HipGymInterface(Component):
         self._delay = collections.deque()
         self.env = BatchedEnv(n_envs=1, track=_track_for(self.gym_config), device=self.gym_config.get("hip_device", 0),
                               img_h=int(self.gym_config["img_h"]), img_w=int(self.gym_config["img_w"]), render=True, _api=_api)
+        if self.gym_config.get("hip_resident"):
+            self.env.set_step_mode(True, idle_us=int(self.gym_config.get("hip_resident_idle_us", 0)))
         self.last_image = None
         self.pos_x = self.pos_y = self.pos_z = self.speed = self.cte = 0.0
         self.seg_idx = 0

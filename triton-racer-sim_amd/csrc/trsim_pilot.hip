@@ -509,8 +509,9 @@ struct FrameConvParams {
     const float* bias;
     unsigned short* out;       // bf16 NHWC [N][OH][OW][COUT]
     int N, IH, IW, OH, OW, COUT, COUT_PAD, KH, KW;
-    int F, cg, cgs;            // frames per workgroup; granules per pixel (8 / 16) and log2 of it
-    int relu;
+    int F, cg, cgs;            // units (frames, or row bands of frames) per workgroup; granules per pixel (8 / 16) and log2 of it
+    int bands, ohb, ihb;       // a frame whose activation does not fit LDS is cut into `bands` bands of ohb output rows = ohb + KH - 1 input rows
+    int relu;                  // (neighbouring bands re-stage KH - 1 rows); bands == 1: ohb = OH, ihb = IH
 };
 // weight prefetch: a register ring of R k-steps (R x NB granules per lane), refilled slot by slot right behind the MFMAs that
 // consumed the slot: R x NT x NB x 32 MFMA clocks of lead time (>= 1,000) against an L2 round trip of 500-800.  The unrolled
@@ -530,40 +531,47 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
     static_assert(R >= 1 && R <= 9 * HALF, "ring depth in k-steps");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int f0 = blockIdx.x * p.F, nf = min(p.F, p.N - f0);
-    const int pix_in = p.IH * p.IW, ohw = p.OH * p.OW;
+    const int n_units = p.N * p.bands;
+    const int u0 = blockIdx.x * p.F, nu = min(p.F, n_units - u0);
+    const int upix = p.ihb * p.IW, uout = p.ohb * p.OW;                     // input pixels staged / output pixel slots per unit
     {   // staging
-        const int total = (nf * pix_in) << p.cgs;
-        const u4v* src0 = p.in + (((size_t)f0 * pix_in) << p.cgs);
+        const int total = (nu * upix) << p.cgs;
         const unsigned lds_base = (unsigned)(uintptr_t)psmem;
         for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
             const int sl = s0 + lane;
             if (sl < total && TRS_FRAME_ABLATE != 4) {
                 const int pix = sl >> p.cgs, q = sl & (p.cg - 1);
                 const int g = q ^ frame_swz(pix, p.cgs);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + ((size_t)pix << p.cgs) + g),
+                const int ul = pix / upix, rp = pix - ul * upix, iyl = rp / p.IW, ix = rp - iyl * p.IW;
+                const int u = u0 + ul, f = u / p.bands, band = u - f * p.bands;
+                const int iy = min(band * p.ohb + iyl, p.IH - 1);             // (rows below the frame are never read by a valid pixel)
+                const size_t gpix = ((size_t)f * p.IH + iy) * p.IW + ix;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + (gpix << p.cgs) + g),
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
             }
         }
-        float* lb = reinterpret_cast<float*>(psmem + (((size_t)(p.F * pix_in) << p.cgs) * 16));
+        float* lb = reinterpret_cast<float*>(psmem + (((size_t)(p.F * upix) << p.cgs) * 16));
         for (int i = tid; i < p.COUT_PAD; i += blockDim.x) lb[i] = p.bias[i];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     const u4v* lin = reinterpret_cast<const u4v*>(psmem);
-    const float4* lbias = reinterpret_cast<const float4*>(psmem + (((size_t)(p.F * pix_in) << p.cgs) * 16));   // staged behind the activations
-    const int m_wg = nf * ohw;                                              // output pixels of this workgroup
+    const float4* lbias = reinterpret_cast<const float4*>(psmem + (((size_t)(p.F * upix) << p.cgs) * 16));   // staged behind the activations
+    const int m_wg = nu * uout;                                             // output pixel slots of this workgroup
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = p.COUT_PAD / (NB * 32);
     constexpr int ksteps = 9 * HALF;                                        // k-steps (16 input channels of one tap each) of a 3x3 kernel
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
         const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
         const int cbase = cgrp * NB * 32;
-        int lbase[NT];                                                      // linear input-pixel index of each of this lane's windows
+        int lbase[NT];                                                      // linear LDS pixel index of each of this lane's windows
+        long long obase[NT];                                                // output pixel index in the layer's activation, -1 = no such pixel
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int m = min(tile * NT * 32 + nt * 32 + r, m_wg - 1);
-            const int f = m / ohw, rem = m - f * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-            lbase[nt] = (f * p.IH + oy) * p.IW + ox;
+            const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
+            const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
+            const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
+            lbase[nt] = (ul * p.ihb + oyl) * p.IW + ox;
+            obase[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
         }
         const u4v* wl = p.w + cbase + r;                                    // + (granule) * COUT_PAD + nb * 32
         u4v ring[R][NB];
@@ -623,8 +631,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
         // dword) so that each lane ends with whole 16-byte groups — lane h = 0 stores groups q = 0, 1, lane h = 1 groups 2, 3
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int m = tile * NT * 32 + nt * 32 + r;
-            unsigned short* o = p.out + ((size_t)f0 * ohw + min(m, m_wg - 1)) * p.COUT + cbase;
+            unsigned short* o = p.out + (size_t)(obase[nt] < 0 ? 0 : obase[nt]) * p.COUT + cbase;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 uint2 w[4];
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
 #if TRS_FRAME_ABLATE == 3
                 asm volatile("" :: "v"(g0), "v"(g1)); (void)o;
 #else
-                if (m < m_wg) {
+                if (obase[nt] >= 0) {
                     *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;       // channels nb*32 + 16h .. + 7
                     *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;   // ... + 8 .. + 15
                 }
@@ -1265,7 +1272,7 @@ struct ConvLayer {
     bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
     bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
-    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
+    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -1351,7 +1358,8 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.COUT = l.COUT; q.COUT_PAD = l.COUT_PAD; q.KH = l.KH; q.KW = l.KW;
         q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
-        const int grid = (n_img + q.F - 1) / q.F;
+        q.bands = l.frame_bands; q.ohb = l.frame_ohb; q.ihb = l.frame_ohb + l.KH - 1;
+        const int grid = (n_img * q.bands + q.F - 1) / q.F;
 #define LAUNCH_FRAME(HALF_, R_, BLOCK_)                                                                                       \
     do {                                                                                                                      \
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<2, 2, HALF_, R_, BLOCK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
@@ -1614,15 +1622,20 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             int mask = 0x78;                                                  // bit i = conv(i+1)
             if (const char* e = std::getenv("TRS_PILOT_FRAME_LAYERS")) mask = std::atoi(e);
             const int cg = l.CIN / 8;
-            const size_t frame_bytes = (size_t)l.IH * l.IW * l.CIN * 2;
             const bool shape_ok = l.S == 1 && l.KH == 3 && l.KW == 3 && (cg == 8 || cg == 16) && l.COUT_PAD % 64 == 0 && l.COUT == l.COUT_PAD && run_pad == l.KW * cg;
-            if (((mask >> i) & 1) && shape_ok && frame_bytes <= 150 * 1024) {
-                // frames per workgroup: as many as keep two workgroups per CU (<= 78 KB) and at least ~2 workgroups per CU in the grid
-                int f = (int)std::max<size_t>(1, std::min<size_t>(8, (78 * 1024) / frame_bytes));
+            if (((mask >> i) & 1) && shape_ok) {
+                // a frame larger than ~110 KB is cut into row bands (conv7 at 240x320: 21 x 31 x 128 = 167 KB -> 2 bands of 10 / 9 rows)
+                int bands = 1;
+                while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
+                const int ohb = (l.OH + bands - 1) / bands, ihb = ohb + l.KH - 1;
+                const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
+                // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
+                int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
                 if (const char* e = std::getenv("TRS_PILOT_FRAME_F")) f = std::max(1, std::atoi(e));
-                while (f > 1 && (c->n_cap + f - 1) / f < c->cu_count) --f;
+                while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
                 l.frame_deep = std::getenv("TRS_PILOT_FRAME_DEEP") != nullptr;
-                l.frame = true; l.frame_f = f; l.frame_lds = (int)(f * frame_bytes) + l.COUT_PAD * 4;
+                l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
+                l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
             }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
