@@ -1068,6 +1068,20 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     if (i >= p.n) return;
+    // The three small layers are latency chains (100 + 50 + 25 dependent FMAs per lane); what made them slow was a global weight
+    // load in front of every FMA.  All of a lane's weights — column `lane` of each matrix — are requested up front (175 independent
+    // loads, coalesced across lanes) and land while the slab sums run; the FMAs then read registers and LDS only.
+    float wc2[100], wc3[50], wc4[25];
+    {
+        const int o2 = min(lane, 49), o3 = min(lane, 24), o4 = min(lane, 1);
+#pragma unroll
+        for (int k = 0; k < 100; ++k) wc2[k] = p.w2[k * 50 + o2];
+#pragma unroll
+        for (int k = 0; k < 50; ++k) wc3[k] = p.w3[k * 25 + o3];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) wc4[k] = p.w4[k * 2 + o4];
+    }
+    const float bias2 = p.b2[min(lane, 49)], bias3 = p.b3[min(lane, 24)], bias4 = p.b4[min(lane, 1)];
     {   // dense1's 100 outputs of this frame = the K-slice slabs added in slice order (fixed order: run-to-run identical).  A lane
         // owns outputs `lane` and `lane + 64`; the phase is pure load latency, so 16 slices x 2 outputs are requested together.
         const bool two = lane + 64 < 100;
@@ -1094,11 +1108,26 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
         if (two) s1[wv][lane + 64] = x1 > 0.f ? x1 : 0.f;
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < 50) { float s = p.b2[lane]; for (int k = 0; k < 100; ++k) s = fmaf(s1[wv][k], p.w2[k * 50 + lane], s); s2[wv][lane] = s > 0.f ? s : 0.f; }
+    if (lane < 50) {
+        float s = bias2;
+#pragma unroll
+        for (int k = 0; k < 100; ++k) s = fmaf(s1[wv][k], wc2[k], s);
+        s2[wv][lane] = s > 0.f ? s : 0.f;
+    }
     __builtin_amdgcn_wave_barrier();
-    if (lane < 25) { float s = p.b3[lane]; for (int k = 0; k < 50; ++k) s = fmaf(s2[wv][k], p.w3[k * 25 + lane], s); s3[wv][lane] = s > 0.f ? s : 0.f; }
+    if (lane < 25) {
+        float s = bias3;
+#pragma unroll
+        for (int k = 0; k < 50; ++k) s = fmaf(s2[wv][k], wc3[k], s);
+        s3[wv][lane] = s > 0.f ? s : 0.f;
+    }
     __builtin_amdgcn_wave_barrier();
-    if (lane < 2) { float s = p.b4[lane]; for (int k = 0; k < 25; ++k) s = fmaf(s3[wv][k], p.w4[k * 2 + lane], s); s4[wv][lane] = s; }
+    if (lane < 2) {
+        float s = bias4;
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s = fmaf(s3[wv][k], wc4[k], s);
+        s4[wv][lane] = s;
+    }
     __builtin_amdgcn_wave_barrier();
     if (lane != 0) return;
     const float out[2] = {s4[wv][0], s4[wv][1]};
