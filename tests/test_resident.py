@@ -187,3 +187,20 @@ def test_resident_after_reloading_the_track(make_env):
         env.step_synthetic(10, 1)
     assert_state_equal(g, o, "after a track reload")
     assert_frames_equal(g, o, "after a track reload")
+
+
+def test_pilot_loop_with_resident_mode_selected(make_env):
+    """trs_step_pilot steps by launch whatever the mode (its convolutions need the CUs' LDS a worker would hold): the same loop,
+    with resident steps before and after it."""
+    from test_pilot import make_weights
+    n = 24
+    ws = make_weights(120, 160, seed=31)
+    a, b = make_env("hip", n_envs=n), make_env("hip", n_envs=n)
+    a.pilot_load(ws); b.pilot_load(ws)
+    a.set_step_mode(True)
+    for env in (a, b):
+        env.step_synthetic(3, 1)                                     # a: posted to the worker; b: launches
+        env.step_pilot(4)
+        env.step_synthetic(2, 1)
+    for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img", "ep_return"):
+        assert np.array_equal(a.fetch(name), b.fetch(name)), name

@@ -73,5 +73,6 @@ int sync_handle(trs_env* e);                               // the handle's strea
 int quiesce_handle(trs_env* e);                            // a resident worker has left; queued work may still be running
 void comm_destroy(trs_env* e);
 bool resident_running(const trs_env* e);
+void resident_clear_fault(trs_env* e);                     // trs_load_track puts every env on a defined state again
 int check_fault(trs_env* e);                               // TRS_ERR_DEVICE (sticky) once a kernel has reported a layout fault
 }  // namespace trsim

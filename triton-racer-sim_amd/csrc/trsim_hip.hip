@@ -1247,6 +1247,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemset(e->stats, 0, 64 * sizeof(unsigned long long)));
     e->step_count = 0;
     e->track_loaded = true;
+    trsim::resident_clear_fault(e);
     if (e->has_frame_filter && e->filter_dynamic && e->max_steps_dyn < 1) {
         e->has_frame_filter = false; e->filter_dynamic = false;
         (void)upload_palette(e);
@@ -1974,6 +1975,14 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
 void trs_internal_count(trs_env* e, uint64_t d2h, uint64_t h2d) { if (e) { e->d2h_bytes += d2h; e->h2d_bytes += h2d; } }
+// one env step by LAUNCH whatever the handle's step mode: the pilot loop's kernels need the CUs' LDS, which a resident worker
+// would hold, and its controls are produced on the handle's stream right in front of the step
+int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, const float* d_br)
+{
+    if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
+    { int rq = quiesce(e); if (rq) return rq; }
+    return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1) : run_physics_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1);
+}
 int trsim::sync_handle(trs_env* e) { return sync_all(e); }
 int trsim::quiesce_handle(trs_env* e) { return quiesce(e); }
 int trsim::check_fault(trs_env* e)

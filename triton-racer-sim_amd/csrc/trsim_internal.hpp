@@ -20,5 +20,6 @@ struct TrsEnvView {
 bool trs_internal_view(trs_env* e, TrsEnvView* out);
 void** trs_internal_pilot_slot(trs_env* e);
 int trs_internal_fail(int code, const std::string& msg);
+int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, const float* d_br);   // one env step by launch, whatever the step mode
 void trs_internal_count(trs_env* e, uint64_t d2h_bytes, uint64_t h2d_bytes);   // trs_counters bookkeeping for copies made outside trsim_hip.hip
 void trs_pilot_free(void* ctx);       // defined in trsim_pilot.hip, called by trs_destroy

@@ -971,6 +971,13 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         if (wt + (int)gridDim.x < total) request(wt + gridDim.x, raw);      // the second item's band is on its way
     }
     __syncthreads();
+    // conv1's weights are the same for every tile of every band: this lane's six granules stay in registers (they were 6 of the
+    // 11 LDS reads of a conv1 tile, in a phase that is bound by LDS bandwidth: 11 KB per 6 MFMAs and wave)
+    u4v wv[6];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
     while (wt < total) {
         const int nxt = wt + gridDim.x;                                     // uniform per workgroup
         int n, y2_0, r2, r1;
@@ -986,14 +993,12 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            u4v xv[5], wv[6];                                               // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
+            u4v xv[5];                                                      // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
 #pragma unroll
             for (int s6 = 0; s6 < 5; ++s6) {
                 const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (size_t)s6 * row_in * 2);
                 xv[s6] = u4v{src[0], src[1], src[2], src[3]};
             }
-#pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
             __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
 #pragma unroll
             for (int s6 = 0; s6 < 6; ++s6)                                  // k-step 5 is padding (zero weights): any finite operand
@@ -1954,7 +1959,7 @@ TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_ste
             hipLaunchKernelGGL(trs_zero_controls_kernel, dim3((v.n + 255) / 256), dim3(256), 0, v.stream, v.ctl_steer, v.ctl_thr, v.ctl_brk, v.n);
             HIPCHK(hipGetLastError());
         }
-        int rc = trs_step(e, v.ctl_steer, v.ctl_thr, v.ctl_brk, nullptr, 1);
+        int rc = trs_internal_step_launch(e, v.ctl_steer, v.ctl_thr, v.ctl_brk);
         if (rc) return rc;
     }
     return TRS_OK;

@@ -86,6 +86,8 @@ struct WParams {
 
 struct Resident {
     bool enabled = false, running = false;
+    bool broken = false;                 // a worker gave up (bounded wait): some workgroups may have taken a step others did not — the env
+                                         // state is undefined until the track is loaded again; every resident call fails meanwhile
     Mailbox* mb = nullptr;
     DevCtl* dc = nullptr;
     hipStream_t sC = nullptr;            // copies while the worker owns the handle's stream
@@ -572,6 +574,7 @@ int worker_error(trs_env* e)
 {
     const uint64_t err = host_load(&e->res->mb->error);
     if (!err) return TRS_OK;
+    e->res->broken = true;
     static const char* const what[] = {"", "waiting for a post", "camera ring back-pressure", "waiting for the physics team", "", "", "", "", "",
                                        "dynamic LDS segment not at offset 0"};
     const unsigned code = (unsigned)(err >> 32);
@@ -636,11 +639,13 @@ namespace trsim {
 
 bool resident_on(const trs_env* e) { return e && e->res && e->res->enabled; }
 bool resident_running(const trs_env* e) { return e && e->res && e->res->running; }
+void resident_clear_fault(trs_env* e) { if (e && e->res) e->res->broken = false; }
 
 int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride)
 {
     Resident* R = e->res;
     Mailbox* mb = R->mb;
+    if (R->broken) return trs_internal_fail(TRS_ERR_DEVICE, "a resident worker gave up earlier: the env state is undefined, load the track again (trs_load_track)");
     for (int k = 0; k < n; ++k) {
         const uint64_t s = e->step_count;
         if (!R->running) R->base = R->seen_done = s;           // no worker: nothing is in flight (the step counter may have moved or restarted since)
