@@ -278,9 +278,11 @@ def test_closed_loop_is_unaffected_by_another_stream(make_env):
 
 
 @pytest.mark.parametrize("size", [(120, 160), (240, 320), (100, 132)])
-def test_fused_head_is_bit_identical_to_the_two_layers(make_env, size, monkeypatch):
-    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels: the same bf16 values go
-    into the same MFMA order, so conv2's output and everything after it are bit-identical."""
+def test_fused_head_equals_the_two_layers(make_env, size, monkeypatch):
+    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels.  The direct form (240x320) feeds
+    the same bf16 values into the same MFMA order: bit-identical.  The band form (120x160) keeps the conv1 tile split by column
+    parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another summation order, so
+    an output can land on the neighbouring bf16 value — at most one ulp (2^-7 relative), on a small fraction of the elements."""
     h, w = size
     n = 21
     ws = make_weights(h, w, seed=3)
@@ -295,5 +297,11 @@ def test_fused_head_is_bit_identical_to_the_two_layers(make_env, size, monkeypat
     monkeypatch.setenv("TRS_PILOT_NO_FUSE", "1")
     plain_out = env.pilot_forward_host(frames)
     plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
-    assert np.array_equal(fused_l1, plain_l1)
-    assert np.array_equal(fused_out, plain_out)
+    if (h, w) == (240, 320):
+        assert np.array_equal(fused_l1, plain_l1)
+        assert np.array_equal(fused_out, plain_out)
+    else:
+        diff = np.abs(fused_l1 - plain_l1)
+        assert (diff <= 2.0 ** -7 * np.abs(plain_l1) + 1e-3).all(), float(diff.max())
+        assert np.mean(diff > 0) < 0.02, float(np.mean(diff > 0))
+        assert np.max(np.abs(fused_out - plain_out)) <= 2e-2

@@ -262,12 +262,10 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const unsigned abs_step = sp.step_base + (unsigned)sidx;                  // sidx = -1: the step before this launch
     uint8_t* const img = (abs_step & 1u) ? sp.img1 : sp.img0;
     float* const dep = (abs_step & 1u) ? sp.dep1 : sp.dep0;
-    // rows with four equal class colours need no map lookup and no pose: every env's are written FIRST, so that in a
-    // single-step call (the raster team waits for this step's poses) 41 % of the frame bytes of ALL the workgroup's envs are
-    // on their way to HBM while the physics team integrates — env by env the team stalled behind the first env's pose with
-    // one env's uniform rows in flight
-    if constexpr (!DYN)
-        for (int e = e_begin; e < e_end; ++e) raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e));
+    // (Writing the uniform rows of ALL the workgroup's envs first — so that more bytes are in flight while a single-step call
+    // waits for its poses — was measured in round 2: the single-step call did not get shorter (16.7 us both ways) and the
+    // pipelined launch got 6 % LONGER (13.5 -> 14.4 us at 1024 envs: the frames are then written in two sweeps over all envs
+    // instead of one contiguous 57.6 KB stream per env).  Env by env it is.)
     for (int e = e_begin; e < e_end; ++e) {
         if constexpr (DYN) {
             // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
@@ -428,8 +426,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
             }
             continue;
         }
+        // rows with four equal class colours need no map lookup and no pose: they are written first, and in a single-step
+        // call while the physics team still integrates
         const FrameDesc fd = frame_desc<DEPTH>(p, img, dep, e);
-        // -- rows that see the track (the rows that need no pose were written above, for every env of the workgroup)
+        raster_uniform_rows<DEPTH>(p, rth, fd);
+        // -- rows that see the track
         float4 cam;
         const int j = e - e_begin;
         if (sidx < 0) {

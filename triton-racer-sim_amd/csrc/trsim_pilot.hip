@@ -911,7 +911,14 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     u4v* lw2 = reinterpret_cast<u4v*>(psmem + q.off_w2);                   // [80][32]
     float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
     float4* lb2 = lb1 + 8;                                                 // [8]
-    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] bf16 (+ padding)
+    // conv1 tile in LDS: [r1 rows][2 planes: even / odd conv1 columns][plane_px][24] bf16.  conv2 (stride 2) reads, per output
+    // pixel x2 and kernel row, the conv1 columns 2 x2 .. 2 x2 + 4: with the columns interleaved the 16 lanes of a ds_read_b128
+    // group sit 96 bytes apart — an EVEN number of 16-byte slots, so only 8 of the 16 bank groups are hit (2-way conflict on
+    // every fragment read, and no padding changes the parity).  Split by column parity, consecutive x2 are 48 bytes = 3 slots
+    // apart (odd: all 16 bank groups), and a window is two runs: even columns (3 pixels = 9 slots) then odd (2 pixels = 6
+    // slots) — conv2's granules are packed in that order for this kernel (w2 = the handle's parity-ordered copy).
+    unsigned char* tile1 = psmem + q.off_tile;
+    const int plane_px = (q.OW1 + 1) >> 1, plane_bytes = plane_px * 48, tile_pitch = 2 * plane_bytes;
     unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] bf16 (+ padding)
     u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + (wave & 7) * 128;   // conv2's output transpose: waves 0..7 only
     for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
@@ -1004,7 +1011,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             for (int s6 = 0; s6 < 6; ++s6)                                  // k-step 5 is padding (zero weights): any finite operand
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[min(s6, 4)]), acc, 0, 0, 0);
             if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
-                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)pp * 48);
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)yl * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = lb1[2 * qd + h];
@@ -1026,19 +1033,24 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
             const int m0 = (n * q.OH2 + y2_0) * q.OW2;                      // first output pixel of the band (consecutive in memory)
 #if TRS_FUSE_ABLATE != 2
+            // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us.  The
+            // phase wants MORE waves with work, not fewer LDS reads.)
             for (int t2 = wave; t2 < ntile2; t2 += 8) {
                 const int mm = min(t2 * 32 + r, npx2 - 1);
                 int yl2, x2;
                 divmod(mm, q.OW2, inv_ow2, yl2, x2);
-                const unsigned char* abase = tile1 + (size_t)((2 * yl2) * q.OW1 + 2 * x2) * 48 + h * 16;
+                const unsigned char* abase = tile1 + (size_t)(2 * yl2) * tile_pitch + (size_t)x2 * 48;   // even plane, conv1 row 2 yl2, pixel x2
                 f32x16 acc2[1];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
                 for (int kh = 0; kh < 5; ++kh) {
-                    const unsigned char* arow = abase + (size_t)kh * q.OW1 * 48;
+                    const unsigned char* arow = abase + (size_t)kh * tile_pitch;
 #pragma unroll
                     for (int t = 0; t < 16; t += 2) {
-                        const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
+                        // slot t + h of the window: 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero weights: the odd run's next 16 bytes)
+                        const int slot = t + h;
+                        const unsigned char* src = slot < 9 ? arow + slot * 16 : arow + plane_bytes + (slot - 9) * 16;
+                        const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(src));
                         const bf16x8 w = __builtin_bit_cast(bf16x8, lw2[(kh * 16 + t + h) * 32 + r]);
                         acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
                     }
@@ -1329,6 +1341,7 @@ struct PilotCtx {
     bool fuse12 = false, fuse_band = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
+    u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
 };
 
 unsigned short host_f2bf(float f)
@@ -1344,7 +1357,7 @@ void free_ctx(PilotCtx* c)
     for (auto& l : c->L) { (void)hipFree(l.w); (void)hipFree(l.bias); (void)hipFree(l.goff); }
     for (auto& a : c->act) (void)hipFree(a);
     (void)hipFree(c->w2); (void)hipFree(c->b2); (void)hipFree(c->w3); (void)hipFree(c->b3); (void)hipFree(c->w4); (void)hipFree(c->b4);
-    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab); (void)hipFree(c->slab2); (void)hipFree(c->xblob);
+    (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab); (void)hipFree(c->slab2); (void)hipFree(c->xblob); (void)hipFree(c->w2_parity);
     delete c;
 }
 
@@ -1760,7 +1773,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             q.off_w2 = off; off += 80 * 32 * 16;
             q.off_b = off; off += 16 * 16;
             q.off_goff = off; off += 64;
-            q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * l0.OW * 48 + 64) + 15) & ~15; off += q.tile_bytes;
+            q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * ((l0.OW + 1) / 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;   // two column-parity planes per row
             q.off_band = off; q.band_bytes = rows_in * row_in * 2 + 64; off += q.band_bytes;
             q.off_stage = off; off += 8 * 2048;
             if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
@@ -1774,6 +1787,19 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             q.off_stage = off; off += 16 * 2048;
             if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
         }
+    }
+    if (c->fuse12 && c->fuse_band) {           // the band kernel reads conv1 columns by parity: conv2's granules in that order
+        const ConvLayer& l1 = c->L[1];
+        std::vector<u4v> orig((size_t)l1.G_pad * l1.COUT_PAD), perm(orig.size());
+        HIPCHK(hipMemcpy(orig.data(), l1.w, orig.size() * sizeof(u4v), hipMemcpyDeviceToHost));
+        for (int kh = 0; kh < 5; ++kh)
+            for (int sl = 0; sl < 16; ++sl) {
+                const int src = sl < 9 ? (2 * (sl / 3)) * 3 + sl % 3 : (sl < 15 ? (2 * ((sl - 9) / 3) + 1) * 3 + (sl - 9) % 3 : 15);   // granule kw * 3 + c8 of the kernel row
+                std::memcpy(&perm[(size_t)(kh * 16 + sl) * l1.COUT_PAD], &orig[(size_t)(kh * 16 + src) * l1.COUT_PAD], (size_t)l1.COUT_PAD * sizeof(u4v));
+            }
+        int rcw = upload(&c->w2_parity, perm);
+        if (rcw) return rcw;
+        c->fuse.w2 = c->w2_parity;
     }
     HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
     for (const ConvLayer& l : c->L) {

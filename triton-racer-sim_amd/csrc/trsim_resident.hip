@@ -82,6 +82,7 @@ struct WParams {
     unsigned long long start;                               // first step index this launch processes
     unsigned long long idle_ticks, life_ticks, safety_ticks;   // wall_clock64() ticks (100 MHz)
     int lds_off_phys, lds_off_ctl, n_blocks;
+    int diag;                                               // diagnostics (env TRS_RESIDENT_DIAG, never set by the product): 1 = arrive without the counted wait, 2 = no telemetry stores
 };
 
 struct Resident {
@@ -476,30 +477,52 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     }
     Duties none{false, false, 0};
     u64 owed = wp.start;                                      // oldest step this wave has not arrived for
+    // diagnostics (diag bit 4): where one raster wave (workgroup 7, wave 0) spends its clocks, into stats[40..45]
+    const bool probe = (wp.diag & 4) && blockIdx.x == 7 && wave == 0;
+    auto now_clk = [&]() -> u64 { u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
+    u64 t_post = 0, t_pose = 0, t_vm = 0, t_all = 0, t_mark = probe ? now_clk() : 0;
     for (u64 s = wp.start;; ++s) {
         const int r = (int)(s - wp.start);
         if (owed < s && (lds_load64(l.word) & kCountMask) <= s) {   // nothing further posted: do not make the host wait
             drain_vmem();
             for (; owed < s; ++owed) raster_arrive(l, owed, lane);
         }
+        const u64 tp0 = probe ? now_clk() : 0;
         if (!wait_posted(wp, l, none, s, lane)) {
             drain_vmem();
             for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+            if (probe && lane == 0) {
+                t_all = now_clk() - t_mark;
+                atomicAdd(&p.stats[40], t_post); atomicAdd(&p.stats[41], t_pose); atomicAdd(&p.stats[42], t_vm); atomicAdd(&p.stats[43], t_all);
+                atomicAdd(&p.stats[44], (u64)r);
+            }
             return;
         }
+        if (probe) t_post += now_clk() - tp0;
         uint8_t* const img = (s & 1ull) ? wp.img1 : wp.img0;
         float* const dep = (s & 1ull) ? wp.dep1 : wp.dep0;
-        for (int j = 0; j < n_loc; ++j)                      // rows that need no pose: every env's first, while the physics team integrates
-            raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j));
-        // the lag shrinks with the queue: with only `ahead` steps posted beyond this one the consumer is waiting for frames
+        // Order of the rows.  With more steps queued behind this one the physics team is ahead and nothing waits for a pose: the
+        // frame of an env is written as ONE contiguous stream (its uniform rows, then its ground rows), env by env — two sweeps
+        // over all envs cost 6 % of the HBM rate.  With nothing queued (a lock-step consumer is waiting for this very frame) the
+        // uniform rows of ALL envs go first: they need no pose and are on their way while the physics team integrates.
         const u64 ahead = (lds_load64(l.word) & kCountMask) - 1 - s;
-        const u64 keep = ahead + 1 < (u64)lag ? ahead + 1 : (u64)lag;
-        while (s - owed >= keep) {
-            wait_vmcnt_le((int)(s - owed - 1) * nstep + nuni);
-            raster_arrive(l, owed++, lane);
-        }
+        const u64 keep = ahead + 1 < (u64)lag ? ahead + 1 : (u64)lag;       // the lag shrinks with the queue: a consumer that waits gets its flag early
+        const bool sweep = ahead == 0;
+        if (sweep)
+            for (int j = 0; j < n_loc; ++j) raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j));
         for (int j = 0; j < n_loc; ++j) {
+            const FrameDesc fd = frame_desc<DEPTH>(p, img, dep, e_begin + j);
+            if (!sweep) raster_uniform_rows<DEPTH>(p, rth, fd);
+            if (j == 0)                                       // arrivals owed: everything this wave has issued since the end of step `owed`
+                while (s - owed >= keep) {                    // is (s - owed - 1) whole steps + this step's uniform rows so far
+                    const u64 tv0 = probe ? now_clk() : 0;
+                    if (!(wp.diag & 1)) wait_vmcnt_le((int)(s - owed - 1) * nstep + (sweep ? nuni : nu));
+                    if (probe) t_vm += now_clk() - tv0;
+                    raster_arrive(l, owed++, lane);
+                }
+            const u64 tq0 = probe ? now_clk() : 0;
             if (!wait_lds_ge(wp, l, nullptr, &l.pprog[j], r + 1, 3u, lane)) return;
+            if (probe) t_pose += now_clk() - tq0;
             const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
             const float4 cam = *reinterpret_cast<const float4*>(sl);
             const bool mine = (j % (kRasterThreads / 64)) == wave;
@@ -507,8 +530,8 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             if (mine) tel = __float_as_uint(sl[4 + min(lane, 12)]);      // lanes 0..11 their word, lane 12 `done`
             asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel) : "memory");
             if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            raster_ground_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j), cam);
-            if (mine) {                                       // the step's telemetry of env j: two wave instructions, written through
+            raster_ground_rows<DEPTH>(p, rth, fd, cam);
+            if (mine && !(wp.diag & 2)) {                     // the step's telemetry of env j: two wave instructions, written through
                 const size_t e = (size_t)(e_begin + j);
                 if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -554,6 +577,7 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.start = start;
     wp.idle_ticks = (unsigned long long)R->idle_us * 100ull;
     wp.life_ticks = 50000000ull;                            // 0.5 s: then the dispatcher leaves and the host starts a new worker at its next post
+    if (const char* dg = std::getenv("TRS_RESIDENT_DIAG")) wp.diag = std::atoi(dg);
     if (const char* lf = std::getenv("TRS_RESIDENT_LIFE_US")) {   // tests: force many worker generations in a short run
         const long v = std::atol(lf);
         if (v > 0) wp.life_ticks = (unsigned long long)v * 100ull;
