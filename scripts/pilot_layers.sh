@@ -9,24 +9,25 @@ echo "== $tag $*"
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("gpurun_out/prof_pl_$tag/**/*kernel_trace.csv",recursive=True)[0]
-rows=[r for r in csv.DictReader(open(f)) if "trs_conv" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"]]
+rows=[r for r in csv.DictReader(open(f)) if "trs_conv" in r["Kernel_Name"] or "tail" in r["Kernel_Name"] or "trs_step" in r["Kernel_Name"] or "trs_pilot_dense" in r["Kernel_Name"]]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-steps=len([r for r in rows if "tail" in r["Kernel_Name"]])
-# position of a launch inside its step identifies the layer
+# a step = the pilot's launches between two env steps
 seq=[]; cur=[]
 for r in rows:
-    cur.append(r)
-    if "tail" in r["Kernel_Name"]:
+    if "trs_step" in r["Kernel_Name"] and cur:
         seq.append(cur); cur=[]
+    cur.append(r)
 seq=[s for s in seq if len(s)==len(seq[-1])]
-names=["env step","conv1","conv2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
-fused=["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense1","tail"]
+layouts={10:["env step","conv1","conv2","conv3","conv4","conv5","conv6","conv7","dense1","tail"],
+         9:["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense1","tail"],
+         8:["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense+tail"]}
+names=fused=layouts.get(len(seq[-1]),[str(i) for i in range(len(seq[-1]))])
 tot=0
 for j in range(len(seq[-1])):
     d=[int(s[j]["End_Timestamp"])-int(s[j]["Start_Timestamp"]) for s in seq]
     r=seq[-1][j]
     kn=r["Kernel_Name"]
-    kind="fused" if "conv12" in kn else "frame" if "conv_frame" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
+    kind="fused" if "conv12" in kn else "dense" if "pilot_dense" in kn else "frame" if "conv_frame" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
     nm=names[j] if len(seq[-1])==len(names) else (fused[j] if len(seq[-1])==len(fused) else str(j))
     tot+=sum(d)/len(d)
     print(f"  {nm:9s} {kind:8s} grid={r['Grid_Size_X']:>8s}x{r['Grid_Size_Y']} wg={r['Workgroup_Size_X']:>4s} lds={r.get('LDS_Block_Size','?'):>7s}  mean {sum(d)/len(d)/1e3:8.1f} us")

@@ -295,6 +295,7 @@ def test_fused_head_equals_the_two_layers(make_env, size, monkeypatch):
     fused_out = env.pilot_forward_host(frames)
     fused_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
     monkeypatch.setenv("TRS_PILOT_NO_FUSE", "1")
+    env.pilot_load(ws)                                                # the switch is read when the weights are loaded
     plain_out = env.pilot_forward_host(frames)
     plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
     if (h, w) == (240, 320):
@@ -305,3 +306,60 @@ def test_fused_head_equals_the_two_layers(make_env, size, monkeypatch):
         assert (diff <= 2.0 ** -7 * np.abs(plain_l1) + 1e-3).all(), float(diff.max())
         assert np.mean(diff > 0) < 0.02, float(np.mean(diff > 0))
         assert np.max(np.abs(fused_out - plain_out)) <= 2e-2
+
+
+@pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5)])
+def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch):
+    """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution
+    kernel (TRS_PILOT_DENSE = 0): the same bf16 products, K split differently — fp32 summation order only.  n is not a multiple
+    of 32 (ragged last frame group) and spans several groups; 240x320 needs several LDS chunks per slice and a ragged last one."""
+    h, w = size
+    ws = make_weights(h, w, seed=5)
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    outs, h1s, l6 = {}, {}, {}
+    oh, ow = h, w
+    for k, s_, _, _ in SPEC:
+        oh, ow = (oh - k) // s_ + 1, (ow - k) // s_ + 1
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TRS_PILOT_DENSE", mode)
+        env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_load(ws)
+        for rep in range(2):
+            outs[mode] = env.pilot_forward_host(frames)
+        h1s[mode] = env.pilot_layer(7, (n, 100))
+        l6[mode] = env.pilot_layer(6, (n, oh, ow, 128))
+    assert np.array_equal(l6["0"], l6["1"])
+    want = torch_layer(7, l6["1"], ws)                                # fp32 dense1 on the kernel's own conv7 activation
+    assert np.max(np.abs(h1s["1"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
+    assert np.max(np.abs(h1s["0"] - h1s["1"])) <= 1e-3 * max(1.0, float(np.abs(h1s["0"]).max()))
+    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-4
+    assert np.std(outs["1"][:, 0]) > 1e-5
+
+
+@pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 6)])
+@pytest.mark.parametrize("layers", ["4", "3"])
+def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, layers, monkeypatch):
+    """conv4..conv7 (or conv5..conv7) in one launch with the activations in LDS (trs_conv_chain_kernel) against one launch per
+    layer (TRS_PILOT_CHAIN = 0): the same MFMA order on the same bf16 values, so every activation — the interior ones are
+    recomputed by the debug getter — and the outputs agree bit for bit.  37 frames: 2 frames per workgroup, odd tail; 1027: 4 per
+    workgroup with a ragged last one (3 frames: the second conv4 pass has one frame); 240x320 does not fit LDS: no chain."""
+    h, w = size
+    ws = make_weights(h, w, seed=9)
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    shapes, (ih, iw) = [], (h, w)
+    for k, s_, _, cout in SPEC:
+        ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
+        shapes.append((n, ih, iw, cout))
+    res = {}
+    for mode in ("0", layers):
+        monkeypatch.setenv("TRS_PILOT_CHAIN", mode)
+        env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_load(ws)
+        out = env.pilot_forward_host(frames)
+        out = env.pilot_forward_host(frames)
+        res[mode] = [out] + [env.pilot_layer(i, shapes[i]) for i in (6, 5, 4, 3, 2)]
+    for a, b in zip(res["0"], res[layers]):
+        assert np.array_equal(a, b)
+    assert np.std(res[layers][0][:, 0]) > 1e-5

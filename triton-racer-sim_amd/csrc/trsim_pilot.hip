@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <memory>
 #include <vector>
 
@@ -660,6 +661,180 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
     }
 }
 
+// ---- conv4 .. conv7 in ONE launch: a frame's activations never leave LDS (round 2) ---------------------------------------------
+// The time line of a workgroup of this loop (profiles/r02_pilot_dense.txt) shows ~3 us from dispatch to the first data in LDS and
+// ~2.3 us from the last store to the end of the launch; the four 3x3 layers paid that four times over for 4-10 us of work each,
+// plus a global round trip of every activation.  At 120x160 the four layers of F = 4 frames fit LDS together:
+//   region A (76.8 KB): conv4's output -> (conv5 reads) -> conv6's output -> (conv7 reads)
+//   region B (53.2 KB): conv4's input, two frames at a time -> conv5's output -> (conv6 reads)
+// conv4 runs in two passes of two frames (its input is the largest tensor of the chain: 26 KB per frame); conv7 stores to global.
+// A layer is trs_conv_frame_kernel's item loop unchanged (2 x 32 pixels x 2 x 32 channels per wave, weights straight from L2
+// through a register ring, the K loop one basic block); its epilogue writes the next layer's LDS image — 16-byte granules in the
+// same XOR-swizzled slots the staging DMA would have produced.  Layers are separated by a workgroup barrier only.
+struct ChainLayer {
+    const u4v* w; const float* bias;
+    int IH, IW, OH, OW, COUT, cg, cgs;     // COUT == COUT_PAD (64 / 128); cg = input granules per pixel (8 / 16), cgs = log2
+};
+struct ChainParams {
+    const u4v* in;             // the first layer's input activation, bf16 NHWC
+    unsigned short* out;       // the last layer's output activation
+    int N, F, nl, split_first; // frames, frames per workgroup, layers (3 = conv5..7, 4 = conv4..7), first layer in two passes of F / 2 frames
+    int offA, offB, off_bias;  // LDS byte offsets
+    ChainLayer L[4];           // every layer but the last reads 64 channels (HALF = 4), the last 128 (HALF = 8)
+};
+
+template <int HALF, int R>
+__device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
+                                            unsigned short* gout, int wave, int nwaves, int lane)
+{
+    constexpr int NT = 2, NB = 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int uout = L.OH * L.OW, m_wg = nu * uout;
+    const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = L.COUT / (NB * 32);
+    const float4* lbias = reinterpret_cast<const float4*>(lbias_f);
+    constexpr int ksteps = 9 * HALF;
+    for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
+        const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
+        const int cbase = cgrp * NB * 32;
+        int lbase[NT], mo[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
+            const int ul = mc / uout, rem = mc - ul * uout, oy = rem / L.OW, ox = rem - oy * L.OW;
+            lbase[nt] = (ul * L.IH + oy) * L.IW + ox;
+            mo[nt] = m < m_wg ? m : -1;
+        }
+        const u4v* wl = L.w + cbase + r;
+        u4v ring[R][NB];
+#pragma unroll
+        for (int d = 0; d < R; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * L.COUT + nb * 32];
+        const u4v* wnext = wl + (size_t)(2 * R + h) * L.COUT;
+        f32x16 acc[NT][NB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        auto pixels = [&](int k, bf16x8 (&x)[NT]) {
+            const int tap = k / HALF, g = 2 * (k % HALF) + h;
+            const int tap_off = (tap / 3) * L.IW + tap % 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pix = lbase[nt] + tap_off;
+                x[nt] = __builtin_bit_cast(bf16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+            }
+        };
+        bf16x8 xa[NT], xb[NT];
+        pixels(0, xa);
+#pragma unroll
+        for (int k = 0; k < ksteps; ++k) {
+            const int d = k % R;
+            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            if (k + 1 < ksteps) pixels(k + 1, xn);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+            if (k + R < ksteps) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
+                wnext += 2 * L.COUT;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                uint2 w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
+                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane keeps (see trs_conv_frame_kernel)
+                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
+                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
+                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};   // channels cbase + nb*32 + 16h .. + 7
+                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};   // ... + 8 .. + 15
+                if (mo[nt] >= 0) {
+                    if (lout) {                                               // the next layer's image: pixel slot, granule ^ swizzle
+                        const int po = out_pix0 + mo[nt], q0 = (cbase + nb * 32 + 16 * h) >> 3, sw = frame_swz(po, cgs_out);
+                        lout[(po << cgs_out) + (q0 ^ sw)] = g0;
+                        lout[(po << cgs_out) + ((q0 + 1) ^ sw)] = g1;
+                    } else {
+                        unsigned short* o = gout + (size_t)mo[nt] * L.COUT + cbase + nb * 32 + 16 * h;
+                        *reinterpret_cast<u4v*>(o) = g0;
+                        *reinterpret_cast<u4v*>(o + 8) = g1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nwaves = BLOCK / 64;
+    const int u0 = blockIdx.x * p.F, nu = min(p.F, p.N - u0);
+    float* const lb = reinterpret_cast<float*>(psmem + p.off_bias);         // [layer][128]
+    for (int li = 0; li < p.nl; ++li)
+        for (int i = tid; i < p.L[li].COUT; i += BLOCK) lb[li * 128 + i] = p.L[li].bias[i];
+    u4v* const A = reinterpret_cast<u4v*>(psmem + p.offA);
+    u4v* const B = reinterpret_cast<u4v*>(psmem + p.offB);
+    const unsigned lds0 = (unsigned)(uintptr_t)psmem;
+    auto stage = [&](const ChainLayer& L, int fa, int cnt, unsigned lds_byte) {   // frames fa .. fa + cnt - 1 of L's input, whole and contiguous
+        const int upix = L.IH * L.IW, total = (cnt * upix) << L.cgs;
+        const u4v* src = p.in + ((size_t)fa * upix << L.cgs);
+        for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
+            const int sl = s0 + lane;
+            if (sl < total) {
+                const int pix = sl >> L.cgs, q = sl & (L.cg - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (pix << L.cgs) + (q ^ frame_swz(pix, L.cgs))),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_byte + s0 * 16), 16, 0, 0);
+            }
+        }
+    };
+    int li = 0;
+    const u4v* cur = A;
+    if (p.split_first) {
+        const ChainLayer& L0 = p.L[0];
+        const int per = p.F / 2;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int cnt = min(per, nu - per * pass);                      // workgroup-uniform
+            if (cnt > 0) stage(L0, u0 + per * pass, cnt, lds0 + p.offB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (cnt > 0) chain_layer<4, 4>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+            __syncthreads();
+        }
+        li = 1;
+    } else {
+        stage(p.L[0], u0, nu, lds0 + p.offA);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (; li < p.nl - 1; ++li) {
+        const ChainLayer& L = p.L[li];
+        u4v* const nxt = cur == A ? B : A;
+        chain_layer<4, 4>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        __syncthreads();
+        cur = nxt;
+    }
+    {
+        const ChainLayer& L = p.L[p.nl - 1];
+        chain_layer<8, 4>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
+    }
+}
+
 // conv2 / conv3 (stride-2 5x5): overlapping windows make the kernel above fetch every input byte ~2.5x, and the texture
 // addresser (about one lookup per clock) is what bounds these layers.  Here a wave stages, per kernel row, the CONTIGUOUS
 // input span its 32-pixel tile needs (a tile crosses output rows, so the span is 1..4 segments, one per output row touched)
@@ -1078,6 +1253,33 @@ struct TailParams {
     int use_break, smooth, direct;   // direct: ModelType.CNN_2D (outputs are steering and throttle)
 };
 
+// raw outputs -> KerasPilot.step's controls for one frame (keras_pilot.py:78-95; ModelType.CNN_2D: :56-62)
+__device__ __forceinline__ void tail_finish(const TailParams& p, int i, float out0, float out1)
+{
+    if (p.raw_out) { p.raw_out[2 * i] = out0; p.raw_out[2 * i + 1] = out1; }
+    if (!p.act) return;
+    if (p.mode && p.mode[i] != TRS_MODE_AI && p.mode[i] != TRS_MODE_AI_STEERING) { p.steer[i] = 0.0f; p.thr[i] = 0.0f; p.brk[i] = 0.0f; return; }
+    float steering = out0 < -1.0f ? -1.0f : (out0 > 1.0f ? 1.0f : out0);           // __cap (keras_pilot.py:142-145)
+    const float predicted = out1 * 20.0f;                                           // :83
+    const float real = p.speed[i];
+    const float kHalfPi = 1.57079632679489661923f;
+    float delta = predicted * p.threshold - real;                                   // calcThrottle (mapping.py:23-28)
+    float throttle = p.rev_mult * atanf(delta * 2.0f) / kHalfPi;
+    if (throttle > -0.2f && throttle < 0.0f) throttle = 0.0f;
+    float breaking = 0.0f;
+    if (p.direct) throttle = out1 < -1.0f ? -1.0f : (out1 > 1.0f ? 1.0f : out1);    // ModelType.CNN_2D: __cap of both outputs (:60)
+    else if (p.use_break) {                                                         // keras_pilot.py:88-90, mapping.py:30-35
+        throttle = (predicted - real > 0.0f) ? 1.0f : 0.0f;
+        breaking = -1.0f * p.brk_mult * atanf(delta * 1.0f) / kHalfPi;
+        if (breaking < 0.4f) breaking = 0.0f;
+    }
+    if (p.smooth) {                                                                 // keras_pilot.py:147-153
+        if (steering > p.smooth_thr) steering = 1.0f;
+        else if (steering < -p.smooth_thr) steering = -1.0f;
+    }
+    p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
+}
+
 __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
 {
     // one wave per frame: lane o owns output neuron o of the current layer; activations travel through LDS
@@ -1147,29 +1349,113 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
     }
     __builtin_amdgcn_wave_barrier();
     if (lane != 0) return;
-    const float out[2] = {s4[wv][0], s4[wv][1]};
-    if (p.raw_out) { p.raw_out[2 * i] = out[0]; p.raw_out[2 * i + 1] = out[1]; }
-    if (!p.act) return;
-    if (p.mode && p.mode[i] != TRS_MODE_AI && p.mode[i] != TRS_MODE_AI_STEERING) { p.steer[i] = 0.0f; p.thr[i] = 0.0f; p.brk[i] = 0.0f; return; }
-    float steering = out[0] < -1.0f ? -1.0f : (out[0] > 1.0f ? 1.0f : out[0]);     // __cap (keras_pilot.py:142-145)
-    const float predicted = out[1] * 20.0f;                                         // :83
-    const float real = p.speed[i];
-    const float kHalfPi = 1.57079632679489661923f;
-    float delta = predicted * p.threshold - real;                                   // calcThrottle (mapping.py:23-28)
-    float throttle = p.rev_mult * atanf(delta * 2.0f) / kHalfPi;
-    if (throttle > -0.2f && throttle < 0.0f) throttle = 0.0f;
-    float breaking = 0.0f;
-    if (p.direct) throttle = out[1] < -1.0f ? -1.0f : (out[1] > 1.0f ? 1.0f : out[1]);   // ModelType.CNN_2D: __cap of both outputs (:60)
-    else if (p.use_break) {                                                         // keras_pilot.py:88-90, mapping.py:30-35
-        throttle = (predicted - real > 0.0f) ? 1.0f : 0.0f;
-        breaking = -1.0f * p.brk_mult * atanf(delta * 1.0f) / kHalfPi;
-        if (breaking < 0.4f) breaking = 0.0f;
+    tail_finish(p, i, s4[wv][0], s4[wv][1]);
+}
+
+// ---- dense1 as its own kernel (round 2) -------------------------------------------------------------------------------------
+// dense1 (4608 -> 100 at 120x160, 83,328 -> 100 at 240x320) is 0.8 % of the network's arithmetic but, as a 1x1 convolution on
+// the chunked kernel, it and the tail were 23 of 267 us: 36 K slices of partial sums written and read back (19 MB against 9.4 MB
+// of activations).  Here a workgroup takes 32 frames x one K slice (8 slices fill the chip at 1024 frames):
+//   * the slice's activations go through LDS (coalesced 16-byte loads of each frame's contiguous run, chunks of 72 granules,
+//     double buffered; row pitch 73 granules = conflict-free ds_read_b128 fragments);
+//   * wave w owns channels 32 w .. 32 w + 31: all 36 k-steps of a chunk on one accumulator, its weight fragments ALL in flight (a
+//     register ring of 36 granules straight from L2, each refilled for the next chunk right behind the MFMA that read it);
+//   * workgroups are numbered so that one XCD works on one K slice: its 1/8 of the weights stays in that XCD's L2;
+//   * the slice's partial sums go to slab [slice][frame][100]; the tail kernel adds the slabs in slice order.
+// 15.5 -> 7.3 us (and the tail 7.5 -> 5.8 with 8 slabs instead of 36); 47 -> 36 us at 512 x 240x320.  Measured and NOT kept
+// (profiles/r02_pilot_dense.txt): the tail in the same launch, run by the last K slice of a frame group to arrive — the hand-over
+// between XCDs costs a write-through drain (2.2 us) and an sc1 read (4 us) and leaves 32 workgroups to do what 256 do in the
+// tail kernel: 17 us in one launch against 7.3 + 5.8 in two.
+struct DenseParams {
+    const u4v* act;            // conv7's output: bf16 [n][G] granules (the NHWC flatten)
+    const u4v* w;              // [G][128] granules
+    const float* bias;         // [128]
+    float* slab;               // [KS][n][100] fp32
+    int n, G, gps, KS, groups;
+};
+
+constexpr int kDenseChunk = 72;            // granules per LDS chunk = 36 k-steps
+constexpr int kDensePitch = 73;            // LDS row pitch in granules (odd: 16 lanes cover all 64 banks)
+constexpr int kDenseSteps = kDenseChunk / 2;
+constexpr int kDenseStage = 9;             // granules a thread stages per chunk (32 x 72 / 256)
+constexpr int kDenseLds = 2 * 32 * kDensePitch * 16;
+
+__global__ __launch_bounds__(256) void trs_pilot_dense_kernel(const DenseParams p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int group = idx % p.groups, slice = xcd + 8 * (idx / p.groups);
+    if (slice >= p.KS) return;                                              // the grid is padded to whole rounds of 8 slices
+    u4v* const st = reinterpret_cast<u4v*>(psmem);                          // [2][32][73] granules
+    const int gs = slice * p.gps, ge = min(p.G, gs + p.gps);
+    const int f0 = group * 32;
+
+    // staging: thread t moves granules e = t + 256 i (i < 9) of a chunk: frame e / 72, granule e % 72
+    int sbase[kDenseStage], sdst[kDenseStage];
+#pragma unroll
+    for (int i = 0; i < kDenseStage; ++i) {
+        const int e = tid + 256 * i, f = e / kDenseChunk, gi = e - f * kDenseChunk;
+        sbase[i] = min(f0 + f, p.n - 1) * p.G;
+        sdst[i] = f * kDensePitch + gi;
     }
-    if (p.smooth) {                                                                 // keras_pilot.py:147-153
-        if (steering > p.smooth_thr) steering = 1.0f;
-        else if (steering < -p.smooth_thr) steering = -1.0f;
+    u4v pf[kDenseStage];
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < kDenseStage; ++i) {
+            const int e = tid + 256 * i, f = e / kDenseChunk, gi = e - f * kDenseChunk;
+            pf[i] = p.act[sbase[i] + min(c0 + gi, p.G - 1)];
+        }
+    };
+    auto stage_write = [&](int buf) {
+        u4v* const sn = st + buf * (32 * kDensePitch);
+#pragma unroll
+        for (int i = 0; i < kDenseStage; ++i) sn[sdst[i]] = pf[i];
+    };
+    // weight ring: granule 2 j + h of the chunk for k-step j, this wave's 32 channels
+    u4v wr[kDenseSteps];
+    const u4v* const wlane = p.w + wave * 32 + r;
+    auto ring_load = [&](int j, int c0) { wr[j] = wlane[(size_t)min(c0 + 2 * j + h, p.G - 1) * 128]; };
+    stage_load(gs);
+#pragma unroll
+    for (int j = 0; j < kDenseSteps; ++j) ring_load(j, gs);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = slice == 0 ? p.bias[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.0f;
+    stage_write(0);
+    __syncthreads();
+
+    auto chunk = [&](int c0, int buf, auto prefetch) {
+        const u4v* const sb = st + buf * (32 * kDensePitch) + r * kDensePitch + h;
+#pragma unroll
+        for (int j = 0; j < kDenseSteps; ++j) {
+            u4v a = sb[2 * j];
+            if (c0 + 2 * j >= ge) a = u4v{0u, 0u, 0u, 0u};                  // ragged last chunk: a zero fragment instead of a branch
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[j]), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+            if constexpr (decltype(prefetch)::value) ring_load(j, c0 + kDenseChunk);
+        }
+    };
+    int c0 = gs, buf = 0;
+    for (; c0 + kDenseChunk < ge; c0 += kDenseChunk, buf ^= 1) {            // every chunk but the last: the next one's operands are requested underneath
+        stage_load(c0 + kDenseChunk);
+        chunk(c0, buf, std::true_type{});
+        stage_write(buf ^ 1);
+        __syncthreads();
     }
-    p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
+    chunk(c0, buf, std::false_type{});
+
+    {   // D[cout][frame]: lane = frame r, registers 4 q4 .. + 3 = channels 32 wave + 8 q4 + 4 h .. + 3: one 16-byte store each
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)((size_t)p.KS * p.n * 400), 0x00020000);
+        const int row = ((slice * p.n + f0 + r) * 100) * 4;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c = wave * 32 + 8 * q4 + 4 * h;
+            if (c < 100 && f0 + r < p.n) {
+                const u4v v = {__float_as_uint(acc[4 * q4]), __float_as_uint(acc[4 * q4 + 1]), __float_as_uint(acc[4 * q4 + 2]), __float_as_uint(acc[4 * q4 + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, row + c * 4, 0, 0);
+            }
+        }
+    }
 }
 
 // The tail of the model types with extra inputs (components/keras_train.py): cnn_2d_speed_as_feature =
@@ -1341,6 +1627,9 @@ struct PilotCtx {
     bool fuse12 = false, fuse_band = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
+    bool dense_new = false;               // dense1 (and dense4) on trs_pilot_dense_kernel
+    int chain_first = -1, chain_lds = 0; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
+    bool chain_mid_valid = true;          // act[chain_first .. 5] hold the last pass (the chain never writes them; the debug getter runs the single layers on demand)
     u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
 };
 
@@ -1464,6 +1753,31 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     return TRS_OK;
 }
 
+// K slices of trs_pilot_dense_kernel: whole LDS chunks, as many slices as give every CU a workgroup (groups of 32 frames x slices)
+void dense_plan(const ConvLayer& l, int n, int cu_count, int* gps, int* ks)
+{
+    const int groups = (n + 31) / 32, G = l.G;
+    int want = std::max(1, cu_count / groups);
+    if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
+    const int chunks = (G + kDenseChunk - 1) / kDenseChunk;
+    const int cps = std::max(1, (chunks + want - 1) / want);
+    *gps = cps * kDenseChunk;
+    *ks = (G + *gps - 1) / *gps;
+}
+
+int launch_dense(PilotCtx* c, const ConvLayer& l, const void* in, int n, void* slab, hipStream_t s)
+{
+    DenseParams q{};
+    q.act = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.slab = static_cast<float*>(slab);
+    q.n = n; q.G = l.G; q.groups = (n + 31) / 32;
+    dense_plan(l, n, c->cu_count, &q.gps, &q.KS);
+    const int grid = q.groups * ((q.KS + 7) / 8) * 8;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_pilot_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLds));
+    hipLaunchKernelGGL(trs_pilot_dense_kernel, dim3(grid), dim3(256), kDenseLds, s, q);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+
 int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
 {
     const void* in = d_frames;
@@ -1489,10 +1803,23 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         in_bytes = (size_t)n * c->act_elems[1] * 2;
         first = 2;
     }
+    c->chain_mid_valid = c->chain_first < 0;
     for (int i = first; i < 8; ++i) {
+        if (i == c->chain_first) {                                          // conv(i + 1) .. conv7 in one launch, activations in LDS
+            ChainParams q = c->chain;
+            q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
+            hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
+            HIPCHK(hipGetLastError());
+            in = c->act[6];
+            in_bytes = (size_t)n * c->act_elems[6] * 2;
+            i = 6;
+            continue;
+        }
         void* out = c->act[i];
         if (i == 7) {                                                       // dense1: one fp32 slab per K slice, added in order by the tail kernel
-            c->last_slices = split_k_slices(c->L[7], n, c->cu_count);
+            if (c->dense_new) { int gps; dense_plan(c->L[7], n, c->cu_count, &gps, &c->last_slices); }
+            else c->last_slices = split_k_slices(c->L[7], n, c->cu_count);
             const size_t need = (size_t)c->last_slices * n * c->act_elems[7] * sizeof(float);
             if (c->slab_bytes < need) {
                 HIPCHK(hipStreamSynchronize(v.stream));
@@ -1502,14 +1829,16 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             }
             out = c->slab;
         }
-        int rc = launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
+        int rc = (i == 7 && c->dense_new) ? launch_dense(c, c->L[7], in, n, out, v.stream)
+                                          : launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
         if (rc) return rc;
         if (i == 0) c->act0_valid = true;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
     }
     if (c->arch == TRS_PILOT_FULL_HOUSE) {                                 // the steering head's dense4 reads conv7's output as well
-        c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count);
+        if (c->dense_new) { int gps; dense_plan(c->L[8], n, c->cu_count, &gps, &c->last_slices2); }
+        else c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count);
         const size_t need = (size_t)c->last_slices2 * n * c->act_elems[8] * sizeof(float);
         if (c->slab2_bytes < need) {
             HIPCHK(hipStreamSynchronize(v.stream));
@@ -1517,7 +1846,8 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             HIPCHK(hipMalloc(&c->slab2, need));
             c->slab2_bytes = need;
         }
-        int rc = launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count);
+        int rc = c->dense_new ? launch_dense(c, c->L[8], c->act[6], n, c->slab2, v.stream)
+                              : launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count);
         if (rc) return rc;
     }
     c->last_n = n;
@@ -1533,6 +1863,21 @@ int check_model_type(const PilotCtx* c, const trs_pilot_config* cfg)
     const bool ok = c->arch == TRS_PILOT_SPD_CTL ? (mt == TRS_PILOT_SPD_CTL || mt == TRS_PILOT_CNN_2D) : mt == c->arch;
     if (!ok) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_config.model_type does not match the loaded weights (22 arrays: cnn_2d_speed_control / cnn_2d; 28: cnn_2d_speed_as_feature; 42: cnn_2d_full_house)");
     return TRS_OK;
+}
+
+TailParams make_tail(const PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act, const ActIo* io)
+{
+    TailParams t{};
+    t.w2 = c->w2; t.b2 = c->b2; t.w3 = c->w3; t.b3 = c->b3; t.w4 = c->w4; t.b4 = c->b4;
+    t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
+    if (act) {
+        t.speed = v.speed; t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
+        if (io) { t.speed = io->speed ? io->speed : v.speed; t.mode = io->mode; t.steer = io->steer; t.thr = io->thr; t.brk = io->brk; }
+        t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
+        t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
+        t.direct = cfg->model_type == TRS_PILOT_CNN_2D;
+    }
+    return t;
 }
 
 int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_pilot_config* cfg, bool act, const ActIo* io = nullptr)
@@ -1555,20 +1900,19 @@ int run_tail(PilotCtx* c, const TrsEnvView& v, int n, float* raw_out, const trs_
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
-    TailParams t{};
+    TailParams t = make_tail(c, v, n, raw_out, cfg, act, io);
     t.h1 = static_cast<const float*>(c->slab); t.h1_slices = c->last_slices; t.h1_stride = (size_t)n * c->act_elems[7];
-    t.w2 = c->w2; t.b2 = c->b2; t.w3 = c->w3; t.b3 = c->b3; t.w4 = c->w4; t.b4 = c->b4;
-    t.raw_out = raw_out; t.n = n; t.act = act ? 1 : 0;
-    if (act) {
-        t.speed = v.speed; t.steer = v.ctl_steer; t.thr = v.ctl_thr; t.brk = v.ctl_brk;
-        if (io) { t.speed = io->speed ? io->speed : v.speed; t.mode = io->mode; t.steer = io->steer; t.thr = io->thr; t.brk = io->brk; }
-        t.threshold = cfg->spd_ctl_threshold; t.rev_mult = cfg->spd_ctl_reverse_multiplier; t.brk_mult = cfg->spd_ctl_break_multiplier;
-        t.use_break = cfg->spd_ctl_break; t.smooth = cfg->smooth_steering_enabled; t.smooth_thr = cfg->smooth_steering_threshold;
-        t.direct = cfg->model_type == TRS_PILOT_CNN_2D;
-    }
     hipLaunchKernelGGL(trs_pilot_tail_kernel, dim3((n + 3) / 4), dim3(256), 0, v.stream, t);
     HIPCHK(hipGetLastError());
     return TRS_OK;
+}
+
+// the whole pilot: convolutions, dense1 and the tail
+int forward_and_tail(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n, float* raw_out, const trs_pilot_config* cfg, bool act, const ActIo* io = nullptr)
+{
+    int rc = forward(c, v, d_frames, n);
+    if (rc) return rc;
+    return run_tail(c, v, n, raw_out, cfg, act, io);
 }
 
 }  // namespace
@@ -1801,6 +2145,45 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         if (rcw) return rcw;
         c->fuse.w2 = c->w2_parity;
     }
+    {   // conv4..conv7 (or conv5..conv7) as one launch when F frames of all their activations fit LDS; TRS_PILOT_CHAIN = 0: off, 3 / 4: layers
+        int want = 4;
+        if (const char* e = std::getenv("TRS_PILOT_CHAIN")) want = std::atoi(e);
+        c->chain_first = -1;
+        for (int nl = std::min(want, 4); nl >= 3 && c->chain_first < 0; --nl) {
+            const int first = 7 - nl;
+            bool ok = true;
+            for (int i = first; i < 7; ++i) {
+                const ConvLayer& l = c->L[i];
+                ok = ok && l.frame && l.frame_bands == 1 && l.COUT == l.COUT_PAD && l.CIN == (i == 6 ? 128 : 64) && (l.COUT == 64 || l.COUT == 128);
+            }
+            if (!ok) continue;
+            auto out_bytes = [&](int i) { return (size_t)c->L[i].OH * c->L[i].OW * c->L[i].COUT * 2; };
+            auto in_bytes_of = [&](int i) { return (size_t)c->L[i].IH * c->L[i].IW * c->L[i].CIN * 2; };
+            for (int f = 4; f >= 2 && c->chain_first < 0; f -= 2) {
+                if (f > 2 && (c->n_cap + f - 1) / f < c->cu_count) continue;          // keep a workgroup per CU
+                const bool split = nl == 4;
+                size_t a, b;
+                if (split) { a = std::max(f * out_bytes(3), f * out_bytes(5)); b = std::max((size_t)(f / 2) * in_bytes_of(3), f * out_bytes(4)); }
+                else { a = std::max(f * in_bytes_of(4), f * out_bytes(5)); b = f * out_bytes(4); }
+                a = (a + 15) & ~(size_t)15; b = (b + 15) & ~(size_t)15;
+                const size_t total = a + b + 4 * 128 * 4;
+                if (total > 158 * 1024) continue;
+                ChainParams& q = c->chain;
+                q = ChainParams{};
+                q.F = f; q.nl = nl; q.split_first = split ? 1 : 0; q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
+                for (int j = 0; j < nl; ++j) {
+                    const ConvLayer& l = c->L[first + j];
+                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4};
+                }
+                c->chain_first = first; c->chain_lds = (int)total;
+            }
+        }
+    }
+    {   // dense1 (and dense4) on trs_pilot_dense_kernel; TRS_PILOT_DENSE = 0: the chunked kernel (A/B measurements)
+        int mode = 1;
+        if (const char* e = std::getenv("TRS_PILOT_DENSE")) mode = std::atoi(e);
+        c->dense_new = mode >= 1 && c->L[7].COUT_PAD == 128 && c->L[7].G % 16 == 0;
+    }
     HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
     for (const ConvLayer& l : c->L) {
         const int nb = l.COUT_PAD / 32;
@@ -1826,9 +2209,7 @@ TRS_EXPORT int trs_pilot_forward(trs_env* e, const uint8_t* d_frames, int n_imag
     }
     if (c->arch != TRS_PILOT_SPD_CTL && n_images != v.n)
         return trs_internal_fail(TRS_ERR_ARG, "this model type also reads speed (and segment): use trs_pilot_forward_ex, or n_images == n_envs for the env's own");
-    int rc = forward(c, v, d_frames, n_images);
-    if (rc) return rc;
-    return run_tail(c, v, n_images, d_out ? d_out : c->raw, nullptr, false);
+    return forward_and_tail(c, v, d_frames, n_images, d_out ? d_out : c->raw, nullptr, false);
 }
 
 TRS_EXPORT int trs_pilot_forward_ex(trs_env* e, const uint8_t* d_frames, const float* d_speed, const float* d_segment, int n_images, float* d_out)
@@ -1844,10 +2225,8 @@ TRS_EXPORT int trs_pilot_forward_ex(trs_env* e, const uint8_t* d_frames, const f
         if (!v.latest_frame || n_images != v.n) return trs_internal_fail(TRS_ERR_ARG, "latest-frame source needs a rendered step and n_images == n_envs");
         d_frames = v.latest_frame;
     }
-    int rc = forward(c, v, d_frames, n_images);
-    if (rc) return rc;
     const ActIo io{d_speed, d_segment, nullptr, nullptr, nullptr, nullptr};
-    return run_tail(c, v, n_images, d_out ? d_out : c->raw, nullptr, false, &io);
+    return forward_and_tail(c, v, d_frames, n_images, d_out ? d_out : c->raw, nullptr, false, &io);
 }
 
 TRS_EXPORT int trs_pilot_forward_host_ex(trs_env* e, const uint8_t* h_frames, const float* h_speed, const float* h_segment, int n_images, float* h_out)
@@ -1919,6 +2298,14 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
         if (rc) return rc;
         c->act0_valid = true;
     }
+    if (c->chain_first >= 0 && layer >= c->chain_first && layer < 6 && !c->chain_mid_valid) {   // the chain kept these activations in LDS: run the single layers now
+        for (int j = c->chain_first; j < 6; ++j) {
+            const void* src = j == 0 ? (const void*)c->last_frames : c->act[j - 1];
+            int rc = launch_conv(c->L[j], src, (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count);
+            if (rc) return rc;
+        }
+        c->chain_mid_valid = true;
+    }
     HIPCHK(hipStreamSynchronize(v.stream));
     if (c->L[layer].out_f32) {                                              // dense1: add the K-slice slabs in slice order, then the ReLU (both live in the tail kernel)
         std::vector<float> part(total);
@@ -1958,10 +2345,8 @@ TRS_EXPORT int trs_pilot_act(trs_env* e, const trs_pilot_config* cfg, const uint
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
-    int rc = forward(c, v, d_frames, n);
-    if (rc) return rc;
     const ActIo io{d_speed, d_segment, d_mode, d_steer, d_thr, d_brk};
-    return run_tail(c, v, n, c->raw, cfg, true, &io);
+    return forward_and_tail(c, v, d_frames, n, c->raw, cfg, true, &io);
 }
 
 TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_steps)
@@ -1978,8 +2363,7 @@ TRS_EXPORT int trs_step_pilot(trs_env* e, const trs_pilot_config* cfg, int n_ste
     for (int k = 0; k < n_steps; ++k) {
         trs_internal_view(e, &v);
         if (v.latest_frame) {                       // KerasPilot.step on the frame of the previous tick
-            int rc = forward(c, v, v.latest_frame, v.n);
-            if (!rc) rc = run_tail(c, v, v.n, c->raw, cfg, true);
+            int rc = forward_and_tail(c, v, v.latest_frame, v.n, c->raw, cfg, true);
             if (rc) return rc;
         } else {                                    // args[0] is None -> (0.0, 0.0, 0.0) (keras_pilot.py:46-47)
             hipLaunchKernelGGL(trs_zero_controls_kernel, dim3((v.n + 255) / 256), dim3(256), 0, v.stream, v.ctl_steer, v.ctl_thr, v.ctl_brk, v.n);
