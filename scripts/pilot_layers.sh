@@ -20,14 +20,16 @@ for r in rows:
 seq=[s for s in seq if len(s)==len(seq[-1])]
 layouts={10:["env step","conv1","conv2","conv3","conv4","conv5","conv6","conv7","dense1","tail"],
          9:["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense1","tail"],
-         8:["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense+tail"]}
+         8:["env step","conv1+2","conv3","conv4","conv5","conv6","conv7","dense+tail"],
+         7:["env step","conv1+2","conv3","conv4","conv5-7","dense1","tail"],
+         6:["env step","conv1+2","conv3","conv4-7","dense1","tail"]}
 names=fused=layouts.get(len(seq[-1]),[str(i) for i in range(len(seq[-1]))])
 tot=0
 for j in range(len(seq[-1])):
     d=[int(s[j]["End_Timestamp"])-int(s[j]["Start_Timestamp"]) for s in seq]
     r=seq[-1][j]
     kn=r["Kernel_Name"]
-    kind="fused" if "conv12" in kn else "dense" if "pilot_dense" in kn else "frame" if "conv_frame" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
+    kind="fused" if "conv12" in kn else "chain" if "conv_chain" in kn else "frame5" if "frame5" in kn else "dense" if "pilot_dense" in kn else "frame" if "conv_frame" in kn else "span" if "span" in kn else "lt" if "conv_lt" in kn else "u8" if "conv_u8" in kn else "chunked" if "conv_mfma" in kn else "-"
     nm=names[j] if len(seq[-1])==len(names) else (fused[j] if len(seq[-1])==len(fused) else str(j))
     tot+=sum(d)/len(d)
     print(f"  {nm:9s} {kind:8s} grid={r['Grid_Size_X']:>8s}x{r['Grid_Size_Y']} wg={r['Workgroup_Size_X']:>4s} lds={r.get('LDS_Block_Size','?'):>7s}  mean {sum(d)/len(d)/1e3:8.1f} us")

@@ -363,3 +363,26 @@ def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, lay
     for a, b in zip(res["0"], res[layers]):
         assert np.array_equal(a, b)
     assert np.std(res[layers][0][:, 0]) > 1e-5
+
+
+@pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9)])
+def test_conv3_with_frames_in_lds_is_bit_identical_to_the_span_kernel(make_env, size, n, monkeypatch):
+    """conv3 on trs_conv_frame5_kernel (input frames in LDS, even / odd column planes, weights from L2) against the span kernel
+    (TRS_PILOT_FRAME5 = 0): the same k order on the same bf16 values — conv3's activation and the outputs agree bit for bit."""
+    h, w = size
+    ws = make_weights(h, w, seed=13)
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    (ih, iw) = (h, w)
+    for k, s_, _, cout in SPEC[:3]:
+        ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TRS_PILOT_FRAME5", mode)
+        env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_load(ws)
+        out = env.pilot_forward_host(frames)
+        res[mode] = (out, env.pilot_layer(2, (n, ih, iw, 64)))
+    assert np.array_equal(res["0"][1], res["1"][1])
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.abs(res["1"][1]).max() > 0

@@ -835,6 +835,134 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     }
 }
 
+// ---- conv3 with its input frames in LDS (round 2) -----------------------------------------------------------------------------
+// conv3 (5x5 stride 2, 32 -> 64 channels) on the span kernel below reads three 1 KB fragments from LDS per two MFMAs (its weights
+// live in LDS: 192 B/clk per CU at full MFMA rate against the 128 the LDS delivers) — 43 us per 1024 frames.  This is the frame
+// kernel's scheme instead: F = 2 input frames (64 KB each) in LDS by LDS-DMA, weights straight from L2 through a register ring,
+// 2 x 32 pixels x 2 x 32 channels per wave, the 50 k-steps (25 taps x 2 halves of the 32 input channels) one basic block.
+// Stride 2 changes the LDS image: a row is stored as its even columns, then its odd columns, so the windows of consecutive
+// output pixels are consecutive 64-byte slots for every tap; granule g of slot s sits at g ^ ((s >> 2) & 3) — 16 consecutive
+// slots of one logical granule cover all 64 banks.
+struct Frame5Params {
+    const u4v* in;             // bf16 NHWC [N][IH][IW][32]
+    const u4v* w;              // [KH*KW*4][64] granules: row (kh, kw, c8), 2 k + h = granule of k-step k, half h
+    const float* bias;
+    unsigned short* out;       // bf16 NHWC [N][OH][OW][64]
+    int N, IH, IW, OH, OW, F, ev, COUT;   // ev = even columns per row = (IW + 1) / 2
+};
+
+template <int R, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trs_conv_frame5_kernel(const Frame5Params p)
+{
+    constexpr int NT = 2, NB = 2, KW = 5, ksteps = 50;
+    const int COUT = p.COUT;                                                // 64; a run-time value on purpose: with a constant the compiler folds the ring's running
+                                                                            // pointer into 46 precomputed addresses (92 live registers, spills)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nwaves = BLOCK / 64;
+    const int r = lane & 31, h = lane >> 5;
+    const int u0 = blockIdx.x * p.F, nu = min(p.F, p.N - u0);
+    const int upix = p.IH * p.IW, uout = p.OH * p.OW;
+    {   // staging: slot sl = 4 * lpix + q holds granule q ^ ((lpix >> 2) & 3) of the pixel that lives in slot lpix
+        const int total = nu * upix * 4;
+        const unsigned lds_base = (unsigned)(uintptr_t)psmem;
+        for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
+            const int sl = s0 + lane;
+            if (sl < total) {
+                const int lpix = sl >> 2, g = (sl & 3) ^ ((lpix >> 2) & 3);
+                const int ul = lpix / upix, rp = lpix - ul * upix, iy = rp / p.IW, s = rp - iy * p.IW;
+                const int col = s < p.ev ? 2 * s : 2 * (s - p.ev) + 1;
+                const size_t gpix = ((size_t)(u0 + ul) * p.IH + iy) * p.IW + col;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + gpix * 4 + g),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
+            }
+        }
+        float* lb = reinterpret_cast<float*>(psmem + (size_t)p.F * upix * 64);
+        for (int i = tid; i < COUT; i += BLOCK) lb[i] = p.bias[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const u4v* lin = reinterpret_cast<const u4v*>(psmem);
+    const float4* lbias = reinterpret_cast<const float4*>(psmem + (size_t)p.F * upix * 64);
+    const int m_wg = nu * uout, n_tiles = (m_wg + NT * 32 - 1) / (NT * 32);
+    for (int item = wave; item < n_tiles; item += nwaves) {
+        int lbase[NT], mo[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = item * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
+            const int ul = mc / uout, rem = mc - ul * uout, oy = rem / p.OW, ox = rem - oy * p.OW;
+            lbase[nt] = (ul * p.IH + 2 * oy) * p.IW + ox;                   // slot of input pixel (2 oy, 2 ox): even plane, position ox
+            mo[nt] = m < m_wg ? m : -1;
+        }
+        const u4v* wl = p.w + r;
+        u4v ring[R][NB];
+#pragma unroll
+        for (int d = 0; d < R; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * COUT + nb * 32];
+        const u4v* wnext = wl + (size_t)(2 * R + h) * COUT;
+        f32x16 acc[NT][NB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        auto pixels = [&](int k, bf16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
+            const int tap = k / 2, g = 2 * (k % 2) + h;
+            const int kh = tap / KW, kw = tap % KW;
+            const int tap_off = kh * p.IW + ((kw & 1) ? p.ev : 0) + (kw >> 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pix = lbase[nt] + tap_off;
+                x[nt] = __builtin_bit_cast(bf16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
+            }
+        };
+        bf16x8 xa[NT], xb[NT];
+        pixels(0, xa);
+#pragma unroll
+        for (int k = 0; k < ksteps; ++k) {
+            const int d = k % R;
+            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            if (k + 1 < ksteps) pixels(k + 1, xn);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+            if (k + R < ksteps) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
+                wnext += 2 * COUT;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            unsigned short* o = p.out + ((size_t)u0 * uout + (mo[nt] < 0 ? 0 : mo[nt])) * COUT;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                uint2 w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = lbias[(nb * 32 + 8 * q + 4 * h) >> 2];
+                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores (see trs_conv_frame_kernel)
+                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
+                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
+                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};
+                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};
+                if (mo[nt] >= 0) {
+                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;
+                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;
+                }
+            }
+        }
+    }
+}
+
 // conv2 / conv3 (stride-2 5x5): overlapping windows make the kernel above fetch every input byte ~2.5x, and the texture
 // addresser (about one lookup per clock) is what bounds these layers.  Here a wave stages, per kernel row, the CONTIGUOUS
 // input span its 32-pixel tile needs (a tile crosses output rows, so the span is 1..4 segments, one per output row touched)
@@ -1605,6 +1733,7 @@ struct ConvLayer {
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
     bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
     bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
+    bool frame5 = false; int frame5_f = 1, frame5_lds = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, input frames in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -1689,6 +1818,15 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > (nt_mb << 20)) ? nt_kind : 0;
     }
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
+    if (l.frame5) {
+        Frame5Params q{};
+        q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
+        q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = l.frame5_f; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((trs_conv_frame5_kernel<4, 512>), dim3((n_img + q.F - 1) / q.F), dim3(512), l.frame5_lds, s, q);
+        HIPCHK(hipGetLastError());
+        return TRS_OK;
+    }
     if (l.frame) {
         FrameConvParams q{};
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
@@ -2028,6 +2166,15 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
                 l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
             }
+        }
+        if (i == 2) {            // conv3: frames in LDS when two fit (120x160: 2 x 64 KB); TRS_PILOT_FRAME5 = 0: the span kernel
+            int on = 1;
+            if (const char* e = std::getenv("TRS_PILOT_FRAME5")) on = std::atoi(e);
+            const size_t unit = (size_t)l.IH * l.IW * 64;
+            const bool shape_ok = l.KH == 5 && l.KW == 5 && l.S == 2 && l.CIN == 32 && l.COUT == 64 && l.COUT_PAD == 64 && run_pad == 20 && l.G_pad == 100;
+            int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
+            while (f > 1 && (c->n_cap + f - 1) / f < c->cu_count) --f;
+            if (on && shape_ok && f >= 1) { l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
         const int ai = i == 8 ? 34 : 2 * i;                               // dense4 of the full-house model
