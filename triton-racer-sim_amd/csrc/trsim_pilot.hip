@@ -683,6 +683,9 @@ struct ChainParams {
     ChainLayer L[4];           // every layer but the last reads 64 channels (HALF = 4), the last 128 (HALF = 8)
 };
 
+#ifndef TRS_CHAIN_ABLATE
+#define TRS_CHAIN_ABLATE 0   /* timing-only diagnostic builds of the chain's layers, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no MFMA */
+#endif
 template <int HALF, int R>
 __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
                                             unsigned short* gout, int wave, int nwaves, int lane)
@@ -724,9 +727,15 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pix = lbase[nt] + tap_off;
+#if TRS_CHAIN_ABLATE == 2
+                if (k == 0) xkeep[nt] = __builtin_bit_cast(bf16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+                x[nt] = xkeep[nt];
+#else
                 x[nt] = __builtin_bit_cast(bf16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+#endif
             }
         };
+        [[maybe_unused]] bf16x8 xkeep[NT];
         bf16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
@@ -738,8 +747,14 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
-            if (k + R < ksteps) {
+                for (int nb = 0; nb < NB; ++nb) {
+#if TRS_CHAIN_ABLATE == 3
+                    asm volatile("" :: "v"(ring[d][nb]), "v"(xc[nt]));
+#else
+                    acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+#endif
+                }
+            if (k + R < ksteps && TRS_CHAIN_ABLATE != 1) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
                 wnext += 2 * L.COUT;
@@ -779,6 +794,9 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
     }
 }
 
+#ifndef TRS_CHAIN_R
+#define TRS_CHAIN_R 4   /* weight ring depth of the chain's layers, in k-steps */
+#endif
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams p)
 {
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
             if (cnt > 0) stage(L0, u0 + per * pass, cnt, lds0 + p.offB);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (cnt > 0) chain_layer<4, 4>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+            if (cnt > 0) chain_layer<4, TRS_CHAIN_R>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
             __syncthreads();
         }
         li = 1;
@@ -825,13 +843,13 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     for (; li < p.nl - 1; ++li) {
         const ChainLayer& L = p.L[li];
         u4v* const nxt = cur == A ? B : A;
-        chain_layer<4, 4>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        chain_layer<4, TRS_CHAIN_R>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
         __syncthreads();
         cur = nxt;
     }
     {
         const ChainLayer& L = p.L[p.nl - 1];
-        chain_layer<8, 4>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
+        chain_layer<8, TRS_CHAIN_R>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
     }
 }
 
@@ -851,10 +869,10 @@ struct Frame5Params {
     int N, IH, IW, OH, OW, F, ev, COUT;   // ev = even columns per row = (IW + 1) / 2
 };
 
-template <int R, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trs_conv_frame5_kernel(const Frame5Params p)
+template <int NT, int R, int BLOCK, int MINB>
+__global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Frame5Params p)
 {
-    constexpr int NT = 2, NB = 2, KW = 5, ksteps = 50;
+    constexpr int NB = 2, KW = 5, ksteps = 50;
     const int COUT = p.COUT;                                                // 64; a run-time value on purpose: with a constant the compiler folds the ring's running
                                                                             // pointer into 46 precomputed addresses (92 live registers, spills)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1281,13 +1299,13 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         if (wt + (int)gridDim.x < total) request(wt + gridDim.x, raw);      // the second item's band is on its way
     }
     __syncthreads();
-    // conv1's weights are the same for every tile of every band: this lane's six granules stay in registers (they were 6 of the
+    // conv1's weights are the same for every tile of every band: this lane's five granules stay in registers (they were 6 of the
     // 11 LDS reads of a conv1 tile, in a phase that is bound by LDS bandwidth: 11 KB per 6 MFMAs and wave)
-    u4v wv[6];
+    u4v wv[5];
 #pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
+    for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
 #pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
+    for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
     while (wt < total) {
         const int nxt = wt + gridDim.x;                                     // uniform per workgroup
         int n, y2_0, r2, r1;
@@ -1311,8 +1329,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
             __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
 #pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6)                                  // k-step 5 is padding (zero weights): any finite operand
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[min(s6, 4)]), acc, 0, 0, 0);
+            for (int s6 = 0; s6 < 5; ++s6)                                  // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[s6]), acc, 0, 0, 0);
             if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
                 uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)yl * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
 #pragma unroll
@@ -1336,8 +1354,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
             const int m0 = (n * q.OH2 + y2_0) * q.OW2;                      // first output pixel of the band (consecutive in memory)
 #if TRS_FUSE_ABLATE != 2
-            // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us.  The
-            // phase wants MORE waves with work, not fewer LDS reads.)
+            // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us; eight
+            // waves of 256 registers with conv2's 40 weight fragments in registers — no weight reads from LDS at all — 100 -> 117 us:
+            // two waves per SIMD do not hide conv1's LDS round trips, profiles/r02_pilot_head_reg.txt.)
             for (int t2 = wave; t2 < ntile2; t2 += 8) {
                 const int mm = min(t2 * 32 + r, npx2 - 1);
                 int yl2, x2;
@@ -1822,8 +1841,14 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         Frame5Params q{};
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = l.frame5_f; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((trs_conv_frame5_kernel<4, 512>), dim3((n_img + q.F - 1) / q.F), dim3(512), l.frame5_lds, s, q);
+#define LAUNCH_F5(NT_, BLOCK_, MINB_, GRID_)                                                                                  \
+    do {                                                                                                                      \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), dim3(GRID_), dim3(BLOCK_), l.frame5_lds, s, q);  \
+    } while (0)
+        if (q.F == 1) LAUNCH_F5(2, 256, 2, n_img);                          // one frame per workgroup, two workgroups per CU
+        else LAUNCH_F5(2, 512, 1, (n_img + q.F - 1) / q.F);
+#undef LAUNCH_F5
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
@@ -2174,6 +2199,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             const bool shape_ok = l.KH == 5 && l.KW == 5 && l.S == 2 && l.CIN == 32 && l.COUT == 64 && l.COUT_PAD == 64 && run_pad == 20 && l.G_pad == 100;
             int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
             while (f > 1 && (c->n_cap + f - 1) / f < c->cu_count) --f;
+            if (const char* e = std::getenv("TRS_PILOT_FRAME5_F")) f = std::max(1, std::min(f, std::atoi(e)));
             if (on && shape_ok && f >= 1) { l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
