@@ -19,6 +19,25 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # the pattern does not match them and `test_packed_mnemonics_are_known` fails when one appears, so that it gets looked at.
 PACKED = re.compile(r"^\s*(v_pk_\w+)\s+(v\[(\d+):(\d+)\]),\s*(.*)$")
 KNOWN_PACKED = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mov_b32"}
+# 16-bit packed forms keep both halves in ONE 32-bit register: in place is half-for-half unless op_sel / op_sel_hi swap the halves
+KNOWN_PACKED_16 = {"v_pk_max_i16"}
+
+
+def swapped_halves_in_place_16(line):
+    """True for a 16-bit packed op whose destination is also a source read with non-default half selection."""
+    m = re.match(r"\s*(v_pk_\w+16)\s+v(\d+),\s*(.*)$", line)
+    if not m:
+        return False
+    dst, rest = int(m.group(2)), m.group(3)
+    ops = [o.strip() for o in rest.split(" op_sel")[0].split(",")]
+    sel = re.search(r"op_sel:\[([01,]+)\]", rest)
+    sel_hi = re.search(r"op_sel_hi:\[([01,]+)\]", rest)
+    lo = [int(x) for x in sel.group(1).split(",")] if sel else [0] * len(ops)
+    hi = [int(x) for x in sel_hi.group(1).split(",")] if sel_hi else [1] * len(ops)
+    for i, op in enumerate(ops):
+        if op == f"v{dst}" and ((i < len(lo) and lo[i] != 0) or (i < len(hi) and hi[i] != 1)):
+            return True
+    return False
 PAIR = re.compile(r"^v\[(\d+):(\d+)\]$")
 
 
@@ -93,8 +112,18 @@ def test_no_in_place_cross_half_packed_op(src, tmp_path_factory):
 
 @pytest.mark.parametrize("src", SOURCES)
 def test_packed_mnemonics_are_known(src, tmp_path_factory):
-    seen = set(re.findall(r"^\s*(v_pk_\w+)", device_asm(src, tmp_path_factory), flags=re.M))
-    assert seen <= KNOWN_PACKED, f"{src}: new packed instruction forms {sorted(seen - KNOWN_PACKED)}: extend the screen (16-bit forms have one-register operands)"
+    text = device_asm(src, tmp_path_factory)
+    seen = set(re.findall(r"^\s*(v_pk_\w+)", text, flags=re.M))
+    assert seen <= KNOWN_PACKED | KNOWN_PACKED_16, f"{src}: new packed instruction forms {sorted(seen - KNOWN_PACKED - KNOWN_PACKED_16)}: extend the screen (16-bit forms have one-register operands)"
+    bad = [l.strip() for l in text.splitlines() if swapped_halves_in_place_16(l)]
+    assert not bad, f"{src}: 16-bit packed ops that swap halves in place: {bad[:5]}"
+
+
+def test_the_16_bit_screen():
+    assert not swapped_halves_in_place_16("\tv_pk_max_i16 v5, v5, 0")
+    assert not swapped_halves_in_place_16("\tv_pk_max_i16 v5, v6, v5 op_sel_hi:[1,1]")
+    assert swapped_halves_in_place_16("\tv_pk_max_i16 v5, v5, v6 op_sel:[1,0] op_sel_hi:[0,1]")
+    assert not swapped_halves_in_place_16("\tv_pk_max_i16 v5, v7, v6 op_sel:[1,0] op_sel_hi:[0,1]")
 
 
 @pytest.mark.parametrize("src,kernels", [("trsim_hip.hip", "trs_step_kernel"), ("trsim_resident.hip", "trs_worker_kernel")])

@@ -86,6 +86,20 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// ReLU on two packed bf16: a bf16's sign bit is the int16's, so max(., 0) as int16 zeroes the negatives (and -0).  One v_pk_max_i16
+// for two values instead of a v_max_f32 each in front of the conversion; round-to-nearest keeps the sign, so the bits are the same.
+// (The epilogues are vector-ALU work between short MFMA runs: conv1's tile of 5 MFMAs carried ~65 VALU instructions.)
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned packed)
+{
+    const s16x2 v = __builtin_bit_cast(s16x2, packed), z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, z));
+}
+__device__ __forceinline__ uint2 relu_pack4(float v0, float v1, float v2, float v3)
+{
+    return make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+}
+
 template <int NB, bool U8IN>
 __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvParams p)
 {
@@ -248,8 +262,7 @@ __device__ __forceinline__ void store_tile_at(u4v* stage, const f32x16 (&acc)[NB
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[nb * 8 + 2 * q + h];
                     float v0 = acc[nb][4 * q] + b.x, v1 = acc[nb][4 * q + 1] + b.y, v2 = acc[nb][4 * q + 2] + b.z, v3 = acc[nb][4 * q + 3] + b.w;
-                    if (p.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f; }
-                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                 }
             }
         }
@@ -640,8 +653,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
-                    if (p.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f; }
-                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
                 }
                 const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores
                 const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
@@ -770,8 +782,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
-                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    w[q] = relu_pack4(v0, v1, v2, v3);
                 }
                 const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane keeps (see trs_conv_frame_kernel)
                 const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
@@ -964,8 +975,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[(nb * 32 + 8 * q + 4 * h) >> 2];
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
-                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                    w[q] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    w[q] = relu_pack4(v0, v1, v2, v3);
                 }
                 const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores (see trs_conv_frame_kernel)
                 const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
@@ -1181,8 +1191,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = lb1[2 * qd + h];
                     float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
-                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                    dst[2 * qd + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
                 }
             }
         }
@@ -1249,7 +1258,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int i = tid; i < q.band_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(band)[i] = (u4v)(0u);
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
-    const float inv_ow1 = 1.0f / (float)q.OW1, inv_ow2 = 1.0f / (float)q.OW2;
+    const float inv_ow2 = 1.0f / (float)q.OW2;
     const int row_in = q.IW * 3;                                            // bytes per frame row = values per band row
     auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
         qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
@@ -1290,6 +1299,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     // band a whole item ahead and unpack it while waves 0..7 run conv2.
     const int total = q.N * q.bands;
     const bool loader = wave >= 8;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);                // tile indices in scalar registers
+    const unsigned magic1 = (unsigned)((0x100000000ull + (unsigned)q.OW1 - 1u) / (unsigned)q.OW1);   // floor(p / OW1) = umulhi(p, magic1) for p < 65536
     int wt = blockIdx.x;
     u4v raw[kBandPf];
     if (loader && wt < total) request(wt, raw);
@@ -1313,10 +1324,13 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         // ---- phase 1: conv1 rows of the band, from the bf16 image ----
         const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1
-        for (int t1 = wave; t1 < ntile1; t1 += nwaves) {
-            const int pp = min(t1 * 32 + r, npx1 - 1);
-            int yl, x;
-            divmod(pp, q.OW1, inv_ow1, yl, x);
+        for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
+            // the tile's first pixel splits into (row, column) on the scalar unit; a lane adds its r (OW1 >= 32: one wrap at most);
+            // lanes past the band's last pixel compute it again (never stored)
+            const int p0 = t1 * 32, yl0 = (int)__umulhi((unsigned)p0, magic1), x0 = p0 - yl0 * q.OW1;
+            int x = x0 + r, yl = yl0;
+            if (x >= q.OW1) { x -= q.OW1; ++yl; }
+            if (p0 + r >= npx1) { yl = r1 - 1; x = q.OW1 - 1; }
             const unsigned char* wbase = band + ((size_t)(2 * yl) * row_in + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
             f32x16 acc;
 #pragma unroll
@@ -1337,8 +1351,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = lb1[2 * qd + h];
                     float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
-                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
-                    dst[2 * qd + h] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
                 }
             }
         }
@@ -1356,7 +1369,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 #if TRS_FUSE_ABLATE != 2
             // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us; eight
             // waves of 256 registers with conv2's 40 weight fragments in registers — no weight reads from LDS at all — 100 -> 117 us:
-            // two waves per SIMD do not hide conv1's LDS round trips, profiles/r02_pilot_head_reg.txt.)
+            // two waves per SIMD do not hide conv1's LDS round trips; the same with conv2's K split over two waves, two tiles per
+            // wave: 100 -> 125 us, profiles/r02_pilot_head_reg.txt.)
             for (int t2 = wave; t2 < ntile2; t2 += 8) {
                 const int mm = min(t2 * 32 + r, npx2 - 1);
                 int yl2, x2;
@@ -2275,6 +2289,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1;
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
+        const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
         int want_r2 = 6;                                                  // measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
         if (const char* e = std::getenv("TRS_PILOT_FUSE_R2")) want_r2 = std::max(1, std::atoi(e));
         c->fuse12 = false; c->fuse_band = false; c->no_fuse = std::getenv("TRS_PILOT_NO_FUSE") != nullptr;
@@ -2283,7 +2298,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
         int band_r2 = 6;
         if (const char* e = std::getenv("TRS_PILOT_FUSE_BAND_R2")) band_r2 = std::atoi(e);            // 0 = use the direct form
-        for (int r2 = std::min(band_r2, l1.OH); shape_ok && r2 >= std::min(4, l1.OH); --r2) {
+        for (int r2 = std::min(band_r2, l1.OH); shape_ok && band_ok && r2 >= std::min(4, l1.OH); --r2) {
             const int rows_in = 2 * (2 * r2 + 3) + 3, row_in = l0.IW * 3;
             if (row_in % 16 != 0 || rows_in * row_in > kBandPf * 512 * 16) continue;
             int off = 12 * 32 * 16;
