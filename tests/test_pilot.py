@@ -277,15 +277,19 @@ def test_closed_loop_is_unaffected_by_another_stream(make_env):
         t.join()
 
 
-@pytest.mark.parametrize("size", [(120, 160), (240, 320), (100, 132)])
-def test_fused_head_equals_the_two_layers(make_env, size, monkeypatch):
-    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels.  The direct form (240x320) feeds
-    the same bf16 values into the same MFMA order: bit-identical.  The band form (120x160) keeps the conv1 tile split by column
-    parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another summation order, so
-    an output can land on the neighbouring bf16 value — at most one ulp (2^-7 relative), on a small fraction of the elements."""
+@pytest.mark.parametrize("size,wsplit", [((120, 160), None), ((240, 320), None), ((240, 320), "1"), ((100, 132), None), ((130, 300), None)])
+def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
+    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels.  The direct form (240x320 with
+    TRS_PILOT_FUSE_WSPLIT = 1: bands may not be cut in width) feeds the same bf16 values into the same MFMA order: bit-identical.
+    The band form (120x160; 240x320 and 130x300 cut in two parts of conv2 columns, the last part narrower) keeps the conv1 tile
+    split by column parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another
+    summation order, so an output can land on the neighbouring bf16 value — at most one ulp (2^-7 relative), on a small fraction
+    of the elements."""
     h, w = size
     n = 21
     ws = make_weights(h, w, seed=3)
+    if wsplit is not None:
+        monkeypatch.setenv("TRS_PILOT_FUSE_WSPLIT", wsplit)
     env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
     env.pilot_load(ws)
     rng = np.random.default_rng(8)
@@ -294,11 +298,13 @@ def test_fused_head_equals_the_two_layers(make_env, size, monkeypatch):
     oh2, ow2 = (oh1 - 5) // 2 + 1, (ow1 - 5) // 2 + 1
     fused_out = env.pilot_forward_host(frames)
     fused_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
+    again = env.pilot_forward_host(frames)
+    assert np.array_equal(fused_out, again) and np.array_equal(fused_l1, env.pilot_layer(1, (n, oh2, ow2, 32)))
     monkeypatch.setenv("TRS_PILOT_NO_FUSE", "1")
     env.pilot_load(ws)                                                # the switch is read when the weights are loaded
     plain_out = env.pilot_forward_host(frames)
     plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
-    if (h, w) == (240, 320):
+    if wsplit == "1":
         assert np.array_equal(fused_l1, plain_l1)
         assert np.array_equal(fused_out, plain_out)
     else:

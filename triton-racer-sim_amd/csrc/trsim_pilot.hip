@@ -296,6 +296,40 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
     store_tile_at<NB>(stage, acc, lbias, p, tile * 32, p.M, cbase, lane);
 }
 
+// The same epilogue for a tile whose 32 pixels are a run of a ROW-SEGMENT grid (the fused head's band cut in width: rows of w2
+// pixels inside an output activation of OW pixels per row): pixel pg of the band part = (row pg / w2, column pg % w2), output
+// pixel m_row0 + row * OW + column.  32 output channels (NB = 1).
+__device__ __forceinline__ void store_tile_rows(u4v* stage, const f32x16 (&acc)[1], const float4* lbias, const ConvParams& p, int pg0, int npx, int w2, float inv_w2,
+                                                int m_row0, int OW, int lane)
+{
+    constexpr int CR = 4;
+    const int r = lane & 31, h = lane >> 5;
+    uint2* st2 = reinterpret_cast<uint2*>(stage);
+    {
+        const int f = (r >> 1) & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = lbias[2 * q + h];
+            float v0 = acc[0][4 * q] + b.x, v1 = acc[0][4 * q + 1] + b.y, v2 = acc[0][4 * q + 2] + b.z, v3 = acc[0][4 * q + 3] + b.w;
+            st2[(r * CR + (q ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out), 0, p.M * p.COUT * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = i * 64 + lane, pix = g >> 2, c = g & 3;                // 32 pixels x 4 chunks of 8 channels
+        const int pg = pg0 + pix;
+        if (pg < npx) {
+            int row = (int)(((float)pg + 0.5f) * inv_w2), col = pg - row * w2;
+            if (col < 0) { --row; col += w2; } else if (col >= w2) { ++row; col -= w2; }
+            const int f = (pix >> 1) & 3;
+            const u4v v = stage[pix * CR + (c ^ f)];
+            const int off = ((m_row0 + row * OW + col) * p.COUT + 8 * c) * 2;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 0);
+        }
+    }
+}
+
 // conv1 (uint8 frame in, kPf = 3 trips = the whole K of 5 kernel rows x 16 bytes): resident weights, persistent workgroups,
 // independent waves, no barrier after the weight stage.  A wave walks 32-pixel tiles; the raw dwords of the NEXT tile are
 // requested before the current tile's MFMAs and epilogue, so their latency hides behind them.
@@ -1119,6 +1153,8 @@ struct Fuse12Params {
     int off_w2, off_b, off_goff, off_tile, off_stage;       // LDS layout
     int tile_bytes;
     int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as bf16 [rows][IW * 3]
+    int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
+    unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
 };
 
 __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
@@ -1233,6 +1269,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
 // image in LDS, and conv1 reads its k-steps (8 consecutive values, 4-byte aligned) from there with two ds_read2_b32.
 // Same values into the same MFMA order: bit-identical to the kernel above and to the separate layers.
 constexpr int kBandPf = 4;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads)
+template <bool SPLIT>
 __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Params q)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -1248,7 +1285,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     // apart (odd: all 16 bank groups), and a window is two runs: even columns (3 pixels = 9 slots) then odd (2 pixels = 6
     // slots) — conv2's granules are packed in that order for this kernel (w2 = the handle's parity-ordered copy).
     unsigned char* tile1 = psmem + q.off_tile;
-    const int plane_px = (q.OW1 + 1) >> 1, plane_bytes = plane_px * 48, tile_pitch = 2 * plane_bytes;
+    const int plane_px = SPLIT ? q.w2p + 2 : (q.OW1 + 1) >> 1, plane_bytes = plane_px * 48, tile_pitch = 2 * plane_bytes;   // (a part's conv1 width is 2 w2p + 3)
     unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] bf16 (+ padding)
     u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + (wave & 7) * 128;   // conv2's output transpose: waves 0..7 only
     for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
@@ -1259,25 +1296,45 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
     const float inv_ow2 = 1.0f / (float)q.OW2;
-    const int row_in = q.IW * 3;                                            // bytes per frame row = values per band row
+    const int row_in = q.IW * 3;                                            // bytes per frame row
+    const int bpitch = SPLIT ? q.cpr * 16 : row_in;                         // values per row of the band image
     auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
         qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
         if (rm < 0) { --qt; rm += d; } else if (rm >= d) { ++qt; rm -= d; }
     };
-    auto geometry = [&](int wt, int& n, int& y2_0, int& r2, int& r1) {
-        n = wt / q.bands;
-        const int b = wt - n * q.bands;
-        y2_0 = b * q.R2; r2 = min(q.R2, q.OH2 - y2_0); r1 = 2 * (r2 - 1) + 5;
+    // item wt = (frame n, band of R2 conv2 rows from y2_0[, part of w2 conv2 columns from x2_0]); w1 = the part's conv1 columns
+    auto geometry = [&](int wt, int& n, int& y2_0, int& r2, int& r1, int& x2_0, int& w2, int& w1) {
+        if constexpr (SPLIT) {
+            const int per = q.bands * q.wsplit;
+            n = wt / per;
+            const int rem = wt - n * per, b = rem / q.wsplit, part = rem - b * q.wsplit;
+            y2_0 = b * q.R2; x2_0 = part * q.w2p; w2 = min(q.w2p, q.OW2 - x2_0); w1 = 2 * w2 + 3;
+        } else {
+            n = wt / q.bands;
+            const int b = wt - n * q.bands;
+            y2_0 = b * q.R2; x2_0 = 0; w2 = q.OW2; w1 = q.OW1;
+        }
+        r2 = min(q.R2, q.OH2 - y2_0); r1 = 2 * (r2 - 1) + 5;
     };
-    // the band of item wt: frame rows 4 b R2 .. + 2 r1 + 2, contiguous in the frame
+    // the band of item wt: frame rows 4 y2_0 .. + 2 r1 + 2 — whole rows are contiguous in the frame; a part takes 16 cpr bytes of each
+    // row from column 4 x2_0 on (what it reads past its own 2 w1 + 3 pixels is never used)
     auto request = [&](int wt, u4v (&raw)[kBandPf]) {
-        int n, y2_0, r2, r1;
-        geometry(wt, n, y2_0, r2, r1);
-        const int start = (n * q.IH + 4 * y2_0) * row_in, nchunk = ((2 * r1 + 3) * row_in) >> 4;
+        int n, y2_0, r2, r1, x2_0, w2, w1;
+        geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
+        if constexpr (SPLIT) {
+            const int start = ((n * q.IH + 4 * y2_0) * q.IW + 4 * x2_0) * 3, nchunk = (2 * r1 + 3) * q.cpr;
 #pragma unroll
-        for (int j = 0; j < kBandPf; ++j) {
-            const int c = (tid - 512) + j * 512;
-            raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + 16 * c : q.frames_bytes, 0, 0);   // past the end: zeros
+            for (int j = 0; j < kBandPf; ++j) {
+                const int c = (tid - 512) + j * 512, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
+                raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + row * row_in + 16 * kk : q.frames_bytes, 0, 0);   // past the end: zeros
+            }
+        } else {
+            const int start = (n * q.IH + 4 * y2_0) * row_in, nchunk = ((2 * r1 + 3) * row_in) >> 4;
+#pragma unroll
+            for (int j = 0; j < kBandPf; ++j) {
+                const int c = (tid - 512) + j * 512;
+                raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + 16 * c : q.frames_bytes, 0, 0);   // past the end: zeros
+            }
         }
     };
     auto unpack = [&](const u4v (&raw)[kBandPf]) {                           // 16 uint8 -> 16 bf16 (exact), 32 bytes of the band image
@@ -1297,7 +1354,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 
     // Waves 8..15 are the loaders: they have no conv2 tiles (and so no stores in their memory queue to wait behind), request a
     // band a whole item ahead and unpack it while waves 0..7 run conv2.
-    const int total = q.N * q.bands;
+    const int total = q.N * q.bands * (SPLIT ? q.wsplit : 1);
     const bool loader = wave >= 8;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);                // tile indices in scalar registers
     const unsigned magic1 = (unsigned)((0x100000000ull + (unsigned)q.OW1 - 1u) / (unsigned)q.OW1);   // floor(p / OW1) = umulhi(p, magic1) for p < 65536
@@ -1319,26 +1376,27 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
     while (wt < total) {
         const int nxt = wt + gridDim.x;                                     // uniform per workgroup
-        int n, y2_0, r2, r1;
-        geometry(wt, n, y2_0, r2, r1);
+        int n, y2_0, r2, r1, x2_0, w2, w1;
+        geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
+        const unsigned magic = SPLIT ? (w2 == q.w2p ? q.magic_full : q.magic_last) : magic1;
         // ---- phase 1: conv1 rows of the band, from the bf16 image ----
-        const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
+        const int npx1 = r1 * w1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1
         for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
             // the tile's first pixel splits into (row, column) on the scalar unit; a lane adds its r (OW1 >= 32: one wrap at most);
             // lanes past the band's last pixel compute it again (never stored)
-            const int p0 = t1 * 32, yl0 = (int)__umulhi((unsigned)p0, magic1), x0 = p0 - yl0 * q.OW1;
+            const int p0 = t1 * 32, yl0 = (int)__umulhi((unsigned)p0, magic), x0 = p0 - yl0 * w1;
             int x = x0 + r, yl = yl0;
-            if (x >= q.OW1) { x -= q.OW1; ++yl; }
-            if (p0 + r >= npx1) { yl = r1 - 1; x = q.OW1 - 1; }
-            const unsigned char* wbase = band + ((size_t)(2 * yl) * row_in + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
+            if (x >= w1) { x -= w1; ++yl; }
+            if (p0 + r >= npx1) { yl = r1 - 1; x = w1 - 1; }
+            const unsigned char* wbase = band + ((size_t)(2 * yl) * bpitch + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
             u4v xv[5];                                                      // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
 #pragma unroll
             for (int s6 = 0; s6 < 5; ++s6) {
-                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (size_t)s6 * row_in * 2);
+                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (size_t)s6 * bpitch * 2);
                 xv[s6] = u4v{src[0], src[1], src[2], src[3]};
             }
             __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
@@ -1364,8 +1422,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
         } else {
             // ---- phase 2: conv2 rows from the tile (waves 0..7: at most a handful of tiles per band) ----
-            const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
-            const int m0 = (n * q.OH2 + y2_0) * q.OW2;                      // first output pixel of the band (consecutive in memory)
+            const int npx2 = r2 * w2, ntile2 = (npx2 + 31) >> 5;
+            const int m0 = (n * q.OH2 + y2_0) * q.OW2 + x2_0;               // first output pixel of the band (a whole band is consecutive in memory)
+            const float inv_w2 = SPLIT ? 1.0f / (float)w2 : inv_ow2;
 #if TRS_FUSE_ABLATE != 2
             // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us; eight
             // waves of 256 registers with conv2's 40 weight fragments in registers — no weight reads from LDS at all — 100 -> 117 us:
@@ -1374,7 +1433,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             for (int t2 = wave; t2 < ntile2; t2 += 8) {
                 const int mm = min(t2 * 32 + r, npx2 - 1);
                 int yl2, x2;
-                divmod(mm, q.OW2, inv_ow2, yl2, x2);
+                divmod(mm, w2, inv_w2, yl2, x2);
                 const unsigned char* abase = tile1 + (size_t)(2 * yl2) * tile_pitch + (size_t)x2 * 48;   // even plane, conv1 row 2 yl2, pixel x2
                 f32x16 acc2[1];
 #pragma unroll
@@ -1391,7 +1450,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                         acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
                     }
                 }
-                store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
+                if constexpr (SPLIT) store_tile_rows(stage, acc2, lb2, q.c2, t2 * 32, npx2, w2, inv_w2, m0, q.OW2, lane);
+                else store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
             }
 #endif
         }
@@ -1967,10 +2027,15 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         q.frames = d_frames; q.frames_bytes = (int)in_bytes; q.N = n;
         q.c2.out = c->act[1]; q.c2.M = n * c->L[1].OH * c->L[1].OW;
         q.c2.nt_out = 0;
-        const int grid = std::max(1, std::min(n * q.bands, c->cu_count));
+        const int grid = std::max(1, std::min(n * q.bands * std::max(1, q.wsplit), c->cu_count));
         if (c->fuse_band) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
-            hipLaunchKernelGGL(trs_conv12_band_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+            if (q.wsplit > 1) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+                hipLaunchKernelGGL(trs_conv12_band_kernel<true>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+            } else {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+                hipLaunchKernelGGL(trs_conv12_band_kernel<false>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+            }
         } else {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
             hipLaunchKernelGGL(trs_conv12_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
@@ -2308,7 +2373,34 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * ((l0.OW + 1) / 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;   // two column-parity planes per row
             q.off_band = off; q.band_bytes = rows_in * row_in * 2 + 64; off += q.band_bytes;
             q.off_stage = off; off += 8 * 2048;
-            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
+            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; q.wsplit = 1; break; }
+        }
+        // the band cut in width (240x320: a whole-width band does not fit): parts of w2p conv2 columns, each with its own conv1 tile and
+        // staged frame-row segments (a part re-stages 2 x 3 + 3 input columns and recomputes 3 conv1 columns of its neighbour)
+        int max_split = 4;
+        if (const char* e = std::getenv("TRS_PILOT_FUSE_WSPLIT")) max_split = std::atoi(e);          // 1 = never cut in width
+        for (int ws = 2; shape_ok && !c->fuse12 && band_r2 > 0 && ws <= max_split; ++ws) {
+            const int w2p = (l1.OW + ws - 1) / ws, w2_last = l1.OW - (ws - 1) * w2p, w1m = 2 * w2p + 3, w1_last = 2 * w2_last + 3;
+            if (w2_last < 15 || w1m * 19 >= 65536) continue;
+            const int cpr = ((2 * w1m + 3) * 3 + 15) / 16;
+            for (int r2 = std::min(band_r2, l1.OH); r2 >= std::min(4, l1.OH); --r2) {
+                const int rows_in = 2 * (2 * r2 + 3) + 3;
+                if (rows_in * cpr > kBandPf * 512) continue;
+                int off = 12 * 32 * 16;
+                q.off_w2 = off; off += 80 * 32 * 16;
+                q.off_b = off; off += 16 * 16;
+                q.off_goff = off; off += 64;
+                q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * (w2p + 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;
+                q.off_band = off; q.band_bytes = rows_in * cpr * 32 + 64; off += q.band_bytes;
+                q.off_stage = off; off += 8 * 2048;
+                if (off > 160 * 1024) continue;
+                c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2;
+                q.wsplit = ws; q.w2p = w2p; q.cpr = cpr;
+                q.magic_full = (unsigned)((0x100000000ull + (unsigned)w1m - 1u) / (unsigned)w1m);
+                q.magic_last = (unsigned)((0x100000000ull + (unsigned)w1_last - 1u) / (unsigned)w1_last);
+                q.magic_cpr = (unsigned)((0x100000000ull + (unsigned)cpr - 1u) / (unsigned)cpr);
+                break;
+            }
         }
         for (int r2 = std::min(want_r2, l1.OH); shape_ok && !c->fuse12 && r2 >= 1; --r2) {
             int off = 12 * 32 * 16;
