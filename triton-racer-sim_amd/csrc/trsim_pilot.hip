@@ -912,6 +912,7 @@ struct Frame5Params {
     const float* bias;
     unsigned short* out;       // bf16 NHWC [N][OH][OW][64]
     int N, IH, IW, OH, OW, F, ev, COUT;   // ev = even columns per row = (IW + 1) / 2
+    int bands, ohb, ihb;                  // a frame that does not fit LDS is cut into `bands` bands of ohb output rows = ihb = 2 ohb + 3 input rows (bands == 1: ohb = OH, ihb = IH)
 };
 
 template <int NT, int R, int BLOCK, int MINB>
@@ -923,8 +924,9 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nwaves = BLOCK / 64;
     const int r = lane & 31, h = lane >> 5;
-    const int u0 = blockIdx.x * p.F, nu = min(p.F, p.N - u0);
-    const int upix = p.IH * p.IW, uout = p.OH * p.OW;
+    const int n_units = p.N * p.bands;
+    const int u0 = blockIdx.x * p.F, nu = min(p.F, n_units - u0);
+    const int upix = p.ihb * p.IW, uout = p.ohb * p.OW;                     // input pixels staged / output pixel slots per unit
     {   // staging: slot sl = 4 * lpix + q holds granule q ^ ((lpix >> 2) & 3) of the pixel that lives in slot lpix
         const int total = nu * upix * 4;
         const unsigned lds_base = (unsigned)(uintptr_t)psmem;
@@ -932,9 +934,11 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
             const int sl = s0 + lane;
             if (sl < total) {
                 const int lpix = sl >> 2, g = (sl & 3) ^ ((lpix >> 2) & 3);
-                const int ul = lpix / upix, rp = lpix - ul * upix, iy = rp / p.IW, s = rp - iy * p.IW;
+                const int ul = lpix / upix, rp = lpix - ul * upix, iyl = rp / p.IW, s = rp - iyl * p.IW;
                 const int col = s < p.ev ? 2 * s : 2 * (s - p.ev) + 1;
-                const size_t gpix = ((size_t)(u0 + ul) * p.IH + iy) * p.IW + col;
+                const int u = u0 + ul, f = u / p.bands, band = u - f * p.bands;
+                const int iy = min(2 * band * p.ohb + iyl, p.IH - 1);         // (rows below the frame are never read by a valid pixel)
+                const size_t gpix = ((size_t)f * p.IH + iy) * p.IW + col;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + gpix * 4 + g),
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
             }
@@ -948,13 +952,15 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
     const float4* lbias = reinterpret_cast<const float4*>(psmem + (size_t)p.F * upix * 64);
     const int m_wg = nu * uout, n_tiles = (m_wg + NT * 32 - 1) / (NT * 32);
     for (int item = wave; item < n_tiles; item += nwaves) {
-        int lbase[NT], mo[NT];
+        int lbase[NT];
+        long long mo[NT];                                                   // output pixel index in the layer's activation, -1 = no such pixel
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int m = item * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-            const int ul = mc / uout, rem = mc - ul * uout, oy = rem / p.OW, ox = rem - oy * p.OW;
-            lbase[nt] = (ul * p.IH + 2 * oy) * p.IW + ox;                   // slot of input pixel (2 oy, 2 ox): even plane, position ox
-            mo[nt] = m < m_wg ? m : -1;
+            const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
+            const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
+            lbase[nt] = (ul * p.ihb + 2 * oyl) * p.IW + ox;                 // slot of input pixel (2 oyl, 2 ox) of the unit: even plane, position ox
+            mo[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
         }
         const u4v* wl = p.w + r;
         u4v ring[R][NB];
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            unsigned short* o = p.out + ((size_t)u0 * uout + (mo[nt] < 0 ? 0 : mo[nt])) * COUT;
+            unsigned short* o = p.out + (size_t)(mo[nt] < 0 ? 0 : mo[nt]) * COUT;
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 uint2 w[4];
@@ -1826,7 +1832,7 @@ struct ConvLayer {
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
     bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
     bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
-    bool frame5 = false; int frame5_f = 1, frame5_lds = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, input frames in LDS)
+    bool frame5 = false; int frame5_f = 1, frame5_lds = 0, frame5_bands = 1, frame5_ohb = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, input frames in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -1915,13 +1921,15 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         Frame5Params q{};
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = l.frame5_f; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
+        q.bands = l.frame5_bands; q.ohb = l.frame5_ohb; q.ihb = l.frame5_bands == 1 ? l.IH : 2 * l.frame5_ohb + 3;
+        const int n_units = n_img * q.bands;
 #define LAUNCH_F5(NT_, BLOCK_, MINB_, GRID_)                                                                                  \
     do {                                                                                                                      \
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), dim3(GRID_), dim3(BLOCK_), l.frame5_lds, s, q);  \
     } while (0)
-        if (q.F == 1) LAUNCH_F5(2, 256, 2, n_img);                          // one frame per workgroup, two workgroups per CU
-        else LAUNCH_F5(2, 512, 1, (n_img + q.F - 1) / q.F);
+        if (q.F == 1) LAUNCH_F5(2, 256, 2, n_units);                        // one unit per workgroup, two workgroups per CU
+        else LAUNCH_F5(2, 512, 1, (n_units + q.F - 1) / q.F);
 #undef LAUNCH_F5
         HIPCHK(hipGetLastError());
         return TRS_OK;
@@ -2260,6 +2268,11 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 // a frame larger than ~110 KB is cut into row bands (conv7 at 240x320: 21 x 31 x 128 = 167 KB -> 2 bands of 10 / 9 rows)
                 int bands = 1;
                 while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
+                if (const char* e = std::getenv("TRS_PILOT_FRAME_BANDS")) {       // tuning hook: "b4,b5,b6,b7" (0 = automatic)
+                    int b[4] = {0, 0, 0, 0};
+                    std::sscanf(e, "%d,%d,%d,%d", &b[0], &b[1], &b[2], &b[3]);
+                    if (b[i - 3] > 0) bands = std::max(bands, std::min(b[i - 3], l.OH));
+                }
                 const int ohb = (l.OH + bands - 1) / bands, ihb = ohb + l.KH - 1;
                 const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
                 // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
@@ -2274,12 +2287,22 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         if (i == 2) {            // conv3: frames in LDS when two fit (120x160: 2 x 64 KB); TRS_PILOT_FRAME5 = 0: the span kernel
             int on = 1;
             if (const char* e = std::getenv("TRS_PILOT_FRAME5")) on = std::atoi(e);
-            const size_t unit = (size_t)l.IH * l.IW * 64;
             const bool shape_ok = l.KH == 5 && l.KW == 5 && l.S == 2 && l.CIN == 32 && l.COUT == 64 && l.COUT_PAD == 64 && run_pad == 20 && l.G_pad == 100;
+            // a frame larger than ~78 KB is cut into row bands (240x320: 57 x 77 x 32 = 281 KB -> 5 bands of 6 output rows = 15 input rows, 74 KB:
+            // two workgroups of one band per CU)
+            int bands = 1;
+            while (bands < l.OH && (size_t)(bands == 1 ? l.IH : 2 * ((l.OH + bands - 1) / bands) + 3) * l.IW * 64 > 78 * 1024) ++bands;
+            if (const char* e = std::getenv("TRS_PILOT_FRAME5_BANDS")) bands = std::max(bands, std::min(std::atoi(e), l.OH));
+            const int ohb = (l.OH + bands - 1) / bands, ihb = bands == 1 ? l.IH : 2 * ohb + 3;
+            const size_t unit = (size_t)ihb * l.IW * 64;
             int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
-            while (f > 1 && (c->n_cap + f - 1) / f < c->cu_count) --f;
+            if (bands > 1) f = std::min(f, 1);
+            while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
             if (const char* e = std::getenv("TRS_PILOT_FRAME5_F")) f = std::max(1, std::min(f, std::atoi(e)));
-            if (on && shape_ok && f >= 1) { l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; }
+            // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; TRS_PILOT_FRAME5 = 2 forces bands)
+            if (on && (bands == 1 || on >= 2) && shape_ok && f >= 1 && f * unit + 256 <= 158 * 1024) {
+                l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
+            }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
         const int ai = i == 8 ? 34 : 2 * i;                               // dense4 of the full-house model
