@@ -354,15 +354,15 @@ def main():
             line["also"] = also
         if args.pilot:
             # closed loop with the CNN: the convolutions dominate (MFMA-bound class); the device time of a step spans
-            # the env launch, 8 conv/dense launches and the tail, so the figure below is a whole-step rate, a lower bound
+            # the env launch, the conv / dense launches and the tail, so the figure below is a whole-step rate, a lower bound
             # on the conv kernels' own rate
             tf = pilot_flops * n * args.steps / (kernel_ms * 1e-3) / 1e12
             line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
             line["dtype"] += " / bf16 MFMA convolutions, f32 accumulate"
             line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
-                                "traffic": None, "kernel": "trs_conv12_band_kernel / trs_conv12_kernel (conv1 + conv2 fused) + trs_conv_span_kernel + 4 x trs_conv_lt_kernel + trs_conv_mfma_kernel (dense1) + trs_step_kernel + trs_pilot_tail_kernel per step",
+                                "traffic": None, "kernel": "per step: trs_step_kernel + trs_conv12_band_kernel (conv1 + conv2 fused) + trs_conv_frame5_kernel (conv3) + trs_conv_chain_kernel (conv4..7 in one launch) + trs_pilot_dense_kernel (dense1) + trs_pilot_tail_kernel at 120x160; frames too large for LDS: trs_conv_span_kernel (conv3) and one trs_conv_frame_kernel launch per 3x3 layer",
                                 "flops_per_frame": pilot_flops, "avg_step_us": round(kernel_ms * 1e3 / args.steps, 3),
-                                "note": "whole closed-loop step by HIP events; per-layer times in profiles/r01_pilot_conv_v2.txt"}
+                                "note": "whole closed-loop step by HIP events; per-layer times in profiles/r02_pilot_final.txt"}
         if gathered is not None:
             line["config"]["allgather_returns_mean"] = round(float(gathered.mean().item()), 4)
         if world == 1 and not args.no_cpu_baseline:
