@@ -1274,7 +1274,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
 // thread, requested one item ahead so that its latency hides behind conv1 of the current item), unpacks them once into a bf16
 // image in LDS, and conv1 reads its k-steps (8 consecutive values, 4-byte aligned) from there with two ds_read2_b32.
 // Same values into the same MFMA order: bit-identical to the kernel above and to the separate layers.
-constexpr int kBandPf = 4;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads)
+constexpr int kBandPf = 2;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads; 4 until round 2:
+                                                                            // the 8 registers now hold conv1's bias)
 template <bool SPLIT>
 __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Params q)
 {
@@ -1380,6 +1381,13 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
 #pragma unroll
     for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
+    // ... and so does its bias (couts 8 qd + 4 h .. + 3): three broadcast ds_read_b128 per tile were 0.9 of the 3.2 thousand LDS clocks
+    // of a band's conv1 phase (SQ_LDS_IDX_ACTIVE of the phase builds, profiles/r02_pilot_pmc.txt)
+    float4 bb1[3];
+#pragma unroll
+    for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
+#pragma unroll
+    for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
     while (wt < total) {
         const int nxt = wt + gridDim.x;                                     // uniform per workgroup
         int n, y2_0, r2, r1, x2_0, w2, w1;
@@ -1413,7 +1421,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)yl * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
-                    const float4 bb = lb1[2 * qd + h];
+                    const float4 bb = bb1[qd];
                     float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
                     dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
                 }
