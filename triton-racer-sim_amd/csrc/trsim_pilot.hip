@@ -720,6 +720,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
 struct ChainLayer {
     const u4v* w; const float* bias;
     int IH, IW, OH, OW, COUT, cg, cgs;     // COUT == COUT_PAD (64 / 128); cg = input granules per pixel (8 / 16), cgs = log2
+    int nt;                                // 32-pixel tiles per wave item: 2 or 3, whichever leaves the busiest SIMD fewer MFMAs (3 also streams 1/3 less weights)
 };
 struct ChainParams {
     const u4v* in;             // the first layer's input activation, bf16 NHWC
@@ -732,11 +733,11 @@ struct ChainParams {
 #ifndef TRS_CHAIN_ABLATE
 #define TRS_CHAIN_ABLATE 0   /* timing-only diagnostic builds of the chain's layers, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no MFMA */
 #endif
-template <int HALF, int R>
+template <int HALF, int R, int NT>
 __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
                                             unsigned short* gout, int wave, int nwaves, int lane)
 {
-    constexpr int NT = 2, NB = 2;
+    constexpr int NB = 2;
     const int r = lane & 31, h = lane >> 5;
     const int uout = L.OH * L.OW, m_wg = nu * uout;
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = L.COUT / (NB * 32);
@@ -876,7 +877,10 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
             if (cnt > 0) stage(L0, u0 + per * pass, cnt, lds0 + p.offB);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (cnt > 0) chain_layer<4, TRS_CHAIN_R>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+            if (cnt > 0) {
+                if (L0.nt == 3) chain_layer<4, TRS_CHAIN_R, 3>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+                else chain_layer<4, TRS_CHAIN_R, 2>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+            }
             __syncthreads();
         }
         li = 1;
@@ -888,13 +892,15 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     for (; li < p.nl - 1; ++li) {
         const ChainLayer& L = p.L[li];
         u4v* const nxt = cur == A ? B : A;
-        chain_layer<4, TRS_CHAIN_R>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        if (L.nt == 3) chain_layer<4, TRS_CHAIN_R, 3>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        else chain_layer<4, TRS_CHAIN_R, 2>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
         __syncthreads();
         cur = nxt;
     }
     {
         const ChainLayer& L = p.L[p.nl - 1];
-        chain_layer<8, TRS_CHAIN_R>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
+        if (L.nt == 3) chain_layer<8, TRS_CHAIN_R, 3>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
+        else chain_layer<8, TRS_CHAIN_R, 2>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
     }
 }
 
@@ -2484,7 +2490,12 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 q.F = f; q.nl = nl; q.split_first = split ? 1 : 0; q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
                 for (int j = 0; j < nl; ++j) {
                     const ConvLayer& l = c->L[first + j];
-                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4};
+                    // tile height per layer: items = ceil(pixels / (32 nt)) x (COUT / 64) over 8 waves = 4 SIMDs; the busiest SIMD's MFMA count decides
+                    const int px = (split && j == 0 ? f / 2 : f) * l.OH * l.OW, cgrps = l.COUT / 64;
+                    auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
+                    int nt = busiest(3) <= busiest(2) ? 3 : 2;
+                    if (const char* e = std::getenv("TRS_PILOT_CHAIN_NT")) { const int v = std::atoi(e); if (v == 2 || v == 3) nt = v; }
+                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt};
                 }
                 c->chain_first = first; c->chain_lds = (int)total;
             }
