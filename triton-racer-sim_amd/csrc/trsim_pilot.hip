@@ -1955,13 +1955,19 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
         q.bands = l.frame_bands; q.ohb = l.frame_ohb; q.ihb = l.frame_ohb + l.KH - 1;
         const int grid = (n_img * q.bands + q.F - 1) / q.F;
-#define LAUNCH_FRAME(HALF_, R_, BLOCK_)                                                                                       \
+#define LAUNCH_FRAME(NT_, HALF_, R_, BLOCK_)                                                                                  \
     do {                                                                                                                      \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<2, 2, HALF_, R_, BLOCK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((trs_conv_frame_kernel<2, 2, HALF_, R_, BLOCK_>), dim3(grid), dim3(BLOCK_), l.frame_lds, s, q);    \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<NT_, 2, HALF_, R_, BLOCK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((trs_conv_frame_kernel<NT_, 2, HALF_, R_, BLOCK_>), dim3(grid), dim3(BLOCK_), l.frame_lds, s, q);  \
     } while (0)
-        if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(4, 12, 512); else LAUNCH_FRAME(4, 4, 512); }
-        else { if (l.frame_deep) LAUNCH_FRAME(8, 8, 512); else LAUNCH_FRAME(8, 4, 512); }
+        // 32-pixel tiles per wave item: 2, or 3 where that leaves the busiest SIMD no more MFMAs (3 streams a third less weights through L1)
+        const int px = std::min(q.F, n_img * q.bands) * q.ohb * q.OW, cgrps = q.COUT_PAD / 64;
+        auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
+        int nt = busiest(3) <= busiest(2) ? 3 : 2;
+        if (const char* e = std::getenv("TRS_PILOT_FRAME_NT")) { const int v = std::atoi(e); if (v == 2 || v == 3) nt = v; }
+        if (l.frame_deep) nt = 2;
+        if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(2, 4, 12, 512); else if (nt == 3) LAUNCH_FRAME(3, 4, 4, 512); else LAUNCH_FRAME(2, 4, 4, 512); }
+        else { if (l.frame_deep) LAUNCH_FRAME(2, 8, 8, 512); else if (nt == 3) LAUNCH_FRAME(3, 8, 4, 512); else LAUNCH_FRAME(2, 8, 4, 512); }
 #undef LAUNCH_FRAME
         HIPCHK(hipGetLastError());
         return TRS_OK;
