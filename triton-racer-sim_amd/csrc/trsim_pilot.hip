@@ -1331,37 +1331,37 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     };
     // the band of item wt: frame rows 4 y2_0 .. + 2 r1 + 2 — whole rows are contiguous in the frame; a part takes 16 cpr bytes of each
     // row from column 4 x2_0 on (what it reads past its own 2 w1 + 3 pixels is never used)
-    auto request = [&](int wt, u4v (&raw)[kBandPf]) {
+    // A loader thread moves HALF chunks (8 frame bytes -> 16 bytes of the image): consecutive lanes then write consecutive 16-byte
+    // slots (whole chunks per lane put the two ds_write_b128 of a lane 32 bytes apart: a 2-way bank conflict on every write)
+    auto request = [&](int wt, uint2 (&raw)[2 * kBandPf]) {
         int n, y2_0, r2, r1, x2_0, w2, w1;
         geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
         if constexpr (SPLIT) {
             const int start = ((n * q.IH + 4 * y2_0) * q.IW + 4 * x2_0) * 3, nchunk = (2 * r1 + 3) * q.cpr;
 #pragma unroll
-            for (int j = 0; j < kBandPf; ++j) {
-                const int c = (tid - 512) + j * 512, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
-                raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + row * row_in + 16 * kk : q.frames_bytes, 0, 0);   // past the end: zeros
+            for (int j = 0; j < 2 * kBandPf; ++j) {
+                const int hc = (tid - 512) + j * 512, c = hc >> 1, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
+                raw[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rin, c < nchunk ? start + row * row_in + 16 * kk + 8 * (hc & 1) : q.frames_bytes, 0, 0));   // past the end: zeros
             }
         } else {
             const int start = (n * q.IH + 4 * y2_0) * row_in, nchunk = ((2 * r1 + 3) * row_in) >> 4;
 #pragma unroll
-            for (int j = 0; j < kBandPf; ++j) {
-                const int c = (tid - 512) + j * 512;
-                raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, c < nchunk ? start + 16 * c : q.frames_bytes, 0, 0);   // past the end: zeros
+            for (int j = 0; j < 2 * kBandPf; ++j) {
+                const int hc = (tid - 512) + j * 512;
+                raw[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rin, (hc >> 1) < nchunk ? start + 8 * hc : q.frames_bytes, 0, 0));   // past the end: zeros
             }
         }
     };
-    auto unpack = [&](const u4v (&raw)[kBandPf]) {                           // 16 uint8 -> 16 bf16 (exact), 32 bytes of the band image
+    auto unpack = [&](const uint2 (&raw)[2 * kBandPf]) {                     // 8 uint8 -> 8 bf16 (exact), 16 bytes of the band image
 #pragma unroll
-        for (int j = 0; j < kBandPf; ++j) {
-            const int c = (tid - 512) + j * 512;
-            if (c * 32 + 32 > q.band_bytes) continue;
+        for (int j = 0; j < 2 * kBandPf; ++j) {
+            const int hc = (tid - 512) + j * 512;
+            if (hc * 16 + 16 > q.band_bytes) continue;
             auto pair = [](unsigned w, int k) -> unsigned {
                 const float f0 = (float)((w >> (8 * k)) & 255u), f1 = (float)((w >> (8 * k + 8)) & 255u);
                 return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
             };
-            u4v* dst = reinterpret_cast<u4v*>(band + (size_t)c * 32);
-            dst[0] = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
-            dst[1] = u4v{pair(raw[j].z, 0), pair(raw[j].z, 2), pair(raw[j].w, 0), pair(raw[j].w, 2)};
+            *reinterpret_cast<u4v*>(band + (size_t)hc * 16) = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
         }
     };
 
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);                // tile indices in scalar registers
     const unsigned magic1 = (unsigned)((0x100000000ull + (unsigned)q.OW1 - 1u) / (unsigned)q.OW1);   // floor(p / OW1) = umulhi(p, magic1) for p < 65536
     int wt = blockIdx.x;
-    u4v raw[kBandPf];
+    uint2 raw[2 * kBandPf];
     if (loader && wt < total) request(wt, raw);
     __syncthreads();                                                        // weights staged, tile and band zeroed
     if (loader && wt < total) {
