@@ -1424,6 +1424,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             for (int s6 = 0; s6 < 5; ++s6)                                  // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[s6]), acc, 0, 0, 0);
             if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
+                // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
+                // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
+                // its selects cost more than the conflict; the same swap instead of ds_bpermute_b32 in the frame kernels' epilogues: no change)
                 uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)yl * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
