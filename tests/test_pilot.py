@@ -314,7 +314,7 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
         assert np.max(np.abs(fused_out - plain_out)) <= 2e-2
 
 
-@pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5)])
+@pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5), ((120, 160), 1)])
 def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch):
     """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution
     kernel (TRS_PILOT_DENSE = 0): the same bf16 products, K split differently — fp32 summation order only.  n is not a multiple
@@ -340,10 +340,10 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch)
     assert np.max(np.abs(h1s["1"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
     assert np.max(np.abs(h1s["0"] - h1s["1"])) <= 1e-3 * max(1.0, float(np.abs(h1s["0"]).max()))
     assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-4
-    assert np.std(outs["1"][:, 0]) > 1e-5
+    assert n == 1 or np.std(outs["1"][:, 0]) > 1e-5
 
 
-@pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 6)])
+@pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 6), ((120, 160), 1)])
 @pytest.mark.parametrize("layers", ["4", "3"])
 def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, layers, monkeypatch):
     """conv4..conv7 (or conv5..conv7) in one launch with the activations in LDS (trs_conv_chain_kernel) against one launch per
@@ -368,7 +368,7 @@ def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, lay
         res[mode] = [out] + [env.pilot_layer(i, shapes[i]) for i in (6, 5, 4, 3, 2)]
     for a, b in zip(res["0"], res[layers]):
         assert np.array_equal(a, b)
-    assert np.std(res[layers][0][:, 0]) > 1e-5
+    assert n == 1 or np.std(res[layers][0][:, 0]) > 1e-5
 
 
 @pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 11)])
