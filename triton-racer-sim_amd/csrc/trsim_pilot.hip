@@ -1726,10 +1726,26 @@ struct TailExParams {
 };
 
 __device__ __forceinline__ void dense_small(const float* in, int nin, const float* w, const float* b, int nout, float* out, int lane, bool relu)
-{   // out[o] = act(b[o] + sum_k in[k] * w[k][o]), lanes over o (nout <= 128)
+{   // out[o] = act(b[o] + sum_k in[k] * w[k][o]), lanes over o (nout <= 128).  One FMA chain per output, k ascending; the weights of 16 k
+    // are requested together (a load in front of every FMA made this the slowest kernel of the full-house loop: one L2 round trip per k)
     for (int o = lane; o < nout; o += 64) {
         float s = b[o];
-        for (int k = 0; k < nin; ++k) s = fmaf(in[k], w[k * nout + o], s);
+        int k = 0;
+        for (; k + 16 <= nin; k += 16) {
+            float wv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wv[j] = w[(k + j) * nout + o];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s = fmaf(in[k + j], wv[j], s);
+        }
+        for (; k + 4 <= nin; k += 4) {
+            float wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = w[(k + j) * nout + o];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = fmaf(in[k + j], wv[j], s);
+        }
+        for (; k < nin; ++k) s = fmaf(in[k], w[k * nout + o], s);
         out[o] = relu ? (s > 0.f ? s : 0.f) : s;
     }
 }
@@ -1771,9 +1787,31 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_ex_kernel(const TailExPara
         const float* wy = B + p.xo[head ? XO_W4Y : XO_W1Y];
         for (int o = lane; o < 100; o += 64) {
             float x = 0.0f;
-            for (int sl = 0; sl < slices; ++sl) x += slab[(size_t)sl * stride + (size_t)i * 100 + o];
-            for (int k = 0; k < p.f3; ++k) x = fmaf(sy[wv][2][k], wy[k * 100 + o], x);
-            if (head) for (int k = 0; k < p.f3; ++k) x = fmaf(ss[wv][2][k], wy[(p.f3 + k) * 100 + o], x);
+            {   // the K-slice slabs in slice order, eight loads in flight
+                int sl = 0;
+                for (; sl + 8 <= slices; sl += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = slab[(size_t)(sl + j) * stride + (size_t)i * 100 + o];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x += v[j];
+                }
+                for (; sl < slices; ++sl) x += slab[(size_t)sl * stride + (size_t)i * 100 + o];
+            }
+            for (int k = 0; k < p.f3; k += 4) {                             // f3 is 16 or 64
+                float w4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = wy[(k + j) * 100 + o];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x = fmaf(sy[wv][2][k + j], w4[j], x);
+            }
+            if (head) for (int k = 0; k < p.f3; k += 4) {
+                float w4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = wy[(p.f3 + k + j) * 100 + o];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x = fmaf(ss[wv][2][k + j], w4[j], x);
+            }
             sh[wv][head][o] = x > 0.f ? x : 0.f;
         }
     }
