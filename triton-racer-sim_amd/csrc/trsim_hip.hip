@@ -573,23 +573,35 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
 // frame; LDS holds the trimmed frame (H*W*3 B), the gradient magnitudes with a zero border ((H+2)*(W+2) int16) and the
 // edge map (H*W B: winning channel, then 0 = weak / 1 = no / 2 = edge).  Hysteresis = repeated 8-neighbour sweeps until
 // a block-wide OR reports no change.  Frames up to ~26,000 pixels (LDS); bound: LDS latency, not HBM.
-constexpr int kEdgeBlock = 512;
+constexpr int kEdgeBlock = 1024;          // 16 waves per frame (512 until round 2: the phases are latency chains of LDS reads, twice the waves hide twice as much)
 
-__device__ __forceinline__ int edge_px(const unsigned char* simg, int H, int W, int y, int x, int c)
+// Six pixels x three channels of frame row `row` around the 4-pixel group at column x0 (pixels x0 - 1 .. x0 + 4, replicated at the
+// frame's left / right edge) from five aligned dword reads (the first version read every byte on its own: 27 LDS reads per pixel
+// for the three Sobels, the kernel was bound by LDS instruction issue).  x0 % 4 == 0, so the group starts on a dword.
+__device__ __forceinline__ void edge_row(const unsigned char* simg, int W, int row, int x0, int (&v)[3][6])
 {
-    y = y < 0 ? 0 : (y >= H ? H - 1 : y);
-    x = x < 0 ? 0 : (x >= W ? W - 1 : x);
-    return simg[(y * W + x) * 3 + c];
+    const unsigned* base = reinterpret_cast<const unsigned*>(simg + ((size_t)row * W + x0) * 3);
+    unsigned d[5];
+    d[0] = x0 ? base[-1] : 0u;
+    d[1] = base[0]; d[2] = base[1]; d[3] = base[2]; d[4] = base[3];           // base[3] past the row's last group is read but not used (see below)
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int bi = 1 + 3 * j + c;                                     // byte of the 20-byte window that starts 4 bytes in front of the group
+            v[c][j] = (int)((d[bi >> 2] >> (8 * (bi & 3))) & 255u);
+        }
+    if (x0 == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][0] = v[c][1];
+    }
+    if (x0 + 4 >= W) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][5] = v[c][4];
+    }
 }
 
-__device__ __forceinline__ void edge_sobel(const unsigned char* simg, int H, int W, int y, int x, int c, int& dx, int& dy)
-{
-    const int a = edge_px(simg, H, W, y - 1, x - 1, c), b = edge_px(simg, H, W, y - 1, x, c), d = edge_px(simg, H, W, y - 1, x + 1, c);
-    const int e = edge_px(simg, H, W, y, x - 1, c), f = edge_px(simg, H, W, y, x + 1, c);
-    const int g = edge_px(simg, H, W, y + 1, x - 1, c), h = edge_px(simg, H, W, y + 1, x, c), i = edge_px(simg, H, W, y + 1, x + 1, c);
-    dx = (d + 2 * f + i) - (a + 2 * e + g);
-    dy = (g + 2 * h + i) - (a + 2 * b + d);
-}
+__device__ __forceinline__ bool has_zero_byte(unsigned w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; }
 
 // SCRATCH = false: the three whole-frame work arrays live in LDS (frames up to ~26,000 pixels).  SCRATCH = true: they live in
 // a per-workgroup global scratch that stays in L2 (any frame size, e.g. config 5's 240x320); only the tables are in
@@ -602,8 +614,8 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     short* const mag = reinterpret_cast<short*>(work + p.off_mag);
     unsigned char* const map = work + p.off_map;
     int* const s_tab = reinterpret_cast<int*>(smem + p.off_tab);
-    unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [8][3]
-    float* const s_delta = reinterpret_cast<float*>(s_part + 24);
+    unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [kEdgeBlock / 64][3]
+    float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = p.H, W = p.W, MW = W + 2, npx = H * W;
     const size_t frame_bytes = (size_t)p.gpe * 12;
@@ -654,47 +666,72 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
             d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
         }
         __syncthreads();
-        // ---- Sobel per channel, the channel with the largest |dx| + |dy| wins (first on ties) ----
-        for (int px = tid; px < npx; px += kEdgeBlock) {
-            const int y = px / W, x = px - y * W;
-            int bn = -1, bc = 0;
+        // ---- Sobel per channel, the channel with the largest |dx| + |dy| wins (first on ties); a thread takes 4-pixel groups ----
+        // mag <- the winner's norm, map <- its gradient direction class for the non-maximum suppression (OpenCV's fixed-point
+        // tangents: 0 = compare left / right, 1 = up / down, 2 / 3 = the two diagonals), so that the suppression needs no second Sobel
+        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
+            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 4;
+            int vt[3][6], vm[3][6], vb[3][6];
+            edge_row(simg, W, y > 0 ? y - 1 : 0, x0, vt);
+            edge_row(simg, W, y, x0, vm);
+            edge_row(simg, W, y + 1 < H ? y + 1 : H - 1, x0, vb);
+            unsigned cls4 = 0u;
+            short* mrow = mag + (y + 1) * MW + x0 + 1;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                int dx, dy;
-                edge_sobel(simg, H, W, y, x, c, dx, dy);
-                const int nrm = abs(dx) + abs(dy);
-                if (nrm > bn) { bn = nrm; bc = c; }
-            }
-            mag[(y + 1) * MW + x + 1] = (short)bn;
-            map[px] = (unsigned char)bc;
-        }
-        __syncthreads();
-        // ---- non-maximum suppression + double threshold ----
-        for (int px = tid; px < npx; px += kEdgeBlock) {
-            const int y = px / W, x = px - y * W;
-            const short* m0 = mag + (y + 1) * MW + x + 1;
-            const int m = *m0;
-            bool ismax = false;
-            if (m > p.edge_low) {
-                int xs, ys;
-                edge_sobel(simg, H, W, y, x, map[px], xs, ys);
-                const int ax = abs(xs), ay = abs(ys) << 15;
-                const int tg22x = ax * 13573;
-                if (ay < tg22x) ismax = m > m0[-1] && m >= m0[1];
-                else {
-                    const int tg67x = tg22x + (ax << 16);
-                    if (ay > tg67x) ismax = m > m0[-MW] && m >= m0[MW];
-                    else { const int sgn = (xs ^ ys) < 0 ? -1 : 1; ismax = m > m0[-MW - sgn] && m > m0[MW + sgn]; }
+            for (int q = 0; q < 4; ++q) {
+                const int j = q + 1;
+                int bn = -1, xs = 0, ys = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int dx = (vt[c][j + 1] + 2 * vm[c][j + 1] + vb[c][j + 1]) - (vt[c][j - 1] + 2 * vm[c][j - 1] + vb[c][j - 1]);
+                    const int dy = (vb[c][j - 1] + 2 * vb[c][j] + vb[c][j + 1]) - (vt[c][j - 1] + 2 * vt[c][j] + vt[c][j + 1]);
+                    const int nrm = abs(dx) + abs(dy);
+                    if (nrm > bn) { bn = nrm; xs = dx; ys = dy; }
                 }
+                const int ax = abs(xs), ay = abs(ys) << 15, tg22x = ax * 13573;
+                int cls;
+                if (ay < tg22x) cls = 0;
+                else if (ay > tg22x + (ax << 16)) cls = 1;
+                else cls = ((xs ^ ys) < 0) ? 3 : 2;
+                mrow[q] = (short)bn;
+                cls4 |= (unsigned)cls << (8 * q);
             }
-            map[px] = ismax ? (m > p.edge_high ? 2 : 0) : 1;
+            *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = cls4;
         }
         __syncthreads();
-        // ---- hysteresis: weak pixels 8-connected to an edge become edges; sweep until nothing changes ----
-        for (int iter = 0; iter < npx; ++iter) {
-            int changed = 0;
-            for (int px = tid; px < npx; px += kEdgeBlock) {
-                if (map[px] != 0) continue;
+        // ---- non-maximum suppression + double threshold: map <- 0 = weak / 1 = no / 2 = edge ----
+        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
+            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 4;
+            int m3[3][6];                                                    // magnitudes of rows y - 1 .. y + 1, columns x0 - 1 .. x0 + 4 (zero border)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const unsigned* mr = reinterpret_cast<const unsigned*>(mag + (y + rr) * MW + x0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const unsigned w = mr[k]; m3[rr][2 * k] = (int)(w & 0xFFFFu); m3[rr][2 * k + 1] = (int)(w >> 16); }
+            }
+            const unsigned cls4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
+            unsigned out4 = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = q + 1, m = m3[1][j], cls = (int)((cls4 >> (8 * q)) & 255u);
+                bool ismax = false;
+                if (m > p.edge_low) {
+                    if (cls == 0) ismax = m > m3[1][j - 1] && m >= m3[1][j + 1];
+                    else if (cls == 1) ismax = m > m3[0][j] && m >= m3[2][j];
+                    else if (cls == 2) ismax = m > m3[0][j - 1] && m > m3[2][j + 1];
+                    else ismax = m > m3[0][j + 1] && m > m3[2][j - 1];
+                }
+                out4 |= (unsigned)(ismax ? (m > p.edge_high ? 2 : 0) : 1) << (8 * q);
+            }
+            *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = out4;
+        }
+        __syncthreads();
+        // ---- hysteresis: weak pixels 8-connected to an edge become edges.  A thread owns a contiguous run of pixels and walks it
+        // forwards, then backwards: a chain along a row closes in one sweep instead of one pixel per sweep (the closure does not
+        // depend on the order: only weak -> edge transitions); sweeps repeat until a block-wide OR reports no change ----
+        {
+            const int strip = 4 * ((p.gpe + kEdgeBlock - 1) / kEdgeBlock), s0 = tid * strip, s1 = min(npx, s0 + strip);
+            auto visit = [&](int px) -> int {
                 const int y = px / W, x = px - y * W;
                 bool hit = false;
                 for (int dy = -1; dy <= 1; ++dy)
@@ -702,17 +739,32 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                         const int yy = y + dy, xx = x + dx;
                         if (yy >= 0 && yy < H && xx >= 0 && xx < W && map[yy * W + xx] == 2) hit = true;
                     }
-                if (hit) { map[px] = 2; changed = 1; }
+                if (hit) map[px] = 2;
+                return hit ? 1 : 0;
+            };
+            for (int iter = 0; iter < npx; ++iter) {
+                int changed = 0;
+                for (int q = s0; q < s1; q += 4) {
+                    if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
+                    for (int k = 0; k < 4; ++k) if (map[q + k] == 0) changed |= visit(q + k);
+                }
+                for (int q = s1 - 4; q >= s0; q -= 4) {
+                    if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
+                    for (int k = 3; k >= 0; --k) if (map[q + k] == 0) changed |= visit(q + k);
+                }
+                if (!__syncthreads_or(changed)) break;
             }
-            if (!__syncthreads_or(changed)) break;
         }
         // ---- colour masks on the trimmed frame, merge, edge layer last (img_preprocessing.py:43-53) ----
         for (int g = tid; g < p.gpe; g += kEdgeBlock) {
             unsigned ob[12];
+            const unsigned* sw = reinterpret_cast<const unsigned*>(simg + (size_t)g * 12);
+            const unsigned w3[3] = {sw[0], sw[1], sw[2]};
+            const unsigned e4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int px = g * 4 + q;
-                const int r = simg[px * 3], gg = simg[px * 3 + 1], b = simg[px * 3 + 2];
+                auto byte_of = [&](int bi) -> int { return (int)((w3[bi >> 2] >> (8 * (bi & 3))) & 255u); };
+                const int r = byte_of(3 * q), gg = byte_of(3 * q + 1), b = byte_of(3 * q + 2);
                 int o0 = r, o1 = gg, o2 = b;
                 if (p.color) {
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
@@ -730,7 +782,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                         o0 = dc == 0 ? mk : o0; o1 = dc == 1 ? mk : o1; o2 = dc == 2 ? mk : o2;
                     }
                 }
-                const int ev = map[px] == 2 ? 255 : 0;
+                const int ev = ((e4 >> (8 * q)) & 255u) == 2u ? 255 : 0;
                 o0 = p.edge_ch == 0 ? ev : o0; o1 = p.edge_ch == 1 ? ev : o1; o2 = p.edge_ch == 2 ? ev : o2;
                 ob[3 * q] = (unsigned)o0; ob[3 * q + 1] = (unsigned)o1; ob[3 * q + 2] = (unsigned)o2;
             }
@@ -1695,7 +1747,7 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
         p.off_mag = (int)align_up(npx * 3, 16);
         p.off_map = p.off_mag + (int)align_up((size_t)(e->H + 2) * (e->W + 2) * 2, 16);
         const size_t work = (size_t)p.off_map + align_up(npx, 16);
-        const int tables = 512 * 4 + 24 * 4 + 16;
+        const int tables = 512 * 4 + 3 * (kEdgeBlock / 64) * 4 + 16;
         const int grid = std::min(n_images, e->cu_count);
         if (work + tables <= 160 * 1024) {                                    // whole frame in LDS
             p.off_tab = (int)work;
