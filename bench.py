@@ -105,6 +105,25 @@ def cpu_baseline(n_envs, h, w, budget_s=12.0):
     }
 
 
+def pilot_weights(h, w):
+    """Random-init Keras_2D_CNN weights (Glorot-uniform kernels, zero biases; keras_train.py:127-174) and the MACs of one forward pass."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    spec = [(5, 2, 3, 24), (5, 2, 24, 32), (5, 2, 32, 64), (3, 1, 64, 64), (3, 1, 64, 64), (3, 1, 64, 128), (3, 1, 128, 128)]
+    ws, ih, iw, macs = [], h, w, 0
+    for k, s_, cin, cout in spec:
+        ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
+        lim = (6.0 / (k * k * (cin + cout))) ** 0.5
+        ws += [rng.uniform(-lim, lim, (k, k, cin, cout)).astype("float32"), np.zeros(cout, "float32")]
+        macs += ih * iw * cout * k * k * cin
+    dims = [ih * iw * 128, 100, 50, 25, 2]
+    for a_, b_ in zip(dims[:-1], dims[1:]):
+        lim = (6.0 / (a_ + b_)) ** 0.5
+        ws += [rng.uniform(-lim, lim, (a_, b_)).astype("float32"), np.zeros(b_, "float32")]
+        macs += a_ * b_
+    return ws, macs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,20 +188,7 @@ def main():
     env = shard.env
     spl = max(1, args.steps_per_launch)
     if args.pilot:
-        import numpy as np
-        rng = np.random.default_rng(0)
-        spec = [(5, 2, 3, 24), (5, 2, 24, 32), (5, 2, 32, 64), (3, 1, 64, 64), (3, 1, 64, 64), (3, 1, 64, 128), (3, 1, 128, 128)]
-        ws, ih, iw, macs = [], args.img_h, args.img_w, 0
-        for k, s_, cin, cout in spec:
-            ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
-            lim = (6.0 / (k * k * (cin + cout))) ** 0.5
-            ws += [rng.uniform(-lim, lim, (k, k, cin, cout)).astype("float32"), np.zeros(cout, "float32")]
-            macs += ih * iw * cout * k * k * cin
-        dims = [ih * iw * 128, 100, 50, 25, 2]
-        for a_, b_ in zip(dims[:-1], dims[1:]):
-            lim = (6.0 / (a_ + b_)) ** 0.5
-            ws += [rng.uniform(-lim, lim, (a_, b_)).astype("float32"), np.zeros(b_, "float32")]
-            macs += a_ * b_
+        ws, macs = pilot_weights(args.img_h, args.img_w)
         env.pilot_load(ws)
         pilot_flops = 2.0 * macs
         run = lambda k_: env.step_pilot(k_)
@@ -281,6 +287,28 @@ def main():
             env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
             env.sync()
         wall_lock = time.perf_counter() - t3
+        # ... and SURVEY 8(f-1): cnn_2d_speed_control inference on the device frame every step, actions fed back (closed loop, launch mode: the
+        # pilot's kernels need the CUs' LDS, so the resident worker is asked to leave first)
+        pilot_leg = None
+        try:
+            env.set_step_mode(False)
+            env.sync()
+            pws, pmacs = pilot_weights(args.img_h, args.img_w)
+            env.pilot_load(pws)
+            psteps = min(args.steps, 200)
+            env.step_pilot(20)
+            env.sync()
+            env.event_record(2)
+            env.step_pilot(psteps)
+            env.event_record(3)
+            ms_p = env.event_elapsed_ms(2, 3)
+            ptf = 2.0 * pmacs * n * psteps / (ms_p * 1e-3) / 1e12
+            pilot_leg = {"env_steps_per_s": round(n * psteps / (ms_p * 1e-3), 1), "us_per_step": round(ms_p * 1e3 / psteps, 3), "tflops_bf16": round(ptf, 1),
+                         "frac_of_mfma_peak": round(ptf / 2500.0, 5),
+                         "note": "trs_step_pilot: env step + cnn_2d_speed_control forward (bf16 MFMA convolutions, fp32 tail) + KerasPilot.step per step, random-init weights; "
+                                 "device time by HIP events; `python bench.py --pilot` reports this loop as the main line"}
+        except Exception as exc:                                    # the leg is informational: never lose the main line to it
+            pilot_leg = {"error": str(exc)}
         env.set_step_mode(resident)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -299,6 +327,8 @@ def main():
                                                 "note": "trs_step_sequence: a different device-resident control set per step (open-loop action sequences), 8 steps per launch"},
                 "steps_per_launch_8": {"env_steps_per_s": rate(ms8), "frac_of_hbm_peak": frac(ms8),
                                        "note": "synthetic controls; physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
+        if pilot_leg:
+            also["pilot_closed_loop"] = pilot_leg
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
