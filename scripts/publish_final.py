@@ -16,6 +16,11 @@ head = (f"# r02 final pilot loop (scripts/pilot_layers.sh: rocprofv3 kernel trac
         f"{d5['roofline']['achieved']:.0f} TFLOP/s = {d5['roofline']['frac']:.3f}, profiles/r02_bench_pilot_*.json; boxes of this pool differ by ~5 % in this loop: the same build "
         f"measured 4.95-5.28 M and 0.82-0.87 M)\n")
 open(os.path.join(P, "r02_pilot_final.txt"), "w").write(head + open(os.path.join(O, "pilot_layers_120.txt")).read() + open(os.path.join(O, "pilot_layers_240.txt")).read() + keep)
+ip = os.path.join(O, "image_path.txt")
+if os.path.exists(ip):
+    old_ip = open(os.path.join(P, "r02_image_path.txt")).read()
+    hdr_ip = "".join(l for l in old_ip.splitlines(True) if l.startswith("#"))
+    open(os.path.join(P, "r02_image_path.txt"), "w").write(hdr_ip + open(ip).read())
 Q = os.path.join(R, "gpurun_out", "prof_r02_final")
 shutil.copyfile(os.path.join(Q, "summary.txt"), os.path.join(P, "r02_worker_kernel_1024envs_rocprofv3_summary.txt"))
 shutil.copyfile(os.path.join(Q, "trace", "trace_kernel_stats.csv"), os.path.join(P, "r02_worker_kernel_1024envs_kernel_stats.csv"))

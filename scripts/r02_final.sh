@@ -16,5 +16,6 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --pilot --steps 200 --warmup
 import json; d=json.load(open('$O/bench_pilot5.json')); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])"
 PL_TAG=final timeout -k 10 300 bash scripts/pilot_layers.sh 2>&1 | tee $O/pilot_layers_120.txt
 PL_TAG=final5 timeout -k 10 300 bash scripts/pilot_layers.sh --envs-per-gpu 512 --img-h 240 --img-w 320 --depth 2>&1 | tee $O/pilot_layers_240.txt
+echo "== image path" && (timeout -k 10 200 python scripts/preprocess_bench.py 2>&1 | grep -v amdgpu; timeout -k 10 200 python scripts/preprocess_bench.py 256 240 320 2>&1 | grep -v amdgpu) | tee $O/image_path.txt
 echo "== config 1" && timeout -k 10 200 python scripts/config1.py 2>&1 | grep -v amdgpu.ids | tee $O/config1.txt
 echo "== profile (resident)" && timeout -k 10 500 bash scripts/profile.sh r02_final > $O/profile.log 2>&1; tail -3 $O/profile.log

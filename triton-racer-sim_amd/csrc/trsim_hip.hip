@@ -493,6 +493,8 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         }
         s_rng[c][x] = bits;
     }
+    int fsel0 = -1, fsel1 = -1, fsel2 = -1;
+    for (int f = 0; f < p.n_filters; ++f) { const int dc = p.dst_ch[f]; if (dc == 0) fsel0 = f; else if (dc == 1) fsel1 = f; else if (dc == 2) fsel2 = f; }
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
@@ -552,11 +554,10 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
                     const unsigned inr = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
-                    for (int f = 0; f < p.n_filters; ++f) {                 // later filters overwrite earlier ones (:57-63)
-                        const unsigned m = (inr >> f) & 1u ? 255u : 0u;
-                        const int dc = p.dst_ch[f];
-                        o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
-                    }
+                    // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it (fsel, -1 = none)
+                    if (fsel0 >= 0) o0 = (inr >> fsel0) & 1u ? 255u : 0u;
+                    if (fsel1 >= 0) o1 = (inr >> fsel1) & 1u ? 255u : 0u;
+                    if (fsel2 >= 0) o2 = (inr >> fsel2) & 1u ? 255u : 0u;
                 }
                 ob[3 * px] = o0; ob[3 * px + 1] = o1; ob[3 * px + 2] = o2;
             }
