@@ -6,7 +6,7 @@ O=gpurun_out/r02_final
 mkdir -p $O
 echo "== full gpu suite" && timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; rc=$?; tail -4 $O/gpu_tests.log; [ $rc -eq 0 ] || exit $rc
 echo "== default bench" && timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; rc=$?; python -c "
-import json; d=json.load(open('$O/bench_default.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic']); [print(' ', k, v['env_steps_per_s'], v['frac_of_hbm_peak'], v.get('us_per_call', v.get('us_per_step')), v.get('lock_step_us_per_call')) for k,v in d['also'].items()]; print(' cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"; [ $rc -eq 0 ] || exit $rc
+import json; d=json.load(open('$O/bench_default.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic']); [print(' ', k, v.get('env_steps_per_s'), v.get('frac_of_hbm_peak', v.get('frac_of_mfma_peak')), v.get('us_per_call', v.get('us_per_step')), v.get('lock_step_us_per_call')) for k,v in d['also'].items()]; print(' cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"; [ $rc -eq 0 ] || exit $rc
 for cfg in "--steps 20 --warmup 5" "--step-mode launch" "--step-mode launch --steps 20 --warmup 5" "--envs-per-gpu 512" "--envs-per-gpu 512 --step-mode launch" "--envs-per-gpu 256" "--envs-per-gpu 2048 --steps 1000" "--envs-per-gpu 4096 --steps 500" "--envs-per-gpu 4096 --steps 500 --step-mode launch" "--envs-per-gpu 16384 --steps 128" "--steps 600 --depth" "--steps 600 --depth --step-mode launch" "--envs-per-gpu 512 --steps 200 --img-h 240 --img-w 320 --depth" "--envs-per-gpu 1024 --steps 200 --img-h 240 --img-w 320 --depth" "--envs-per-gpu 256 --steps 4000 --no-render" "--envs-per-gpu 256 --steps 4000 --no-render --steps-per-launch 16" "--envs-per-gpu 65536 --steps 256 --no-render --steps-per-launch 16"; do
   echo "== $cfg"; timeout -k 10 200 python bench.py --no-cpu-baseline --no-also $cfg 2>> $O/bench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['config']['step_mode'])" || exit 1
 done | tee $O/sweep.txt
