@@ -309,6 +309,28 @@ def main():
                                  "device time by HIP events; `python bench.py --pilot` reports this loop as the main line"}
         except Exception as exc:                                    # the leg is informational: never lose the main line to it
             pilot_leg = {"error": str(exc)}
+        # ... and BASELINE configs[4]'s per-GPU share: 512 envs x 240x320 RGB + fp32 depth with the same pilot in the loop (its own handle)
+        pilot5_leg = None
+        if (args.img_h, args.img_w) == (120, 160) and not args.depth:
+            try:
+                from triton_racer_sim_amd.env import BatchedEnv
+                env5 = BatchedEnv(n_envs=512, img_h=240, img_w=320, depth=True, auto_reset=True, device=local_rank)
+                w5, macs5 = pilot_weights(240, 320)
+                env5.pilot_load(w5)
+                env5.step_synthetic(2, 1)
+                env5.step_pilot(10)
+                env5.sync()
+                env5.event_record(0)
+                env5.step_pilot(60)
+                env5.event_record(1)
+                ms5 = env5.event_elapsed_ms(0, 1)
+                tf5 = 2.0 * macs5 * 512 * 60 / (ms5 * 1e-3) / 1e12
+                pilot5_leg = {"env_steps_per_s": round(512 * 60 / (ms5 * 1e-3), 1), "us_per_step": round(ms5 * 1e3 / 60, 3), "tflops_bf16": round(tf5, 1),
+                              "frac_of_mfma_peak": round(tf5 / 2500.0, 5),
+                              "note": "512 envs x 240x320 RGB + fp32 depth + cnn_2d_speed_control in the loop = one GPU's share of BASELINE configs[4]; device time by HIP events"}
+                env5.close()
+            except Exception as exc:
+                pilot5_leg = {"error": str(exc)}
         env.set_step_mode(resident)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -329,6 +351,8 @@ def main():
                                        "note": "synthetic controls; physics team runs 8 steps ahead inside one launch (LDS hand-off); device time by HIP events"}}
         if pilot_leg:
             also["pilot_closed_loop"] = pilot_leg
+        if pilot5_leg:
+            also["pilot_closed_loop_512x240x320_depth"] = pilot5_leg
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
