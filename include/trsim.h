@@ -163,6 +163,14 @@ int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h
  *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident. */
 enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
 int trs_set_step_mode(trs_env* env, int mode, int idle_us);
+/* Resident mode only (a no-op otherwise): the worker leaves the GPU now — every posted step is complete in memory when the call
+ * returns — and the next posted step starts a new one.  For a caller about to run work of ANOTHER stream or library that needs
+ * the CUs the worker occupies (one workgroup slot and most of the LDS on every CU): a collective, a large kernel.  The step mode
+ * stays TRS_STEP_RESIDENT. */
+int trs_quiesce(trs_env* env);
+/* Test hook: a resident worker leaves by itself after life_us microseconds (default 500,000; <= 0 restores it) and the next post
+ * starts a new one — tests use a short lifetime to run many worker generations under load.  Needs trs_set_step_mode first. */
+int trs_resident_debug_lifetime(trs_env* env, int life_us);
 
 /* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
 int trs_get_state(trs_env* env, trs_state_view* out);
@@ -306,6 +314,38 @@ enum {
 };
 
 void trs_default_pilot_config(trs_pilot_config* cfg);
+
+/* Which kernel serves which layer is decided by trs_pilot_load from the frame size (table: DESIGN.md §3 "shape -> kernel").  This
+ * struct is the ONE place where that choice can be overridden — by tests that compare a kernel with the simpler kernel it replaced
+ * (same weights, same frames; tests/test_pilot.py) and by measurements (scripts/).  Nothing in the library reads the environment
+ * for it.  trs_default_pilot_tuning fills in the defaults; trs_pilot_set_tuning stores a copy in the handle, used by every later
+ * trs_pilot_load (NULL = back to the defaults). */
+typedef struct trs_pilot_tuning {
+    uint32_t struct_size;
+    int32_t no_fuse;             /* 0; 1: conv1 and conv2 as separate kernels (trs_conv_u8_kernel, trs_conv_span / _lt_kernel) */
+    int32_t fuse_band_r2;        /* 6: conv2 rows per band of the band-form head (trs_conv12_band_kernel); 0: direct form (trs_conv12_kernel) */
+    int32_t fuse_r2;             /* 6: conv2 rows per band of the direct form */
+    int32_t fuse_wsplit_max;     /* 4: a band may be cut into up to this many parts in width (240x320 needs 2); 1: never */
+    int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel */
+    int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel when whole input frames fit LDS; 0: span kernel; 2: also in row bands */
+    int32_t frame5_bands;        /* 0: automatic; else at least this many row bands */
+    int32_t frame5_f;            /* 0: automatic; else at most this many frames per workgroup */
+    int32_t frame_layers_mask;   /* 0x78: bit i = conv(i+1) (3x3 layers) on trs_conv_frame_kernel where its input fits LDS */
+    int32_t frame_bands[4];      /* conv4..conv7: 0 automatic, else at least this many row bands */
+    int32_t frame_f;             /* 0: automatic; else frames (units) per workgroup */
+    int32_t frame_deep;          /* 0; 1: the deep-ring instantiation (measured slower, kept for A/B) */
+    int32_t frame_nt;            /* 0: automatic (2 or 3 tiles of 32 pixels per wave item); 2 or 3 forces it */
+    int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
+    int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it */
+    int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel; 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
+    int32_t ksplit;              /* 0: automatic; else K slices of dense1 */
+    int32_t min_waves;           /* 7: conv layers on the quad-load kernel keep 64-channel slices while this many waves fit */
+    int32_t waves;               /* 0: automatic (about 16 per CU); else waves per CU for the quad-load / span kernels */
+    int32_t nt_mb;               /* 128: activations larger than this many MB leave with non-temporal stores */
+    int32_t nt_kind;             /* 1: nt; 2: sc0 sc1 */
+} trs_pilot_tuning;
+void trs_default_pilot_tuning(trs_pilot_tuning* t);
+int trs_pilot_set_tuning(trs_env* env, const trs_pilot_tuning* t_or_null);
 
 /* Load the weights of Keras_2D_CNN.get_model(input_shape=(img_h,img_w,3), num_outputs=2) (components/keras_train.py:127-174,
  * selected for cnn_2d_speed_control at :393-395): 11 layers, in order conv1..conv7, dense1, dense2, dense3, output_layer;

@@ -165,3 +165,34 @@ def test_device_resident_part_graph_equals_step_pilot_and_copies_no_frames():
     assert gym.env.fetch("speed").max() > 0.0
     ref.close()
     car.stop()
+
+
+@pytest.mark.gpu
+def test_pilot_part_uses_a_host_speed_beside_a_device_frame():
+    """KerasPilot.step always uses ITS 'gym/speed' input (keras_pilot.py:78-90).  A pilot part that owns its env (no
+    sim behind it) and gets a device 'cam/img' with a HOST speed used to drop the speed silently and read its own (all-zero)
+    array; the value is now uploaded, and a missing one is an error."""
+    from test_pilot import make_weights
+    from triton_racer_sim_amd.components import HipKerasPilot
+    from triton_racer_sim_amd.env import BatchedEnv
+    n = 8
+    ws = make_weights(120, 160, seed=12)
+    cfg = {"spd_ctl_threshold": 1.1, "spd_ctl_reverse_multiplier": 1.0}
+    sim = BatchedEnv(n_envs=n, auto_reset=True)
+    sim.step_synthetic(9, 1)
+    frames_dev = sim.device_array("img")                              # (waits for the sim's stream)
+    frames = sim.fetch("img")
+    speeds = np.array([0.0, 1.5, 3.0, 6.0, 9.0, 12.0, 18.0, 25.0], dtype=np.float32)
+    part = HipKerasPilot(cfg, weights=ws, n_cars=n)                   # its own env: no track, no sim
+    want = part.step(frames, speeds, None, None, "ai")               # host path: the reference's arithmetic on the host
+    import torch
+    handles = part.step(frames_dev, speeds, None, None, "ai")        # device frame, host speeds -> three device handles
+    part.env.sync()
+    got = [torch.as_tensor(g, device="cuda").cpu().numpy() for g in handles]
+    assert np.max(np.abs(got[0] - want[0])) <= 1e-6
+    assert np.max(np.abs(got[1] - want[1])) <= 1e-4, (got[1], want[1])   # float atan on the device against math.atan
+    assert np.ptp(want[1]) > 0.1                                     # the throttles do depend on the speeds given
+    with pytest.raises(ValueError, match="gym/speed"):
+        part.step(frames_dev, None, None, None, "ai")
+    part.onShutdown()
+    sim.close()

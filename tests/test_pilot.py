@@ -277,10 +277,10 @@ def test_closed_loop_is_unaffected_by_another_stream(make_env):
         t.join()
 
 
-@pytest.mark.parametrize("size,wsplit", [((120, 160), None), ((240, 320), None), ((240, 320), "1"), ((100, 132), None), ((130, 300), None)])
-def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
+@pytest.mark.parametrize("size,wsplit", [((120, 160), None), ((240, 320), None), ((240, 320), 1), ((100, 132), None), ((130, 300), None)])
+def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
     """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels.  The direct form (240x320 with
-    TRS_PILOT_FUSE_WSPLIT = 1: bands may not be cut in width) feeds the same bf16 values into the same MFMA order: bit-identical.
+    trs_pilot_tuning.fuse_wsplit_max = 1: bands may not be cut in width) feeds the same bf16 values into the same MFMA order: bit-identical.
     The band form (120x160; 240x320 and 130x300 cut in two parts of conv2 columns, the last part narrower) keeps the conv1 tile
     split by column parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another
     summation order, so an output can land on the neighbouring bf16 value — at most one ulp (2^-7 relative), on a small fraction
@@ -288,9 +288,10 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
     h, w = size
     n = 21
     ws = make_weights(h, w, seed=3)
-    if wsplit is not None:
-        monkeypatch.setenv("TRS_PILOT_FUSE_WSPLIT", wsplit)
     env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+    tune = {} if wsplit is None else {"fuse_wsplit_max": wsplit}
+    if tune:
+        env.pilot_tuning(**tune)
     env.pilot_load(ws)
     rng = np.random.default_rng(8)
     frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
@@ -300,11 +301,11 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
     fused_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
     again = env.pilot_forward_host(frames)
     assert np.array_equal(fused_out, again) and np.array_equal(fused_l1, env.pilot_layer(1, (n, oh2, ow2, 32)))
-    monkeypatch.setenv("TRS_PILOT_NO_FUSE", "1")
-    env.pilot_load(ws)                                                # the switch is read when the weights are loaded
+    env.pilot_tuning(no_fuse=1, **tune)
+    env.pilot_load(ws)                                                # the choice is read when the weights are loaded
     plain_out = env.pilot_forward_host(frames)
     plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
-    if wsplit == "1":
+    if wsplit == 1:
         assert np.array_equal(fused_l1, plain_l1)
         assert np.array_equal(fused_out, plain_out)
     else:
@@ -315,9 +316,9 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit, monkeypatch):
 
 
 @pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5), ((120, 160), 1)])
-def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch):
+def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution
-    kernel (TRS_PILOT_DENSE = 0): the same bf16 products, K split differently — fp32 summation order only.  n is not a multiple
+    kernel (trs_pilot_tuning.dense = 0): the same bf16 products, K split differently — fp32 summation order only.  n is not a multiple
     of 32 (ragged last frame group) and spans several groups; 240x320 needs several LDS chunks per slice and a ragged last one."""
     h, w = size
     ws = make_weights(h, w, seed=5)
@@ -328,8 +329,8 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch)
     for k, s_, _, _ in SPEC:
         oh, ow = (oh - k) // s_ + 1, (ow - k) // s_ + 1
     for mode in ("0", "1"):
-        monkeypatch.setenv("TRS_PILOT_DENSE", mode)
         env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_tuning(dense=int(mode))
         env.pilot_load(ws)
         for rep in range(2):
             outs[mode] = env.pilot_forward_host(frames)
@@ -345,9 +346,9 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n, monkeypatch)
 
 @pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 6), ((120, 160), 1)])
 @pytest.mark.parametrize("layers", ["4", "3"])
-def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, layers, monkeypatch):
+def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, layers):
     """conv4..conv7 (or conv5..conv7) in one launch with the activations in LDS (trs_conv_chain_kernel) against one launch per
-    layer (TRS_PILOT_CHAIN = 0): the same MFMA order on the same bf16 values, so every activation — the interior ones are
+    layer (trs_pilot_tuning.chain_layers = 0): the same MFMA order on the same bf16 values, so every activation — the interior ones are
     recomputed by the debug getter — and the outputs agree bit for bit.  37 frames: 2 frames per workgroup, odd tail; 1027: 4 per
     workgroup with a ragged last one (3 frames: the second conv4 pass has one frame); 240x320 does not fit LDS: no chain."""
     h, w = size
@@ -360,8 +361,8 @@ def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, lay
         shapes.append((n, ih, iw, cout))
     res = {}
     for mode in ("0", layers):
-        monkeypatch.setenv("TRS_PILOT_CHAIN", mode)
         env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_tuning(chain_layers=int(mode))
         env.pilot_load(ws)
         out = env.pilot_forward_host(frames)
         out = env.pilot_forward_host(frames)
@@ -372,9 +373,9 @@ def test_conv_chain_is_bit_identical_to_the_single_layers(make_env, size, n, lay
 
 
 @pytest.mark.parametrize("size,n", [((120, 160), 37), ((120, 160), 1027), ((100, 132), 9), ((240, 320), 11)])
-def test_conv3_with_frames_in_lds_is_bit_identical_to_the_span_kernel(make_env, size, n, monkeypatch):
+def test_conv3_with_frames_in_lds_is_bit_identical_to_the_span_kernel(make_env, size, n):
     """conv3 on trs_conv_frame5_kernel (input frames in LDS, even / odd column planes, weights from L2) against the span kernel
-    (TRS_PILOT_FRAME5 = 0): the same k order on the same bf16 values — conv3's activation and the outputs agree bit for bit.  240x320: the input frame (281 KB)
+    (trs_pilot_tuning.frame5 = 0): the same k order on the same bf16 values — conv3's activation and the outputs agree bit for bit.  240x320: the input frame (281 KB)
     is cut into 5 bands of 6 output rows (the last has 3)."""
     h, w = size
     ws = make_weights(h, w, seed=13)
@@ -385,8 +386,8 @@ def test_conv3_with_frames_in_lds_is_bit_identical_to_the_span_kernel(make_env, 
         ih, iw = (ih - k) // s_ + 1, (iw - k) // s_ + 1
     res = {}
     for mode in ("0", "2"):                                          # 2: also when the frame has to be cut into row bands
-        monkeypatch.setenv("TRS_PILOT_FRAME5", mode)
         env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_tuning(frame5=int(mode))
         env.pilot_load(ws)
         out = env.pilot_forward_host(frames)
         res["1" if mode == "2" else mode] = (out, env.pilot_layer(2, (n, ih, iw, 64)))

@@ -159,13 +159,13 @@ def test_resident_sequence_and_mode_errors(make_env, hip_api):
     assert hip_api.set_step_mode(g._h, 7, 0) != 0
 
 
-def test_resident_worker_generations_under_load(make_env, monkeypatch):
+def test_resident_worker_generations_under_load(make_env):
     """The worker leaves on its own when its lifetime is spent, even while posts keep coming; the host restarts it from the
     first step it did not take.  With a 1.5 ms lifetime a 4,000-step run crosses that seam dozens of times."""
-    monkeypatch.setenv("TRS_RESIDENT_LIFE_US", "1500")
     n = 128
     g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
     g.set_step_mode(True)
+    g.resident_lifetime(1500)                                    # trs_resident_debug_lifetime
     for chunk in (1500, 1, 2499):
         for env in (g, o):
             env.step_synthetic(chunk, 1)
@@ -204,3 +204,48 @@ def test_pilot_loop_with_resident_mode_selected(make_env):
         env.step_synthetic(2, 1)
     for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img", "ep_return"):
         assert np.array_equal(a.fetch(name), b.fetch(name)), name
+
+
+def test_pilot_steps_then_fetch_with_resident_mode_selected(make_env):
+    """in resident mode trs_step_pilot steps by LAUNCH, so the newest steps have no completion flag — trs_sync,
+    trs_copy_to_host and trs_fetch_outputs called right behind them must wait for the stream (they used to spin on a flag nobody
+    writes until the 10 s timeout).  Compared with a launch-mode env."""
+    from test_pilot import make_weights
+    n = 24
+    ws = make_weights(120, 160, seed=33)
+    a, b = make_env("hip", n_envs=n), make_env("hip", n_envs=n)
+    a.pilot_load(ws); b.pilot_load(ws)
+    a.set_step_mode(True)
+    for env in (a, b):
+        env.step_synthetic(3, 1)                                     # a: posted to the worker
+        env.step_pilot(5)                                            # a: launched although resident mode is selected
+    t0 = time.perf_counter()
+    a.sync()                                                         # straight behind the launched steps
+    got = {name: a.fetch(name) for name in ("pos_x", "pos_z", "yaw", "speed", "seg_idx", "img", "ep_return")}
+    outs = a.fetch_outputs() if hasattr(a, "fetch_outputs") else None
+    assert time.perf_counter() - t0 < 5.0                            # no completion-flag timeout
+    for name, v in got.items():
+        assert np.array_equal(v, b.fetch(name)), name
+    if outs is not None:
+        assert np.array_equal(outs[0], b.fetch("img"))
+    for env in (a, b):                                               # and the worker starts again behind the launched steps
+        env.step_synthetic(2, 1)
+        env.step_pilot(1)
+        env.step_synthetic(1, 1)
+    for name in ("pos_x", "speed", "seg_idx", "img"):
+        assert np.array_equal(a.fetch(name), b.fetch(name)), name
+
+
+def test_quiesce_keeps_the_mode_and_the_results(make_env):
+    """trs_quiesce: the worker leaves (posted steps complete first), the mode stays resident, the next step starts a new worker."""
+    n = 32
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.quiesce()                                                      # no-op before resident mode was ever selected
+    g.set_step_mode(True)
+    for k in (5, 1, 7):
+        for env in (g, o):
+            env.step_synthetic(k, 1)
+        g.quiesce()
+        g.quiesce()
+    assert_state_equal(g, o, "after quiesce calls")
+    assert_frames_equal(g, o, "after quiesce calls")

@@ -71,7 +71,7 @@ FIELDS = {
 # every symbol include/trsim.h declares (suffix after the prefix)
 SYMBOLS = [
     "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic", "step_sequence", "step_sequence_host",
-    "set_step_mode", "get_state", "copy_to_host", "fetch_outputs", "set_pose", "locate", "map_info_get", "sync", "event_record",
+    "set_step_mode", "quiesce", "get_state", "copy_to_host", "fetch_outputs", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
     "default_pre_config", "preprocess", "preprocess_host", "set_frame_filter", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
@@ -98,6 +98,17 @@ class TrsPilotConfig(C.Structure):
     ]
 
 
+class TrsPilotTuning(C.Structure):
+    """``trs_pilot_tuning`` (include/trsim.h): kernel choices of ``trs_pilot_load``; tests and measurements only."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("no_fuse", C.c_int32), ("fuse_band_r2", C.c_int32), ("fuse_r2", C.c_int32), ("fuse_wsplit_max", C.c_int32),
+        ("span_layers_mask", C.c_int32), ("frame5", C.c_int32), ("frame5_bands", C.c_int32), ("frame5_f", C.c_int32),
+        ("frame_layers_mask", C.c_int32), ("frame_bands", C.c_int32 * 4), ("frame_f", C.c_int32), ("frame_deep", C.c_int32), ("frame_nt", C.c_int32),
+        ("chain_layers", C.c_int32), ("chain_nt", C.c_int32), ("dense", C.c_int32), ("ksplit", C.c_int32), ("min_waves", C.c_int32), ("waves", C.c_int32),
+        ("nt_mb", C.c_int32), ("nt_kind", C.c_int32),
+    ]
+
+
 COMM_ID_BYTES = 128                                                    # TRS_COMM_ID_BYTES
 
 PILOT_MODEL_TYPES = {"cnn_2d_speed_control": 0, "cnn_2d": 1, "cnn_2d_speed_as_feature": 2, "cnn_2d_full_house": 3}   # TRS_PILOT_*; ModelType values (utils/types.py)
@@ -114,7 +125,8 @@ PILOT_ARRAYS_OF_TYPE = {"cnn_2d_speed_control": 22, "cnn_2d": 22, "cnn_2d_speed_
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
 PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_forward_ex", "pilot_forward_host_ex",
-                 "pilot_debug_layer", "pilot_act", "step_pilot"]
+                 "pilot_debug_layer", "pilot_act", "step_pilot", "default_pilot_tuning", "pilot_set_tuning",
+                 "resident_debug_lifetime"]      # (the last: a test hook of the resident worker, which the oracle does not have either)
 
 
 class Api:
@@ -135,6 +147,7 @@ class Api:
             "step_sequence": (i32, [vp, fp, fp, fp, u8p, i32, i32]),
             "step_sequence_host": (i32, [vp, fp, fp, fp, u8p, i32, i32]),
             "set_step_mode": (i32, [vp, i32, i32]),
+            "quiesce": (i32, [vp]),
             "get_state": (i32, [vp, C.POINTER(TrsStateView)]),
             "copy_to_host": (i32, [vp, i32, vp, C.c_size_t]),
             "fetch_outputs": (i32, [vp] + [vp] * 8),
@@ -178,6 +191,9 @@ class Api:
             "pilot_forward_host_ex": (i32, [vp, vp, vp, vp, i32, vp]),
             "pilot_act": (i32, [vp, C.POINTER(TrsPilotConfig), vp, vp, vp, vp, vp, vp, vp, i32]),
             "step_pilot": (i32, [vp, C.POINTER(TrsPilotConfig), i32]),
+            "default_pilot_tuning": (None, [C.POINTER(TrsPilotTuning)]),
+            "pilot_set_tuning": (i32, [vp, C.POINTER(TrsPilotTuning)]),
+            "resident_debug_lifetime": (i32, [vp, i32]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(cdll, prefix + name)

@@ -13,7 +13,7 @@ Swap in ``car_templates/manage.py:72-75``::
 import numpy as np
 
 from .core import Component
-from .env import SLOT_MODE, SLOT_USR, BatchedEnv, device_ptr, is_device_array
+from .env import SLOT_MODE, SLOT_PILOT_IN, SLOT_USR, BatchedEnv, device_ptr, is_device_array
 
 GYM_INPUTS = ["mux/steering", "mux/throttle", "mux/breaking", "usr/reset"]       # gyminterface.py:52
 GYM_OUTPUTS = ["cam/img", "gym/x", "gym/y", "gym/z", "gym/speed", "gym/cte"]     # gyminterface.py:52
@@ -346,8 +346,24 @@ class HipKerasPilot(Component):
                 d_mode = self.env.scratch(SLOT_MODE, (self.env.n,), np.uint8)
                 self.env.upload(d_mode, self.env.encode_modes(modes))
             pc = dict(self.cfg); pc["model_type"] = self.model_type
-            speed = args[1] if is_device_array(args[1]) else None
-            segment = args[2] if is_device_array(args[2]) else None     # 'loc/segment' (full house); None = from the env's own tracker index
+            # keras_pilot.py:78-90 always uses ITS inputs: a speed / segment that arrives as a host value beside a device frame is
+            # uploaded (as modes and usr/* are); only a missing value (None) falls back to the env's own arrays — and a pilot
+            # that owns its env has no sim behind those arrays, so it must be given the speed
+            def as_device(value, slot, what):
+                if is_device_array(value):
+                    return value
+                if value is None:
+                    if self._own_env:
+                        raise ValueError(f"HipKerasPilot: {what!r} is None beside a device 'cam/img' and this pilot does not share a sim's env "
+                                         "(env=...): there is no speed / track index to read")
+                    return None
+                buf = self.env.scratch(slot, (self.env.n,), np.float32)
+                self.env.upload(buf, np.asarray(value, dtype=np.float32))
+                return buf
+            speed = as_device(args[1], SLOT_PILOT_IN[0], "gym/speed")
+            segment = None
+            if self.model_type == "cnn_2d_full_house":                   # 'loc/segment'; None = from the shared env's own tracker index
+                segment = as_device(args[2], SLOT_PILOT_IN[1], "loc/segment")
             return self.env.pilot_act_device(frames=img, speed=speed, mode=d_mode, cfg=pc, segment=segment)
         if img is None or mode not in ("ai", "ai_steering"):               # keras_pilot.py:46-48,139
             return 0.0, 0.0, 0.0

@@ -49,6 +49,7 @@ struct trs_env {
     int seq_stride = 0;                  // trs_step_sequence: n_envs while a sequence call is running, else 0
     int max_steps_dyn = 0;               // steps per launch that still fit beside the dynamic-brightness palette (0 = it does not fit at all)
     void* pilot = nullptr;               // trsim_pilot.hip context (cnn_2d_speed_control weights + activations)
+    trs_pilot_tuning pilot_tuning{}; bool has_pilot_tuning = false;   // trs_pilot_set_tuning: kernel choices of the next trs_pilot_load
     unsigned long long* fault = nullptr; // pinned host word the kernels set when they refuse to run (dynamic LDS not at offset 0)
     float* glue = nullptr; size_t glue_bytes = 0;   // device scratch of the *_host control glue (trs_driver_assist_host, trs_control_mux_host)
     void* scratch[32] = {}; size_t scratch_bytes[32] = {};   // trs_scratch
@@ -68,6 +69,7 @@ int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const f
 hipStream_t resident_copy_stream(trs_env* e);             // a stream that is not blocked by the worker (the handle's own when none runs)
 int resident_wait(trs_env* e);                            // every posted step complete (the worker stays resident)
 int resident_quiesce(trs_env* e);                         // ... and the worker has left the GPU: the stream is free again
+void resident_note_launch(trs_env* e);                    // a step was launched on the stream while resident mode is selected (pilot loop)
 void resident_destroy(trs_env* e);
 int sync_handle(trs_env* e);                               // the handle's stream is idle (a resident worker is asked to leave first)
 int quiesce_handle(trs_env* e);                            // a resident worker has left; queued work may still be running

@@ -1958,6 +1958,13 @@ TRS_EXPORT int trs_sync(trs_env* e)
     return sync_all(e);
 }
 
+TRS_EXPORT int trs_quiesce(trs_env* e)
+{
+    if (!e) return fail(TRS_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(e->device));
+    return quiesce(e);
+}
+
 TRS_EXPORT int trs_event_record(trs_env* e, int slot)
 {
     if (!e || slot < 0 || slot >= 8) return fail(TRS_ERR_ARG, "bad event slot");
@@ -2027,6 +2034,13 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
     return true;
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }
+const trs_pilot_tuning* trs_internal_pilot_tuning(trs_env* e) { return e && e->has_pilot_tuning ? &e->pilot_tuning : nullptr; }
+void trs_internal_set_pilot_tuning(trs_env* e, const trs_pilot_tuning* t)
+{
+    if (!e) return;
+    e->has_pilot_tuning = t != nullptr;
+    if (t) e->pilot_tuning = *t;
+}
 int trs_internal_fail(int code, const std::string& msg) { return fail(code, msg); }
 void trs_internal_count(trs_env* e, uint64_t d2h, uint64_t h2d) { if (e) { e->d2h_bytes += d2h; e->h2d_bytes += h2d; } }
 // one env step by LAUNCH whatever the handle's step mode: the pilot loop's kernels need the CUs' LDS, which a resident worker
@@ -2035,7 +2049,9 @@ int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, c
 {
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     { int rq = quiesce(e); if (rq) return rq; }
-    return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1) : run_physics_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1);
+    const int rc = e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1) : run_physics_steps(e, d_st, d_th, d_br, nullptr, 0, 1, 1);
+    if (!rc) trsim::resident_note_launch(e);               // resident mode selected: this step has no completion flag, trs_sync / the copies wait for the stream
+    return rc;
 }
 int trsim::sync_handle(trs_env* e) { return sync_all(e); }
 int trsim::quiesce_handle(trs_env* e) { return quiesce(e); }

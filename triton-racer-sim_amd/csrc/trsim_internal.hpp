@@ -19,6 +19,8 @@ struct TrsEnvView {
 
 bool trs_internal_view(trs_env* e, TrsEnvView* out);
 void** trs_internal_pilot_slot(trs_env* e);
+const trs_pilot_tuning* trs_internal_pilot_tuning(trs_env* e);   // what trs_pilot_set_tuning stored, or nullptr (defaults)
+void trs_internal_set_pilot_tuning(trs_env* e, const trs_pilot_tuning* t);
 int trs_internal_fail(int code, const std::string& msg);
 int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, const float* d_br);   // one env step by launch, whatever the step mode
 void trs_internal_count(trs_env* e, uint64_t d2h_bytes, uint64_t h2d_bytes);   // trs_counters bookkeeping for copies made outside trsim_hip.hip

@@ -1914,6 +1914,7 @@ struct PilotCtx {
     int chain_first = -1, chain_lds = 0; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
     bool chain_mid_valid = true;          // act[chain_first .. 5] hold the last pass (the chain never writes them; the debug getter runs the single layers on demand)
     u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
+    trs_pilot_tuning tun{};               // the kernel choices this context was loaded with (trs_pilot_set_tuning, else the defaults)
 };
 
 unsigned short host_f2bf(float f)
@@ -1943,18 +1944,18 @@ int upload(T** dst, const std::vector<T>& v)
 
 // split-K only as far as it takes to fill the chip about twice (every extra slice is another slab for the tail kernel to add;
 // dense1 at 240x320: 551 one-chunk slices x 4 row tiles spent 166 us), and never an empty slice
-int split_k_slices(const ConvLayer& l, int n_img, int cu_count)
+int split_k_slices(const ConvLayer& l, int n_img, int cu_count, const trs_pilot_tuning& T)
 {
     if (l.ksplit <= 1) return 1;
     const int M = n_img * l.OH * l.OW, grid = (M + kRowsPerWg - 1) / kRowsPerWg;
     int want = std::max(1, (2 * cu_count + grid - 1) / grid);
-    if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
+    if (T.ksplit > 0) want = T.ksplit;
     const int ks = std::min(l.ksplit, want);
     const int nchunks = (l.G_pad + l.gchunk - 1) / l.gchunk, cps = (nchunks + ks - 1) / ks;
     return (nchunks + cps - 1) / cps;
 }
 
-int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count)
+int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count, const trs_pilot_tuning& T)
 {
     ConvParams p{};
     p.in = in; p.w = l.w; p.bias = l.bias; p.goff = l.goff; p.out = out;
@@ -1965,10 +1966,8 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
     p.ksplit = l.ksplit;
     {
-        size_t nt_mb = 128;                                                // outputs above this many MB leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
-        if (const char* e = std::getenv("TRS_PILOT_NT_MB")) nt_mb = (size_t)std::atoi(e);
-        int nt_kind = 1;
-        if (const char* e = std::getenv("TRS_PILOT_NT_KIND")) nt_kind = std::atoi(e);
+        const size_t nt_mb = (size_t)std::max(0, T.nt_mb);                 // outputs above this many MB (128) leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
+        const int nt_kind = T.nt_kind;
         p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > (nt_mb << 20)) ? nt_kind : 0;
     }
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
@@ -2005,7 +2004,7 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         const int px = std::min(q.F, n_img * q.bands) * q.ohb * q.OW, cgrps = q.COUT_PAD / 64;
         auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
         int nt = busiest(3) <= busiest(2) ? 3 : 2;
-        if (const char* e = std::getenv("TRS_PILOT_FRAME_NT")) { const int v = std::atoi(e); if (v == 2 || v == 3) nt = v; }
+        if (T.frame_nt == 2 || T.frame_nt == 3) nt = T.frame_nt;
         if (l.frame_deep) nt = 2;
         if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(2, 4, 12, 512); else if (nt == 3) LAUNCH_FRAME(3, 4, 4, 512); else LAUNCH_FRAME(2, 4, 4, 512); }
         else { if (l.frame_deep) LAUNCH_FRAME(2, 8, 8, 512); else if (nt == 3) LAUNCH_FRAME(3, 8, 4, 512); else LAUNCH_FRAME(2, 8, 4, 512); }
@@ -2046,7 +2045,7 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         return TRS_OK;
     }
     const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
-    const int ks = split_k_slices(l, n_img, cu_count);                     // > 1: `out` is the slab buffer [ks][M][COUT]
+    const int ks = split_k_slices(l, n_img, cu_count, T);                  // > 1: `out` is the slab buffer [ks][M][COUT]
     p.ksplit = ks;
     const int nb = l.COUT_PAD / 32;
 #define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, ks), dim3(kConvBlock), l.lds, s, p)
@@ -2060,11 +2059,11 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
 }
 
 // K slices of trs_pilot_dense_kernel: whole LDS chunks, as many slices as give every CU a workgroup (groups of 32 frames x slices)
-void dense_plan(const ConvLayer& l, int n, int cu_count, int* gps, int* ks)
+void dense_plan(const ConvLayer& l, int n, int cu_count, const trs_pilot_tuning& T, int* gps, int* ks)
 {
     const int groups = (n + 31) / 32, G = l.G;
     int want = std::max(1, cu_count / groups);
-    if (const char* e = std::getenv("TRS_PILOT_KSPLIT")) want = std::max(1, std::atoi(e));
+    if (T.ksplit > 0) want = T.ksplit;
     const int chunks = (G + kDenseChunk - 1) / kDenseChunk;
     const int cps = std::max(1, (chunks + want - 1) / want);
     *gps = cps * kDenseChunk;
@@ -2076,7 +2075,7 @@ int launch_dense(PilotCtx* c, const ConvLayer& l, const void* in, int n, void* s
     DenseParams q{};
     q.act = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.slab = static_cast<float*>(slab);
     q.n = n; q.G = l.G; q.groups = (n + 31) / 32;
-    dense_plan(l, n, c->cu_count, &q.gps, &q.KS);
+    dense_plan(l, n, c->cu_count, c->tun, &q.gps, &q.KS);
     const int grid = q.groups * ((q.KS + 7) / 8) * 8;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_pilot_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLds));
     hipLaunchKernelGGL(trs_pilot_dense_kernel, dim3(grid), dim3(256), kDenseLds, s, q);
@@ -2129,8 +2128,8 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         }
         void* out = c->act[i];
         if (i == 7) {                                                       // dense1: one fp32 slab per K slice, added in order by the tail kernel
-            if (c->dense_new) { int gps; dense_plan(c->L[7], n, c->cu_count, &gps, &c->last_slices); }
-            else c->last_slices = split_k_slices(c->L[7], n, c->cu_count);
+            if (c->dense_new) { int gps; dense_plan(c->L[7], n, c->cu_count, c->tun, &gps, &c->last_slices); }
+            else c->last_slices = split_k_slices(c->L[7], n, c->cu_count, c->tun);
             const size_t need = (size_t)c->last_slices * n * c->act_elems[7] * sizeof(float);
             if (c->slab_bytes < need) {
                 HIPCHK(hipStreamSynchronize(v.stream));
@@ -2141,15 +2140,15 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             out = c->slab;
         }
         int rc = (i == 7 && c->dense_new) ? launch_dense(c, c->L[7], in, n, out, v.stream)
-                                          : launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
+                                          : launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count, c->tun);
         if (rc) return rc;
         if (i == 0) c->act0_valid = true;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
     }
     if (c->arch == TRS_PILOT_FULL_HOUSE) {                                 // the steering head's dense4 reads conv7's output as well
-        if (c->dense_new) { int gps; dense_plan(c->L[8], n, c->cu_count, &gps, &c->last_slices2); }
-        else c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count);
+        if (c->dense_new) { int gps; dense_plan(c->L[8], n, c->cu_count, c->tun, &gps, &c->last_slices2); }
+        else c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count, c->tun);
         const size_t need = (size_t)c->last_slices2 * n * c->act_elems[8] * sizeof(float);
         if (c->slab2_bytes < need) {
             HIPCHK(hipStreamSynchronize(v.stream));
@@ -2158,7 +2157,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             c->slab2_bytes = need;
         }
         int rc = c->dense_new ? launch_dense(c, c->L[8], c->act[6], n, c->slab2, v.stream)
-                              : launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count);
+                              : launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count, c->tun);
         if (rc) return rc;
     }
     c->last_n = n;
@@ -2239,6 +2238,23 @@ TRS_EXPORT void trs_default_pilot_config(trs_pilot_config* c)
     c->smooth_steering_enabled = 0; c->smooth_steering_threshold = 0.9f;
 }
 
+TRS_EXPORT void trs_default_pilot_tuning(trs_pilot_tuning* t)
+{
+    if (!t) return;
+    std::memset(t, 0, sizeof *t);
+    t->struct_size = (uint32_t)sizeof *t;
+    t->fuse_band_r2 = 6; t->fuse_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
+    t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
+}
+
+TRS_EXPORT int trs_pilot_set_tuning(trs_env* e, const trs_pilot_tuning* t)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    if (t && t->struct_size != sizeof(trs_pilot_tuning)) return trs_internal_fail(TRS_ERR_ARG, "trs_pilot_tuning.struct_size does not match this library (start from trs_default_pilot_tuning)");
+    trs_internal_set_pilot_tuning(e, t);
+    return TRS_OK;
+}
+
 TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
 {
     TrsEnvView v;
@@ -2254,6 +2270,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
     std::unique_ptr<PilotCtx, void (*)(PilotCtx*)> guard(new PilotCtx(), free_ctx);
     PilotCtx* const c = guard.get();
     c->n_cap = v.n; c->H = v.H; c->W = v.W;
+    trs_default_pilot_tuning(&c->tun);
+    if (const trs_pilot_tuning* user = trs_internal_pilot_tuning(e)) c->tun = *user;
+    const trs_pilot_tuning& T = c->tun;
     c->arch = n_arrays == 28 ? TRS_PILOT_SPD_FTR : (n_arrays == 42 ? TRS_PILOT_FULL_HOUSE : TRS_PILOT_SPD_CTL);
     c->n_layers = c->arch == TRS_PILOT_FULL_HOUSE ? 9 : 8;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, v.device) == hipSuccess && prop.multiProcessorCount > 0) c->cu_count = prop.multiProcessorCount; }
@@ -2289,8 +2308,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             // stride-2 layers with wide kernels re-fetch every byte ~2.5x through overlapping windows: span staging instead
             const int cgr = l.CIN / 8, pix_gran = l.S * cgr;
             const int nseg_max = 30 / l.OW + 2;
-            int span_mask = 0x6;                                              // bit i = conv(i+1) uses the span kernel: conv2 and conv3
-            if (const char* e = std::getenv("TRS_PILOT_SPAN_LAYERS")) span_mask = std::atoi(e);
+            const int span_mask = T.span_layers_mask;                         // bit i = conv(i+1) uses the span kernel: conv2 and conv3 (0x6)
             l.res_span = !l.u8in && l.S == 2 && l.KW >= 5 && nseg_max <= 4 && ((span_mask >> i) & 1);
             if (l.res_span) {
                 l.span_nl = ((32 - nseg_max) * pix_gran + nseg_max * run_pad + 63) / 64;
@@ -2298,8 +2316,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             }
             const int stage_per_wave = l.res_span ? l.span_nl * 1024 : 2048;  // input transpose / span stage; output transpose (all kernels)
             auto lds_for = [&](int nb, int waves) { return l.G_pad * nb * 32 * 16 + ((l.G_pad * 4 + 15) & ~15) + nb * 32 * 4 + waves * stage_per_wave; };
-            int min_waves = 7;                                                // conv7: 64-channel slices at 7 waves beat 32-channel slices at 16 (240x320: 199 -> 143 us; the pixels are read twice instead of four times)
-            if (const char* e = std::getenv("TRS_PILOT_MIN_WAVES")) min_waves = std::atoi(e);
+            const int min_waves = T.min_waves;                                // 7: conv7's 64-channel slices at 7 waves beat 32-channel slices at 16 (240x320: 199 -> 143 us; the pixels are read twice instead of four times)
             if (lds_for(l.res_nb, min_waves) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // conv7: 32-channel slices
             const int base = lds_for(l.res_nb, 0);
             if (base + 4 * stage_per_wave > 160 * 1024) l.resident = false;    // does not happen for Keras_2D_CNN; the chunked kernel takes over
@@ -2314,52 +2331,46 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             while (waves > 4 && l.res_wg_per_cu * (lds_for(l.res_nb, waves) + 512) > 160 * 1024) --waves;
             l.res_block = 64 * waves;
             l.res_lds = lds_for(l.res_nb, waves);
-            if (const char* e = std::getenv("TRS_PILOT_WAVES")) {            // tuning hook: waves per CU
-                const int wv = std::max(4, std::min(32, std::atoi(e)));
+            if (T.waves > 0) {                                                // tuning: waves per CU
+                const int wv = std::max(4, std::min(32, (int)T.waves));
                 const int w2 = std::max(1, std::min(16, wv / l.res_wg_per_cu));
                 if (l.res_wg_per_cu * (lds_for(l.res_nb, w2) + 512) <= 160 * 1024) { l.res_block = 64 * w2; l.res_lds = lds_for(l.res_nb, w2); }
             }
         }
         if (i >= 3 && i < 7) {   // conv4..7: frames in LDS when they fit (240x320: conv7's 167 KB frame does not: the quad-load kernel stays)
-            int mask = 0x78;                                                  // bit i = conv(i+1)
-            if (const char* e = std::getenv("TRS_PILOT_FRAME_LAYERS")) mask = std::atoi(e);
+            const int mask = T.frame_layers_mask;                             // bit i = conv(i+1) (0x78)
             const int cg = l.CIN / 8;
             const bool shape_ok = l.S == 1 && l.KH == 3 && l.KW == 3 && (cg == 8 || cg == 16) && l.COUT_PAD % 64 == 0 && l.COUT == l.COUT_PAD && run_pad == l.KW * cg;
             if (((mask >> i) & 1) && shape_ok) {
                 // a frame larger than ~110 KB is cut into row bands (conv7 at 240x320: 21 x 31 x 128 = 167 KB -> 2 bands of 10 / 9 rows)
                 int bands = 1;
                 while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
-                if (const char* e = std::getenv("TRS_PILOT_FRAME_BANDS")) {       // tuning hook: "b4,b5,b6,b7" (0 = automatic)
-                    int b[4] = {0, 0, 0, 0};
-                    std::sscanf(e, "%d,%d,%d,%d", &b[0], &b[1], &b[2], &b[3]);
-                    if (b[i - 3] > 0) bands = std::max(bands, std::min(b[i - 3], l.OH));
-                }
+                if (T.frame_bands[i - 3] > 0) bands = std::max(bands, std::min((int)T.frame_bands[i - 3], l.OH));   // tuning (0 = automatic)
                 const int ohb = (l.OH + bands - 1) / bands, ihb = ohb + l.KH - 1;
                 const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
                 // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
                 int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
-                if (const char* e = std::getenv("TRS_PILOT_FRAME_F")) f = std::max(1, std::atoi(e));
+                if (T.frame_f > 0) f = T.frame_f;
                 while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
-                l.frame_deep = std::getenv("TRS_PILOT_FRAME_DEEP") != nullptr;
+                l.frame_deep = T.frame_deep != 0;
                 l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
                 l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
             }
         }
         if (i == 2) {            // conv3: frames in LDS when two fit (120x160: 2 x 64 KB); TRS_PILOT_FRAME5 = 0: the span kernel
-            int on = 1;
-            if (const char* e = std::getenv("TRS_PILOT_FRAME5")) on = std::atoi(e);
+            const int on = T.frame5;
             const bool shape_ok = l.KH == 5 && l.KW == 5 && l.S == 2 && l.CIN == 32 && l.COUT == 64 && l.COUT_PAD == 64 && run_pad == 20 && l.G_pad == 100;
             // a frame larger than ~78 KB is cut into row bands (240x320: 57 x 77 x 32 = 281 KB -> 5 bands of 6 output rows = 15 input rows, 74 KB:
             // two workgroups of one band per CU)
             int bands = 1;
             while (bands < l.OH && (size_t)(bands == 1 ? l.IH : 2 * ((l.OH + bands - 1) / bands) + 3) * l.IW * 64 > 78 * 1024) ++bands;
-            if (const char* e = std::getenv("TRS_PILOT_FRAME5_BANDS")) bands = std::max(bands, std::min(std::atoi(e), l.OH));
+            if (T.frame5_bands > 0) bands = std::max(bands, std::min((int)T.frame5_bands, l.OH));
             const int ohb = (l.OH + bands - 1) / bands, ihb = bands == 1 ? l.IH : 2 * ohb + 3;
             const size_t unit = (size_t)ihb * l.IW * 64;
             int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
             if (bands > 1) f = std::min(f, 1);
             while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
-            if (const char* e = std::getenv("TRS_PILOT_FRAME5_F")) f = std::max(1, std::min(f, std::atoi(e)));
+            if (T.frame5_f > 0) f = std::max(1, std::min(f, (int)T.frame5_f));
             // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; TRS_PILOT_FRAME5 = 2 forces bands)
             if (on && (bands == 1 || on >= 2) && shape_ok && f >= 1 && f * unit + 256 <= 158 * 1024) {
                 l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
@@ -2439,14 +2450,12 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
-        int want_r2 = 6;                                                  // measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
-        if (const char* e = std::getenv("TRS_PILOT_FUSE_R2")) want_r2 = std::max(1, std::atoi(e));
-        c->fuse12 = false; c->fuse_band = false; c->no_fuse = std::getenv("TRS_PILOT_NO_FUSE") != nullptr;
+        const int want_r2 = std::max(1, (int)T.fuse_r2);                  // 6: measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
+        c->fuse12 = false; c->fuse_band = false; c->no_fuse = T.no_fuse != 0;
         // band form (conv1's input staged once per band as a bf16 image): tile + band image + 8 wave stages
         // (measured, 1024 frames of 120x160: R2 = 7 / 6 / 5 -> 129 / 114 / 125 us against 131 for the direct form; 512 frames of
         // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
-        int band_r2 = 6;
-        if (const char* e = std::getenv("TRS_PILOT_FUSE_BAND_R2")) band_r2 = std::atoi(e);            // 0 = use the direct form
+        const int band_r2 = T.fuse_band_r2;                               // 6; 0 = use the direct form
         for (int r2 = std::min(band_r2, l1.OH); shape_ok && band_ok && r2 >= std::min(4, l1.OH); --r2) {
             const int rows_in = 2 * (2 * r2 + 3) + 3, row_in = l0.IW * 3;
             if (row_in % 16 != 0 || rows_in * row_in > kBandPf * 512 * 16) continue;
@@ -2461,8 +2470,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         }
         // the band cut in width (240x320: a whole-width band does not fit): parts of w2p conv2 columns, each with its own conv1 tile and
         // staged frame-row segments (a part re-stages 2 x 3 + 3 input columns and recomputes 3 conv1 columns of its neighbour)
-        int max_split = 4;
-        if (const char* e = std::getenv("TRS_PILOT_FUSE_WSPLIT")) max_split = std::atoi(e);          // 1 = never cut in width
+        const int max_split = T.fuse_wsplit_max;                          // 4; 1 = never cut in width
         for (int ws = 2; shape_ok && !c->fuse12 && band_r2 > 0 && ws <= max_split; ++ws) {
             const int w2p = (l1.OW + ws - 1) / ws, w2_last = l1.OW - (ws - 1) * w2p, w1m = 2 * w2p + 3, w1_last = 2 * w2_last + 3;
             if (w2_last < 15 || w1m * 19 >= 65536) continue;
@@ -2510,8 +2518,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         c->fuse.w2 = c->w2_parity;
     }
     {   // conv4..conv7 (or conv5..conv7) as one launch when F frames of all their activations fit LDS; TRS_PILOT_CHAIN = 0: off, 3 / 4: layers
-        int want = 4;
-        if (const char* e = std::getenv("TRS_PILOT_CHAIN")) want = std::atoi(e);
+        const int want = T.chain_layers;
         c->chain_first = -1;
         for (int nl = std::min(want, 4); nl >= 3 && c->chain_first < 0; --nl) {
             const int first = 7 - nl;
@@ -2541,7 +2548,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                     const int px = (split && j == 0 ? f / 2 : f) * l.OH * l.OW, cgrps = l.COUT / 64;
                     auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
                     int nt = busiest(3) <= busiest(2) ? 3 : 2;
-                    if (const char* e = std::getenv("TRS_PILOT_CHAIN_NT")) { const int v = std::atoi(e); if (v == 2 || v == 3) nt = v; }
+                    if (T.chain_nt == 2 || T.chain_nt == 3) nt = T.chain_nt;
                     q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt};
                 }
                 c->chain_first = first; c->chain_lds = (int)total;
@@ -2549,8 +2556,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         }
     }
     {   // dense1 (and dense4) on trs_pilot_dense_kernel; TRS_PILOT_DENSE = 0: the chunked kernel (A/B measurements)
-        int mode = 1;
-        if (const char* e = std::getenv("TRS_PILOT_DENSE")) mode = std::atoi(e);
+        const int mode = T.dense;
         c->dense_new = mode >= 1 && c->L[7].COUT_PAD == 128 && c->L[7].G % 16 == 0;
     }
     HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
@@ -2663,14 +2669,14 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
     HIPCHK(hipSetDevice(v.device));
     if (layer == 0 && !c->act0_valid) {                                     // the fused head never wrote conv1's activation: run the unfused conv1 now
-        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count);
+        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count, c->tun);
         if (rc) return rc;
         c->act0_valid = true;
     }
     if (c->chain_first >= 0 && layer >= c->chain_first && layer < 6 && !c->chain_mid_valid) {   // the chain kept these activations in LDS: run the single layers now
         for (int j = c->chain_first; j < 6; ++j) {
             const void* src = j == 0 ? (const void*)c->last_frames : c->act[j - 1];
-            int rc = launch_conv(c->L[j], src, (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count);
+            int rc = launch_conv(c->L[j], src, (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count, c->tun);
             if (rc) return rc;
         }
         c->chain_mid_valid = true;

@@ -31,6 +31,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <string>
 
@@ -48,12 +49,18 @@ constexpr int kSlots = 8;       // posts in flight: ring entries, arrival counte
 constexpr int kCamDepth = 4;    // steps the physics team may run ahead of the raster team
 
 struct WEntry {                 // one posted step: ONE 64-B line, so the dispatcher learns of a post and gets it in one PCIe read
-    const float* steer; const float* thr; const float* brk; const uint8_t* reset;
+    uint64_t seq_lo;            // step index + 1: the tag of the line's FIRST 32-byte half, written by the host after steer / thr / brk
+    const float* steer; const float* thr; const float* brk;
+    const uint8_t* reset;
     uint32_t synth, pad0;
-    uint64_t seq;               // step index + 1, written LAST by the host: the line is valid for step s iff seq == s + 1
-    uint64_t pad1[2];
+    uint64_t seq;               // step index + 1, written LAST: the tag of the second half.  The line is a valid post for step s iff
+                                // seq_lo == seq == s + 1 — should the device's 64-byte read ever be served as two 32-byte requests, a
+                                // stale half cannot pair with a fresh one (each half carries its own tag, written after its payload)
+    uint64_t pad1;
 };
 static_assert(sizeof(WEntry) == 64, "one entry per 64-B line");
+constexpr int kTagLo = 0, kTagHi = 6;   // u64 word indices of the two tags within a line
+static_assert(offsetof(WEntry, seq_lo) == 8 * kTagLo && offsetof(WEntry, seq) == 8 * kTagHi && offsetof(WEntry, reset) == 32, "tag placement");
 
 struct Mailbox {                // pinned host memory the device reads and writes over PCIe
     alignas(64) uint64_t close;             // host -> device: leave once everything posted is done
@@ -82,8 +89,11 @@ struct WParams {
     unsigned long long start;                               // first step index this launch processes
     unsigned long long idle_ticks, life_ticks, safety_ticks;   // wall_clock64() ticks (100 MHz)
     int lds_off_phys, lds_off_ctl, n_blocks;
-    int diag;                                               // diagnostics (env TRS_RESIDENT_DIAG, never set by the product): 1 = arrive without the counted wait, 2 = no telemetry stores
 };
+#ifndef TRS_RESIDENT_DIAG
+#define TRS_RESIDENT_DIAG 0   /* timing-only diagnostic builds (-DTRS_RESIDENT_DIAG=bits), never shipped, like TRS_ABLATE: 1 = arrive without the counted wait (WRONG completion flags), 2 = no telemetry stores, 4 = clock probe of one raster wave into stats[40..44] */
+#endif
+constexpr int kDiag = TRS_RESIDENT_DIAG;
 
 struct Resident {
     bool enabled = false, running = false;
@@ -94,7 +104,10 @@ struct Resident {
     hipStream_t sC = nullptr;            // copies while the worker owns the handle's stream
     uint64_t base = 0;                   // steps [base, step_count) were handed to the worker since the last quiesce
     uint64_t seen_done = 0;              // every step below this index has been observed complete
+    bool launched = false;               // steps were LAUNCHED on the handle's stream since the last wait (trs_step_pilot in resident mode): no
+                                         // completion flag will ever be written for them — the stream is what to wait for
     unsigned idle_us = 2000;
+    unsigned life_us = 500000;           // a worker leaves after this long whatever happens (trs_resident_debug_lifetime: tests force many generations)
     unsigned char* hctl = nullptr;       // pinned staging for host-array controls: [kSlots] x (3 float[n] + uint8[n])
     size_t hctl_slot = 0;
     int lds_bytes = 0, lds_off_ctl = 0;
@@ -202,18 +215,19 @@ __device__ __forceinline__ int dispatcher_take(const WParams& wp, const WLds& l,
     int fresh = 0;
     for (; fresh < kSlots; ++fresh) {
         const int slot = (int)((L.known + (u64)fresh) & (kSlots - 1));
-        const int src = slot * 8 + 5;                        // u64 word 5 of a line = its tag
-        const u64 tag = ((u64)(unsigned)__shfl((int)(v >> 32), src, 64) << 32) | (u64)(unsigned)__shfl((int)v, src, 64);
-        if (tag != L.known + (u64)fresh + 1) break;
+        const int hi = slot * 8 + kTagHi, lo = slot * 8 + kTagLo;   // both halves of the line carry the tag
+        const u64 tag = ((u64)(unsigned)__shfl((int)(v >> 32), hi, 64) << 32) | (u64)(unsigned)__shfl((int)v, hi, 64);
+        const u64 tag_lo = ((u64)(unsigned)__shfl((int)(v >> 32), lo, 64) << 32) | (u64)(unsigned)__shfl((int)v, lo, 64);
+        if (tag != L.known + (u64)fresh + 1 || tag_lo != tag) break;
     }
     if (fresh == 0) return 0;
     const int rel = (int)(((u64)(lane >> 3) - L.known) & (kSlots - 1));   // this lane's slot is the rel-th behind `known`
     if (rel < fresh) agent_store64(reinterpret_cast<u64*>(&wp.dc->ring[0]) + lane, v);
     drain_vmem();                                            // the entries are in the device ring before the count says so
     L.known += (u64)fresh;
-    if (lane == 0) {                                         // max, not store: an abort bit another workgroup has set stays
-        __hip_atomic_fetch_max(&wp.dc->word, L.known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lds_store64(l.word, L.known);
+    if (lane == 0) {                                         // max, not store: an abort bit (1 << 62: above every count) stays set, in the
+        __hip_atomic_fetch_max(&wp.dc->word, L.known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device word another workgroup OR'ed it into
+        __hip_atomic_fetch_max(l.word, L.known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // and in the LDS word a wave of THIS workgroup did
     }
     return fresh;
 }
@@ -242,7 +256,11 @@ __device__ __forceinline__ void dispatcher_run(const WParams& wp, const WLds& l,
         if (lane == 0) {
             sys_store64(&wp.mb->consumed, L.known);
             const u64 w = L.known | kExitBit;                // the EXIT bit goes out once, with the FINAL count
-            __hip_atomic_fetch_max(&wp.dc->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds_store64(l.word, w);
+            // EXIT (1 << 63) outranks ABORT (1 << 62) in a max: an abort that arrived just before is carried over by hand
+            const u64 old_g = __hip_atomic_fetch_max(&wp.dc->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old_g & kAbortBit) __hip_atomic_fetch_or(&wp.dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 old_l = __hip_atomic_fetch_max(l.word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old_l | old_g) & kAbortBit) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         drain_vmem();
         return;
@@ -382,12 +400,12 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             const int r = (int)(s - wp.start);
             if (!wait_posted(wp, l, D, s, lane)) break;
             const u64* en = reinterpret_cast<const u64*>(&wp.dc->ring[s & (kSlots - 1)]);
-            const u64 ev = lane < 5 ? agent_load64(en + lane) : 0ull;
-            const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 0));
-            const float* const c_th = reinterpret_cast<const float*>(lane_u64(ev, 1));
-            const float* const c_br = reinterpret_cast<const float*>(lane_u64(ev, 2));
-            const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(lane_u64(ev, 3));
-            const int synth = (int)(unsigned)lane_u64(ev, 4);
+            const u64 ev = lane < 6 ? agent_load64(en + lane) : 0ull;   // words 1..5 of the entry (WEntry): steer, thr, brk, reset, synth
+            const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 1));
+            const float* const c_th = reinterpret_cast<const float*>(lane_u64(ev, 2));
+            const float* const c_br = reinterpret_cast<const float*>(lane_u64(ev, 3));
+            const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(lane_u64(ev, 4));
+            const int synth = (int)(unsigned)lane_u64(ev, 5);
             for (int j = pw - first; j < n_loc; j += nphys) {
                 const int e = e_begin + j;
                 // back-pressure: slot r % kCamDepth is free once every raster wave has read step r - kCamDepth of this env
@@ -478,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     Duties none{false, false, 0};
     u64 owed = wp.start;                                      // oldest step this wave has not arrived for
     // diagnostics (diag bit 4): where one raster wave (workgroup 7, wave 0) spends its clocks, into stats[40..45]
-    const bool probe = (wp.diag & 4) && blockIdx.x == 7 && wave == 0;
+    const bool probe = (kDiag & 4) && blockIdx.x == 7 && wave == 0;
     auto now_clk = [&]() -> u64 { u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
     u64 t_post = 0, t_pose = 0, t_vm = 0, t_all = 0, t_mark = probe ? now_clk() : 0;
     for (u64 s = wp.start;; ++s) {
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             if (j == 0)                                       // arrivals owed: everything this wave has issued since the end of step `owed`
                 while (s - owed >= keep) {                    // is (s - owed - 1) whole steps + this step's uniform rows so far
                     const u64 tv0 = probe ? now_clk() : 0;
-                    if (!(wp.diag & 1)) wait_vmcnt_le((int)(s - owed - 1) * nstep + (sweep ? nuni : nu));
+                    if (!(kDiag & 1)) wait_vmcnt_le((int)(s - owed - 1) * nstep + (sweep ? nuni : nu));
                     if (probe) t_vm += now_clk() - tv0;
                     raster_arrive(l, owed++, lane);
                 }
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel) : "memory");
             if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             raster_ground_rows<DEPTH>(p, rth, fd, cam);
-            if (mine && !(wp.diag & 2)) {                     // the step's telemetry of env j: two wave instructions, written through
+            if (mine && !(kDiag & 2)) {                     // the step's telemetry of env j: two wave instructions, written through
                 const size_t e = (size_t)(e_begin + j);
                 if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -560,13 +578,21 @@ __global__ void trs_worker_init_kernel(DevCtl* dc, u64 start)
 inline uint64_t host_load(const uint64_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 inline void host_store(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 
+// the worker's LDS need with the track that is loaded NOW (a larger track may have been loaded since resident mode was selected)
+int worker_fits(trs_env* e)
+{
+    Resident* R = e->res;
+    R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables
+    R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
+    if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
+    return TRS_OK;
+}
+
 int worker_launch(trs_env* e, uint64_t start)
 {
     Resident* R = e->res;
     Mailbox* mb = R->mb;
-    R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables of the track that is loaded NOW
-    R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
-    if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
+    { int rc = worker_fits(e); if (rc) return rc; }
     host_store(&mb->exited, 0); host_store(&mb->consumed, start); host_store(&mb->error, 0);
     host_store(&mb->close, 0);
     WParams wp{};
@@ -576,12 +602,7 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.mb = mb; wp.dc = R->dc;
     wp.start = start;
     wp.idle_ticks = (unsigned long long)R->idle_us * 100ull;
-    wp.life_ticks = 50000000ull;                            // 0.5 s: then the dispatcher leaves and the host starts a new worker at its next post
-    if (const char* dg = std::getenv("TRS_RESIDENT_DIAG")) wp.diag = std::atoi(dg);
-    if (const char* lf = std::getenv("TRS_RESIDENT_LIFE_US")) {   // tests: force many worker generations in a short run
-        const long v = std::atol(lf);
-        if (v > 0) wp.life_ticks = (unsigned long long)v * 100ull;
-    }
+    wp.life_ticks = (unsigned long long)R->life_us * 100ull;   // 0.5 s by default: then the dispatcher leaves and the host starts a new worker at its next post
     wp.safety_ticks = 200000000ull;                         // 2 s
     wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl;
     const int grid = (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg;
@@ -672,15 +693,18 @@ int resident_post(trs_env* e, const float* st, const float* th, const float* br,
     if (R->broken) return trs_internal_fail(TRS_ERR_DEVICE, "a resident worker gave up earlier: the env state is undefined, load the track again (trs_load_track)");
     for (int k = 0; k < n; ++k) {
         const uint64_t s = e->step_count;
-        if (!R->running) R->base = R->seen_done = s;           // no worker: nothing is in flight (the step counter may have moved or restarted since)
+        if (!R->running) { R->base = R->seen_done = s; R->launched = false; }   // no worker: nothing is in flight that a flag will report (the step counter may have moved or restarted since; launched steps are ahead of the worker on the same stream)
         if (s >= R->base + kSlots) { int rc = wait_done(e, s - kSlots); if (rc) return rc; }   // ring slot, counters and done flag of s % 8 are free
         WEntry en{};
         const size_t off = (size_t)k * stride;
         en.steer = st ? st + off : nullptr; en.thr = th ? th + off : nullptr; en.brk = br ? br + off : nullptr;
         en.reset = k == 0 ? rs : nullptr; en.synth = synth ? 1u : 0u;
+        if (!R->running) { int rc = worker_fits(e); if (rc) return rc; }   // nothing is published for a worker that could not be launched
         WEntry* slot = &mb->ring[s & (kSlots - 1)];
-        slot->steer = en.steer; slot->thr = en.thr; slot->brk = en.brk; slot->reset = en.reset; slot->synth = en.synth;
-        host_store(&slot->seq, s + 1);                            // the tag last (x86 keeps the store order): the line is now a valid post
+        slot->steer = en.steer; slot->thr = en.thr; slot->brk = en.brk;
+        host_store(&slot->seq_lo, s + 1);                         // first half: payload, then its tag (x86 keeps the store order)
+        slot->reset = en.reset; slot->synth = en.synth;
+        host_store(&slot->seq, s + 1);                            // second half likewise; this tag last: the line is now a valid post
         host_store(&mb->posted, s + 1);
         std::atomic_thread_fence(std::memory_order_seq_cst);     // the post is visible before `exited` is read
         e->step_count = s + 1;
@@ -693,8 +717,25 @@ int resident_post(trs_env* e, const float* st, const float* th, const float* br,
 int resident_wait(trs_env* e)
 {
     Resident* R = e->res;
-    if (!R || e->step_count <= R->seen_done || e->step_count <= R->base) return TRS_OK;
+    if (!R) return TRS_OK;
+    if (R->launched && !R->running) {                        // the newest steps went through launches (resident_note_launch): wait for the stream
+        RCHK(hipStreamSynchronize(e->sP));
+        R->launched = false;
+        R->base = R->seen_done = e->step_count;
+        return TRS_OK;
+    }
+    if (e->step_count <= R->seen_done || e->step_count <= R->base) return TRS_OK;
     return wait_done(e, e->step_count - 1);
+}
+
+// a step was launched on the handle's stream although resident mode is selected (the pilot loop: its kernels need the LDS a worker
+// would hold).  The caller has quiesced the worker; the step has no post and gets no completion flag.
+void resident_note_launch(trs_env* e)
+{
+    Resident* R = e->res;
+    if (!R) return;
+    R->launched = true;
+    R->base = R->seen_done = e->step_count;
 }
 
 int resident_quiesce(trs_env* e)
@@ -710,7 +751,7 @@ int resident_quiesce(trs_env* e)
     if (!rc && R->running) rc = trs_internal_fail(TRS_ERR_DEVICE, "resident worker did not leave");
     R->base = R->seen_done = e->step_count;
     if (!R->running)                                         // tags and flags of the past must not match a step index that comes round again
-        for (int k = 0; k < kSlots; ++k) { host_store(&R->mb->ring[k].seq, 0); host_store(&R->mb->done[k], 0); }
+        for (int k = 0; k < kSlots; ++k) { host_store(&R->mb->ring[k].seq, 0); host_store(&R->mb->ring[k].seq_lo, 0); host_store(&R->mb->done[k], 0); }
     return rc;
 }
 
@@ -760,6 +801,14 @@ int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const f
 }
 
 }  // namespace trsim
+
+TRS_EXPORT int trs_resident_debug_lifetime(trs_env* e, int life_us)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    if (!e->res) return trs_internal_fail(TRS_ERR_STATE, "resident mode has not been selected on this handle");
+    e->res->life_us = life_us > 0 ? (unsigned)std::min(life_us, 10000000) : 500000u;
+    return TRS_OK;
+}
 
 TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
 {

@@ -77,6 +77,7 @@ SLOT_AI = (0, 1, 2)            # 'ai/steering', 'ai/throttle', 'ai/breaking'    
 SLOT_MODE = 3                  # 'usr/mode' as uint8 codes                         (BatchedControlMultiplexer, HipKerasPilot)
 SLOT_USR = (4, 5, 6)           # 'usr/steering', 'usr/throttle', 'usr/breaking'   (uploaded joystick values)
 SLOT_MUX = (7, 8, 9)           # 'mux/steering', 'mux/throttle', 'mux/breaking'   (BatchedControlMultiplexer)
+SLOT_PILOT_IN = (10, 11)       # 'gym/speed', 'loc/segment' that reached HipKerasPilot as HOST values beside a device frame
 
 
 def _stream_ptr(stream):
@@ -197,6 +198,11 @@ class BatchedEnv:
 
     def sync(self):
         self.api.check(self.api.sync(self._h), "sync")
+
+    def quiesce(self):
+        """Resident mode: the worker kernel leaves the GPU (posted steps complete first); the next step starts a new one
+        (``trs_quiesce``).  Call before work of another stream that needs the CUs the worker occupies (collectives)."""
+        self.api.check(self.api.quiesce(self._h), "quiesce")
 
     # -- outputs -----------------------------------------------------------------------------
     def _shape(self, name):
@@ -395,6 +401,29 @@ class BatchedEnv:
         arrs = [np.ascontiguousarray(w, dtype=np.float32) for w in weights]
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         self.api.check(self.api.pilot_load(self._h, ptrs, len(arrs)), "pilot_load")
+
+    def pilot_tuning(self, **choices):
+        """Override kernel choices of the NEXT ``pilot_load`` (``trs_pilot_tuning``, include/trsim.h) — tests that compare a kernel
+        with the one it replaced, and measurements.  No arguments: back to the defaults.  ``frame_bands`` takes 4 ints."""
+        if not choices:
+            self.api.check(self.api.pilot_set_tuning(self._h, None), "pilot_set_tuning")
+            return
+        t = _ffi.TrsPilotTuning()
+        self.api.default_pilot_tuning(C.byref(t))
+        names = {f[0] for f in _ffi.TrsPilotTuning._fields_} - {"struct_size"}
+        for k, v in choices.items():
+            if k not in names:
+                raise ValueError(f"trs_pilot_tuning has no field {k!r}")
+            if k == "frame_bands":
+                for i, b in enumerate(v):
+                    t.frame_bands[i] = int(b)
+            else:
+                setattr(t, k, int(v))
+        self.api.check(self.api.pilot_set_tuning(self._h, C.byref(t)), "pilot_set_tuning")
+
+    def resident_lifetime(self, life_us):
+        """Test hook (``trs_resident_debug_lifetime``): resident workers leave by themselves after ``life_us``."""
+        self.api.check(self.api.resident_debug_lifetime(self._h, int(life_us)), "resident_debug_lifetime")
 
     def pilot_config(self, cfg=None):
         pc = _ffi.TrsPilotConfig()

@@ -49,6 +49,10 @@ class ShardedEnvs:
         if not dist.is_initialized():
             return torch.from_numpy(self.env.fetch(name))
         if dist.get_backend() == "nccl":                       # device-resident, zero copy: RCCL all-gather over xGMI
+            # a resident worker holds one workgroup slot on EVERY CU and most of their LDS; the collective's kernel of another
+            # stream must not have to squeeze in beside it (and with N > 1 must not wait on a peer whose worker never yields):
+            # ask the worker to leave first, as the C-ABI path does (trs_allgather_returns -> quiesce); the next step restarts it
+            self.env.quiesce()
             local = torch.as_tensor(self.env.device_array(name), device="cuda")      # (device_array waits for the env's stream)
             out = torch.empty(self.n_total, dtype=local.dtype, device="cuda")
         else:                                                  # gloo (CPU tests)
