@@ -49,6 +49,26 @@
  *   reset (usr/reset truthy, or auto_reset && previous done): state := start pose of the env,
  *   no integration this step, reward 0, last_return := ep_return, ep_return := 0, ep_len := 0.
  *
+ * ---- class map (the track surface the camera sees; built on the host in binary64) ----
+ *   polyline Q: the raw track points in (x, z), consecutive equal points dropped, a closing duplicate of the first dropped;
+ *     it is CLOSED: m points, m segments Q[k] -> Q[(k+1) mod m]; s_k = sum of the lengths of segments 0..k-1.
+ *   grid: cell = TRS_MAP_CELL_MIN * 2^j with the smallest j >= 0 for which the packed map fits TRS_MAP_LDS_BUDGET:
+ *     x0 = floor((min x of Q - map_margin) / cell) * cell,  GW = ceil((max x of Q + map_margin - x0) / cell);  z0, GH likewise;
+ *     MW = ceil(GW / 16) 32-bit words per row (16 cells of 2 bits, cell ix in bits 2*(ix mod 16)..+1 of word ix / 16);
+ *     it fits when MW * 4 * GH <= TRS_MAP_LDS_BUDGET.
+ *   cell (ix, iz), centre c = (x0 + (ix + 0.5) * cell, z0 + (iz + 0.5) * cell):
+ *     per segment k: t = clamp(((c - Q[k]) . (Q[k+1] - Q[k])) / |Q[k+1] - Q[k]|^2, 0, 1), foot = Q[k] + t (Q[k+1] - Q[k])
+ *     d   = min over k of |c - foot_k|  (Euclidean), taken at the LOWEST k that attains it
+ *     arc = s_k + t_k * |Q[k+1] - Q[k]| at that k  (arc length along the centre line)
+ *     class = CENTRE  if d <= centre_half and fmod(arc, dash_period) < dash_on      (dashed centre line)
+ *             EDGE    else if |d - road_half| <= edge_half                           (solid edge lines, centred on the road edge)
+ *             ROAD    else if d < road_half
+ *             GRASS   otherwise
+ *     the outermost ring of cells (ix = 0, GW-1 or iz = 0, GH-1) is GRASS whatever the rule says: lookups that fall outside
+ *     the map are clamped onto it.  (A builder may skip segments farther from a cell than road_half + edge_half + cell:
+ *     they cannot change the class.)
+ *   An independent numpy restatement of this paragraph checks both builders: tests/test_independent_spec.py.
+ *
  * ---- camera (pinhole over the ground plane y = 0; no roll) ----------------
  *   per image row v (tables built on the host in binary64, stored binary32):
  *     f = (H/2)/tan(fov_v/2);  yn = (H/2-(v+0.5))/f

@@ -11,6 +11,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -58,8 +59,24 @@ std::string g_rccl_err;
 bool load_rccl()
 {
     if (g_rccl.lib) return true;
-    const char* env = std::getenv("TRS_RCCL_LIB");
-    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const char* env = std::getenv("TRS_RCCL_LIB");                   // an explicit path wins (deployment knob, the only one this library reads)
+    // a copy some other module of the process has already mapped — PyTorch bundles its own librccl under torch/lib, which a lookup
+    // by soname would miss — is found by its PATH in /proc/self/maps and shared, so that one process never runs two RCCLs
+    std::string mapped;
+    if (!env) {
+        if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+            char line[4096];
+            while (std::fgets(line, sizeof line, f)) {
+                const char* path = std::strchr(line, '/');
+                if (!path || !std::strstr(path, "librccl.so")) continue;
+                mapped.assign(path);
+                while (!mapped.empty() && (mapped.back() == '\n' || mapped.back() == ' ')) mapped.pop_back();
+                break;
+            }
+            std::fclose(f);
+        }
+    }
+    const char* names[] = {env, mapped.empty() ? nullptr : mapped.c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
     for (const char* n : names) { if (n && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL))) break; }
     if (!h) for (const char* n : names) { if (n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
