@@ -200,10 +200,21 @@ def main():
         env.set_step_mode(True)
 
     def barrier():
+        # every step handed to the env so far is complete in memory (resident mode: completion flags; launch mode: the stream has drained),
+        # torch's own work is done, and every rank is here.  While a resident worker is on the GPU a DEVICE-wide synchronisation would
+        # wait for that kernel to end (it leaves 2 ms after the last post): resident mode synchronises torch's stream instead — the
+        # worker's steps are covered by env.sync() — so that the worker stays across the warm-up -> timed boundary (steady state:
+        # what a consumer that keeps posting sees)
         env.sync()
-        torch.cuda.synchronize()
         if dist is not None:
+            if resident:
+                env.quiesce()                       # the collective's kernel needs CU resources the worker holds: N > 1 restarts the worker inside the timed region
+            torch.cuda.synchronize()
             dist.barrier()
+            torch.cuda.synchronize()
+        elif resident:
+            torch.cuda.current_stream().synchronize()
+        else:
             torch.cuda.synchronize()
 
     if dist is not None:   # warm the communicator outside the timed region
@@ -213,14 +224,25 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    env.event_record(0)
+    if not resident:
+        env.event_record(0)
     run(args.steps)
-    env.event_record(1)
+    if not resident:
+        env.event_record(1)
     gathered = None
     if dist is not None:
-        gathered = shard.allgather("ep_return")                        # the single RCCL all-gather over xGMI (4 B per env)
+        gathered = shard.allgather("ep_return")                        # the single RCCL all-gather over xGMI (4 B per env; asks a resident worker to leave first)
     barrier()
     wall = time.perf_counter() - t0
+    if resident:
+        # the dominant kernel's launch duration by HIP events on its own stream: an event on that stream makes the worker leave, so this
+        # is a SECOND pass over the same K steps, bracketed by events = exactly one trs_worker_kernel launch (start-up, K steps, exit)
+        env.quiesce()
+        torch.cuda.synchronize()
+        env.event_record(0)
+        run(args.steps)
+        env.event_record(1)
+        env.sync()
     kernel_ms = env.event_elapsed_ms(0, 1)
 
     # informational only (never part of `value`): the same workload with 8 steps per launch, timed separately
@@ -331,6 +353,36 @@ def main():
                 env5.close()
             except Exception as exc:
                 pilot5_leg = {"error": str(exc)}
+        # ... and BASELINE configs[3]'s per-GPU share: the LAST shard of the 4096-env job (512 envs, global ids 3584..4095), every step
+        # posted on its own to its resident worker — the only driver-side evidence for the 8-GPU target while no 8-GPU node runs this
+        shard_leg = None
+        if (args.img_h, args.img_w) == (120, 160) and not args.depth:
+            try:
+                from triton_racer_sim_amd.env import BatchedEnv
+                env3 = BatchedEnv(n_envs=512, env_id_base=3584, img_h=120, img_w=160, auto_reset=True, device=local_rank)
+                env3.set_step_mode(True)
+                s3 = max(args.steps, 1000)
+                env3.step_synthetic(200, 1)
+                env3.sync()
+                t5 = time.perf_counter()
+                env3.step_synthetic(s3, 1)
+                env3.sync()                                             # completion flags: the worker stays resident (steady state)
+                wall3 = time.perf_counter() - t5
+                env3.event_record(0)                                    # (the worker leaves) ... and one worker launch bracketed by HIP events
+                env3.step_synthetic(s3, 1)
+                env3.event_record(1)
+                ms3 = env3.event_elapsed_ms(0, 1)
+                B3 = algorithmic_bytes(120, 160, True)
+                shard_leg = {"env_steps_per_s": round(512 * s3 / wall3, 1), "us_per_step": round(wall3 * 1e6 / s3, 3),
+                             "frac_of_hbm_peak": round(B3 * 512 * s3 / wall3 / 1e9 / HBM_PEAK_GBS, 5),
+                             "frac_of_hbm_peak_by_hip_events": round(B3 * 512 * s3 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                             "x8_gpus_env_steps_per_s": round(8 * 512 * s3 / wall3, 1),
+                             "note": "512 envs at env_id_base 3584 = one GPU's share of BASELINE configs[3] (4096 envs over 8 GPUs), resident worker, every step posted on its own; "
+                                     "host wall clock between completion flags (steady state), and one worker launch by HIP events; x8 = what eight independent shards add up to "
+                                     "(no data-path collective; the one all-gather of 4 B per env is outside the step loop)"}
+                env3.close()
+            except Exception as exc:
+                shard_leg = {"error": str(exc)}
         env.set_step_mode(resident)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -353,6 +405,8 @@ def main():
             also["pilot_closed_loop"] = pilot_leg
         if pilot5_leg:
             also["pilot_closed_loop_512x240x320_depth"] = pilot5_leg
+        if shard_leg:
+            also["shard_512_of_4096"] = shard_leg
     if dist is not None:
         tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -394,7 +448,9 @@ def main():
                             + (" + fp32 depth" if render and args.depth else "")
                             + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
                             + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
-                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
+                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call",
+                "timing": ("host wall clock from the post of the first timed step to the completion flag of the last (worker resident across the warm-up -> timed boundary); "
+                           "roofline.achieved from a second pass of the same steps bracketed by HIP events = one whole worker launch") if resident else "host wall clock around the timed steps; HIP events on the env's stream for roofline.achieved", "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

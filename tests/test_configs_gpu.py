@@ -71,6 +71,51 @@ def test_configs4_closed_loop_240x320_depth_pilot_in_the_loop(make_env):
     assert np.array_equal(g2.fetch("img"), o.fetch("img"))
 
 
+def test_configs4_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
+    """configs[4]'s closed loop against a loop that shares NO code with the product: the env half is the
+    CPU oracle, the pilot half is PyTorch — the fp32 "mirror" of tests/test_pilot.py (fp32 arithmetic on bf16-rounded weights
+    and activations, i.e. the product's stated arithmetic, any summation order) — and KerasPilot's post-processing is the
+    reference's scalar Python (keras_pilot.py:78-95).  6 ticks, 240x320 RGB + depth.
+    Tolerances: the two pilots differ by fp32 summation order in front of bf16 roundings: raw outputs within 2e-2 (stated bound
+    of tests/test_pilot.py is 5e-2 against PURE fp32; the mirror is closer), controls within 3e-2; six ticks of 0.05 s at
+    <= 3 units/s turn that into <= 5e-3 in pose and 2e-2 in speed; the tracker index may differ where a car sits on the
+    boundary between two track points (at most one env), and frames are compared through the pose (<= 2 % of the pixels)."""
+    from test_pilot import make_weights, pilot_postprocess, torch_layer, torch_tail
+    n, h, w, ticks = 8, 240, 320, 6
+    ws = make_weights(h, w, seed=19)
+    cfg = {"spd_ctl_threshold": 1.1, "spd_ctl_reverse_multiplier": 1.0}
+    g = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True)
+    g.pilot_load(ws)
+    g.step_pilot(1, cfg)                                             # tick 1: no frame yet -> (0, 0, 0)
+    o = make_env("oracle", n_envs=n, img_h=h, img_w=w, depth=True)
+    o.step(0.0, 0.0, 0.0)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+
+    def mirror_pilot(frames):
+        x = frames
+        for layer in range(8):
+            x = torch_layer(layer, x, ws, mirror=True)
+        return torch_tail(x, ws)
+
+    worst_ctl = 0.0
+    for _ in range(ticks - 1):
+        out = mirror_pilot(o.fetch("img"))
+        spd = o.fetch("speed")
+        ctl = np.array([pilot_postprocess(out[i], float(spd[i]), cfg) for i in range(n)], dtype=np.float32)
+        o.step(ctl[:, 0], ctl[:, 1], ctl[:, 2])
+        g.step_pilot(1, cfg)
+        got = np.stack([g.fetch("ctl_steer"), g.fetch("ctl_thr"), g.fetch("ctl_brk")], 1)     # what the product's pilot fed the env this tick
+        worst_ctl = max(worst_ctl, float(np.max(np.abs(got - ctl))))
+    assert worst_ctl <= 3e-2, worst_ctl
+    for name, tol in (("pos_x", 5e-3), ("pos_z", 5e-3), ("yaw", 5e-3), ("speed", 2e-2), ("cte", 5e-3)):
+        assert np.max(np.abs(g.fetch(name) - o.fetch(name))) <= tol, (name, float(np.max(np.abs(g.fetch(name) - o.fetch(name)))))
+    assert np.count_nonzero(g.fetch("seg_idx") != o.fetch("seg_idx")) <= 1
+    assert np.array_equal(g.fetch("done"), o.fetch("done"))
+    assert np.mean((g.fetch("img") != o.fetch("img")).any(-1)) <= 0.02
+    assert np.array_equal(g.fetch("depth"), o.fetch("depth"))         # z-depth depends on the camera row only
+    assert g.fetch("speed").max() > 0.1                               # the cars did move under the pilot (random-init weights: gentle throttle)
+
+
 def test_allgather_through_torch_nccl_and_through_the_c_abi(make_env):
     """The one collective of the path, at world size 1 on this box's GPU: (a) ShardedEnvs.allgather over a torch.distributed
     nccl group (= RCCL): the zero-copy device-array branch; (b) trs_comm_init with a real RCCL unique id + trs_allgather_returns

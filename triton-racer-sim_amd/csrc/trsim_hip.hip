@@ -570,16 +570,32 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
 }
 
 // ImgPreprocessing with the Canny edge layer (components/img_preprocessing.py:37-54,76-79): cv2.Canny(img, a, b) on the trimmed
-// 3-channel frame, OpenCV's algorithm (see oracle/trsim_oracle.c canny_u8c3 for the statement).  One 512-thread workgroup per
-// frame; LDS holds the trimmed frame (H*W*3 B), the gradient magnitudes with a zero border ((H+2)*(W+2) int16) and the
-// edge map (H*W B: winning channel, then 0 = weak / 1 = no / 2 = edge).  Hysteresis = repeated 8-neighbour sweeps until
-// a block-wide OR reports no change.  Frames up to ~26,000 pixels (LDS); bound: LDS latency, not HBM.
+// 3-channel frame, OpenCV's algorithm (see oracle/trsim_oracle.c canny_u8c3 for the statement).  One 1024-thread workgroup per
+// frame; LDS holds the trimmed frame (H*W*3 B), the gradient magnitudes with a zero border ((H+2) x (W+8) int16) and the
+// edge map (H*W B: direction class, then 0 = weak / 1 = no / 2 = edge).  Hysteresis = repeated 8-neighbour sweeps until
+// a block-wide OR reports no change.  Frames up to ~26,000 pixels (LDS).
+// Round 3 (counters first, profiles/r03_image_path.txt: the kernel is bound by instruction ISSUE — its SIMDs issue ~100 % of
+// the launch, 212 vector + 85 scalar instructions per pixel — not by LDS (11 % busy) or memory): the instruction count per
+// pixel was cut, phase by phase (timing-only builds -DTRS_EDGE_ABLATE: Sobel 60 of 154 us, output 44):
+//   * trim: one table of this frame's trim of every byte value (256 threads compute it once) instead of 9 operations per byte;
+//   * Sobel: in binary32 — every value is an integer below 2^24, so the arithmetic is exact and |x| is a free source modifier —
+//     on a thread that walks DOWN its 4-pixel column group (one new row of 18 values per output row instead of three), with the
+//     separable form (column sums t + 2m + b and differences b - t shared by the 4 pixels); the direction class from the same
+//     exact comparisons (|ys| 2^15 < |xs| 13573 etc.: all products below 2^24, the 67.5-degree test as
+//     fma(|xs|, -2^16, |ys| 2^15) > |xs| 13573, whose left side is 2^15 (|ys| - 2 |xs|));
+//   * output: the in-range tests of all (<= 4) filters from three table lookups (as trs_preprocess_kernel does).
+#ifndef TRS_EDGE_ABLATE
+#define TRS_EDGE_ABLATE 0   /* timing-only diagnostic builds of trs_preprocess_edge_kernel, never shipped (wrong results): 1 = no Sobel phase, 3 = no hysteresis, 4 = no output phase, 6 = no suppression compare (every pixel "no edge") */
+#endif
 constexpr int kEdgeBlock = 1024;          // 16 waves per frame (512 until round 2: the phases are latency chains of LDS reads, twice the waves hide twice as much)
+constexpr int kEdgeGpt = 5;              // 4-pixel groups per thread held in registers between the two passes over a frame: 5120 groups = 20,480 pixels (120x160: 4800 groups)
+constexpr int kEdgeTables = 512 * 4 + 3 * (kEdgeBlock / 64) * 4 + 16 + 256 * 4 + 3 * 256 * 4;   // s_tab | s_part | s_delta | s_trim | s_rng
 
-// Six pixels x three channels of frame row `row` around the 4-pixel group at column x0 (pixels x0 - 1 .. x0 + 4, replicated at the
-// frame's left / right edge) from five aligned dword reads (the first version read every byte on its own: 27 LDS reads per pixel
-// for the three Sobels, the kernel was bound by LDS instruction issue).  x0 % 4 == 0, so the group starts on a dword.
-__device__ __forceinline__ void edge_row(const unsigned char* simg, int W, int row, int x0, int (&v)[3][6])
+__device__ __forceinline__ bool has_zero_byte(unsigned w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; }
+
+// Six pixels x three channels of trimmed-frame row `row` around the 4-pixel group at column x0 (pixels x0 - 1 .. x0 + 4, replicated
+// at the frame's left / right edge) as binary32, from five aligned dword reads and one v_cvt_f32_ubyteN per value.  x0 % 4 == 0.
+__device__ __forceinline__ void edge_row_f(const unsigned char* simg, int W, int row, int x0, float (&v)[3][6])
 {
     const unsigned* base = reinterpret_cast<const unsigned*>(simg + ((size_t)row * W + x0) * 3);
     unsigned d[5];
@@ -590,7 +606,7 @@ __device__ __forceinline__ void edge_row(const unsigned char* simg, int W, int r
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int bi = 1 + 3 * j + c;                                     // byte of the 20-byte window that starts 4 bytes in front of the group
-            v[c][j] = (int)((d[bi >> 2] >> (8 * (bi & 3))) & 255u);
+            v[c][j] = (float)((d[bi >> 2] >> (8 * (bi & 3))) & 255u);
         }
     if (x0 == 0) {
 #pragma unroll
@@ -602,7 +618,39 @@ __device__ __forceinline__ void edge_row(const unsigned char* simg, int W, int r
     }
 }
 
-__device__ __forceinline__ bool has_zero_byte(unsigned w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; }
+// One output row of a 4-pixel group from its three input rows (t above, m the row itself, b below): per pixel the channel with the
+// largest |dx| + |dy| (first on ties), its norm (-> mag, 4 x int16 = one 8-byte store) and its direction class (-> map).
+__device__ __forceinline__ void edge_sobel_row(const float (&t)[3][6], const float (&m)[3][6], const float (&b)[3][6], short* mrow, unsigned char* maprow)
+{
+    // channel by channel (12 live column values instead of 36): column sums t + 2 m + b and differences b - t shared by the 4
+    // pixels, then per pixel the running best (a strictly larger norm replaces it: the FIRST channel that reaches the maximum wins)
+    float bn[4], xs[4], ys[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sv[6], dv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { sv[j] = __builtin_fmaf(2.0f, m[c][j], t[c][j]) + b[c][j]; dv[j] = b[c][j] - t[c][j]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = q + 1;
+            const float dx = sv[j + 1] - sv[j - 1];
+            const float dy = dv[j - 1] + __builtin_fmaf(2.0f, dv[j], dv[j + 1]);
+            const float nr = __builtin_fabsf(dx) + __builtin_fabsf(dy);
+            if (c == 0 || nr > bn[q]) { bn[q] = nr; xs[q] = dx; ys[q] = dy; }
+        }
+    }
+    unsigned cls4 = 0u, mg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float ax = __builtin_fabsf(xs[q]), tg22x = ax * 13573.0f, ay = __builtin_fabsf(ys[q]) * 32768.0f;
+        const float over = __builtin_fmaf(ax, -65536.0f, ay);                 // ay - (ax << 16), exact
+        const unsigned cls = ay < tg22x ? 0u : (over > tg22x ? 1u : (xs[q] * ys[q] < 0.0f ? 3u : 2u));
+        mg[q] = (unsigned)(int)bn[q];
+        cls4 |= cls << (8 * q);
+    }
+    *reinterpret_cast<uint2*>(mrow) = make_uint2(mg[0] | (mg[1] << 16), mg[2] | (mg[3] << 16));
+    *reinterpret_cast<unsigned*>(maprow) = cls4;
+}
 
 // SCRATCH = false: the three whole-frame work arrays live in LDS (frames up to ~26,000 pixels).  SCRATCH = true: they live in
 // a per-workgroup global scratch that stays in L2 (any frame size, e.g. config 5's 240x320); only the tables are in
@@ -612,126 +660,226 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
 {
     unsigned char* const work = SCRATCH ? p.scratch + (size_t)blockIdx.x * p.scratch_stride : smem;
     unsigned char* const simg = work;
-    short* const mag = reinterpret_cast<short*>(work + p.off_mag);
+    short* const mag = reinterpret_cast<short*>(work + p.off_mag);           // pixel (x, y) at mag[(y + 1) * MP + x + 4]: a group's 4 values are 8-byte aligned
     unsigned char* const map = work + p.off_map;
     int* const s_tab = reinterpret_cast<int*>(smem + p.off_tab);
     unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [kEdgeBlock / 64][3]
     float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
+    unsigned* const s_trim = reinterpret_cast<unsigned*>(s_delta + 4);        // [256] this frame's trim of every byte value
+    unsigned* const s_rng = s_trim + 256;                                    // [3][256] bit f: value x of component c (h, s, v) lies inside filter f's range
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = p.H, W = p.W, MW = W + 2, npx = H * W;
+    // Every phase takes its thread index through `fresh`: an empty asm the compiler cannot see through, so that what a phase derives from
+    // the index (row / column splits, addresses) is computed where it is used.  Left alone, hipcc hoisted those values of ALL phases in
+    // front of the frame loop and kept them alive across it: 65 spilled registers, 240 bytes of scratch per lane = 63 MB written at
+    // the start of a launch and re-read at every phase (the first frame's first phase took 40 k clocks against 3.7 k for the others).
+    auto fresh = [](int v) -> int { asm volatile("" : "+v"(v)); return v; };
+    const int H = p.H, W = p.W, MP = W + 8, npx = H * W;
     const size_t frame_bytes = (size_t)p.gpe * 12;
     for (int i = tid; i < 512; i += kEdgeBlock) s_tab[i] = p.hsv_tab[i];
+    for (int i = tid; i < 768; i += kEdgeBlock) {
+        const int c = i >> 8, x = i & 255;
+        unsigned bits = 0;
+        for (int f = 0; f < p.n_filters; ++f) {
+            const int lo = (p.lo[f] >> (8 * c)) & 255, hi = (p.hi[f] >> (8 * c)) & 255;
+            bits |= (x >= lo && x <= hi) ? 1u << f : 0u;
+        }
+        s_rng[i] = bits;
+    }
+    int fsel0 = -1, fsel1 = -1, fsel2 = -1;                                  // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it
+    for (int f = 0; f < p.n_filters; ++f) { const int dc = p.dst_ch[f]; if (dc == 0) fsel0 = f; else if (dc == 1) fsel1 = f; else if (dc == 2) fsel2 = f; }
+    // Sobel work items: (4-pixel column group, chunk of rows); the whole block works at once when the frame has <= 1024 / gpr chunks
+    const int nchunk = max(1, kEdgeBlock / p.gpr), rows_per = (H + nchunk - 1) / nchunk;
+#ifdef TRS_EDGE_STAMPS   /* diagnostic build: shader clocks per phase of workgroup 7, summed over its frames, printed at the end */
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define EDGE_STAMP(k) do { if (blockIdx.x == 7 && tid == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) ph[k] += tn - tprev; tprev = tn; } } while (0)
+#else
+#define EDGE_STAMP(k) do { } while (0)
+#endif
+    u3v R[kEdgeGpt];                                                          // this thread's groups of the frame (see below)
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
+        EDGE_STAMP(0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
-        for (int i = tid; i < (H + 2) * MW; i += kEdgeBlock) mag[i] = 0;
+        // magnitudes outside the image are 0: the rows above / below and the columns left / right of it (the interior is overwritten)
+        for (int i = fresh(tid); i < 2 * MP + 2 * H; i += kEdgeBlock) {
+            int idx;
+            if (i < MP) idx = i;
+            else if (i < 2 * MP) idx = (H + 1) * MP + (i - MP);
+            else { const int k = i - 2 * MP, y = k >> 1; idx = (y + 1) * MP + ((k & 1) ? W + 4 : 3); }
+            mag[idx] = 0;
+        }
+        // ---- the frame: kEdgeGpt groups per thread in registers, every load issued before the first is used (a thread that loaded and used
+        // its groups one after the other paid one memory round trip per group: the two passes over the frame were 29 % of the kernel).
+        // A frame of up to 1024 x kEdgeGpt groups (every frame whose work arrays fit LDS) is read from memory ONCE — both passes work
+        // on the registers — and the next frame's loads are issued as soon as the registers are free, in front of the Sobel phase.
+        // Larger frames take the passes in chunks of 1024 x kEdgeGpt groups (the second pass reads L2). ----
+        const int chunk_groups = kEdgeBlock * kEdgeGpt, nchunks = (p.gpe + chunk_groups - 1) / chunk_groups;
+        const bool one_chunk = nchunks == 1;
+        auto fetch = [&](const __amdgpu_buffer_rsrc_t& r, int c, u3v (&R)[kEdgeGpt]) {
+            const int t = fresh(tid);
+#pragma unroll
+            for (int k = 0; k < kEdgeGpt; ++k) R[k] = __builtin_amdgcn_raw_buffer_load_b96(r, (c * chunk_groups + k * kEdgeBlock + t) * 12, 0, 0);   // past the frame: zeros (buffer bounds)
+        };
+        if (!(one_chunk && img != (int)blockIdx.x)) fetch(rs, 0, R);        // (one-chunk frames after the first: prefetched during the previous frame)
         // ---- channel sums over the brightness rows -> delta (as trs_preprocess_kernel) ----
         unsigned sr = 0, sg = 0, sb = 0;
-        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += kEdgeBlock) {
-            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
-            sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
-            sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
-            sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+        for (int c = 0, t = fresh(tid); c < nchunks; ++c) {
+            if (c > 0) fetch(rs, c, R);
+#pragma unroll
+            for (int k = 0; k < kEdgeGpt; ++k) {
+                const int g = c * chunk_groups + k * kEdgeBlock + t;
+                if (g >= p.r0 * p.gpr && g < p.r1 * p.gpr) {
+                    const u3v w = R[k];
+                    sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
+                    sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
+                    sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+                }
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
         if (lane == 0) { s_part[wave * 3] = sr; s_part[wave * 3 + 1] = sg; s_part[wave * 3 + 2] = sb; }
         __syncthreads();
-        if (tid == 0) {
+        EDGE_STAMP(1);
+        // every wave of the table's 256 threads adds the 16 partial sums itself (lanes 0..15 one wave's three sums each, 4 shuffle steps:
+        // exact integers, any order) and evaluates the same binary64 expression: no serial pass by one thread, no barrier for the delta
+        if (tid < 256) {                                                    // this frame's trim of every byte value, in numpy's operation order (:92-99)
+            unsigned long long t3[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                unsigned v = lane < kEdgeBlock / 64 ? s_part[lane * 3 + ch] : 0u;
+                unsigned long long tot = v;
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)tot, off, 64), hi = __shfl_xor((unsigned)(tot >> 32), off, 64);
+                    tot += ((unsigned long long)hi << 32) | lo;
+                }
+                t3[ch] = tot;                                               // lanes 0..15 hold the total; lane 0's is broadcast below
+            }
             const double cnt = (double)(p.r1 - p.r0) * (double)W;
             double cur = 0.0;
+#pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                unsigned long long tot = 0;
-                for (int w = 0; w < kEdgeBlock / 64; ++w) tot += s_part[w * 3 + ch];
+                const unsigned long long tot = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(t3[ch] >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t3[ch]);
                 cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
             }
             cur = cur + 0.0;
-            *s_delta = (float)((p.baseline - cur) / 3);
+            const float deltaf = (float)((p.baseline - cur) / 3), off = p.offset, con = p.contrast;
+            float x = (float)tid;
+            if (p.dynamic) x = x + deltaf;
+            x = x - off; x = x * con; x = x + off;
+            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+            s_trim[tid] = (unsigned)(int)x;
         }
         __syncthreads();
-        const float deltaf = *s_delta, off = p.offset, con = p.contrast;
+        EDGE_STAMP(2);
         // ---- trimmed frame -> LDS ----
-        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
-            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
-            unsigned out[3] = {0u, 0u, 0u};
+        for (int c = 0, t = fresh(tid); c < nchunks; ++c) {
+            if (!one_chunk) fetch(rs, c, R);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const unsigned src = k < 4 ? w.x : (k < 8 ? w.y : w.z);
-                float x = (float)((src >> (8 * (k & 3))) & 255u);
-                if (p.dynamic) x = x + deltaf;
-                x = x - off; x = x * con; x = x + off;
-                x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
-                out[k >> 2] |= (unsigned)(int)x << (8 * (k & 3));
+            for (int k = 0; k < kEdgeGpt; ++k) {
+                const int g = c * chunk_groups + k * kEdgeBlock + t;
+                if (g < p.gpe) {
+                    const unsigned src[3] = {R[k].x, R[k].y, R[k].z};
+                    unsigned out[3];
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; ++k3) {
+                        const unsigned v = src[k3];
+                        out[k3] = s_trim[v & 255u] | (s_trim[(v >> 8) & 255u] << 8) | (s_trim[(v >> 16) & 255u] << 16) | (s_trim[v >> 24] << 24);
+                    }
+                    unsigned* d = reinterpret_cast<unsigned*>(simg + (size_t)g * 12);
+                    d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+                }
             }
-            unsigned* d = reinterpret_cast<unsigned*>(simg + g * 12);
-            d[0] = out[0]; d[1] = out[1]; d[2] = out[2];
+        }
+        if (one_chunk && img + (int)gridDim.x < p.n_img) {                 // the next frame of this workgroup: on its way during the phases below
+            const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)(img + gridDim.x) * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+            fetch(rn, 0, R);
         }
         __syncthreads();
-        // ---- Sobel per channel, the channel with the largest |dx| + |dy| wins (first on ties); a thread takes 4-pixel groups ----
+        EDGE_STAMP(3);
+        // ---- Sobel per channel, the channel with the largest |dx| + |dy| wins (first on ties) ----
         // mag <- the winner's norm, map <- its gradient direction class for the non-maximum suppression (OpenCV's fixed-point
         // tangents: 0 = compare left / right, 1 = up / down, 2 / 3 = the two diagonals), so that the suppression needs no second Sobel
-        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
-            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 4;
-            int vt[3][6], vm[3][6], vb[3][6];
-            edge_row(simg, W, y > 0 ? y - 1 : 0, x0, vt);
-            edge_row(simg, W, y, x0, vm);
-            edge_row(simg, W, y + 1 < H ? y + 1 : H - 1, x0, vb);
-            unsigned cls4 = 0u;
-            short* mrow = mag + (y + 1) * MW + x0 + 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = q + 1;
-                int bn = -1, xs = 0, ys = 0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int dx = (vt[c][j + 1] + 2 * vm[c][j + 1] + vb[c][j + 1]) - (vt[c][j - 1] + 2 * vm[c][j - 1] + vb[c][j - 1]);
-                    const int dy = (vb[c][j - 1] + 2 * vb[c][j] + vb[c][j + 1]) - (vt[c][j - 1] + 2 * vt[c][j] + vt[c][j + 1]);
-                    const int nrm = abs(dx) + abs(dy);
-                    if (nrm > bn) { bn = nrm; xs = dx; ys = dy; }
+        for (int item = fresh(tid); item < (TRS_EDGE_ABLATE == 1 ? 0 : p.gpr * nchunk); item += kEdgeBlock) {
+            const int rc = item / p.gpr, cg = item - rc * p.gpr, x0 = cg * 4;
+            const int y0 = rc * rows_per, y1 = min(H, y0 + rows_per);
+            if (y0 >= y1) continue;
+            float ra[3][6], rb[3][6], rc3[3][6];                              // three rows in rotating roles: no register copies between output rows
+            edge_row_f(simg, W, y0 > 0 ? y0 - 1 : 0, x0, ra);
+            edge_row_f(simg, W, y0, x0, rb);
+            for (int y = y0; y < y1; y += 3) {
+                edge_row_f(simg, W, y + 1 < H ? y + 1 : H - 1, x0, rc3);
+                edge_sobel_row(ra, rb, rc3, mag + (y + 1) * MP + x0 + 4, map + (size_t)y * W + x0);
+                if (y + 1 < y1) {
+                    edge_row_f(simg, W, y + 2 < H ? y + 2 : H - 1, x0, ra);
+                    edge_sobel_row(rb, rc3, ra, mag + (y + 2) * MP + x0 + 4, map + (size_t)(y + 1) * W + x0);
                 }
-                const int ax = abs(xs), ay = abs(ys) << 15, tg22x = ax * 13573;
-                int cls;
-                if (ay < tg22x) cls = 0;
-                else if (ay > tg22x + (ax << 16)) cls = 1;
-                else cls = ((xs ^ ys) < 0) ? 3 : 2;
-                mrow[q] = (short)bn;
-                cls4 |= (unsigned)cls << (8 * q);
+                if (y + 2 < y1) {
+                    edge_row_f(simg, W, y + 3 < H ? y + 3 : H - 1, x0, rb);
+                    edge_sobel_row(rc3, ra, rb, mag + (y + 3) * MP + x0 + 4, map + (size_t)(y + 2) * W + x0);
+                }
             }
-            *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = cls4;
         }
         __syncthreads();
+        EDGE_STAMP(4);
         // ---- non-maximum suppression + double threshold: map <- 0 = weak / 1 = no / 2 = edge ----
-        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
-            const int y = g / p.gpr, x0 = (g - y * p.gpr) * 4;
-            int m3[3][6];                                                    // magnitudes of rows y - 1 .. y + 1, columns x0 - 1 .. x0 + 4 (zero border)
+        // Branch-free, two pixels per instruction (hipcc turned the per-pixel choice of neighbours into divergent branches with LDS reads
+        // inside them: 133 instructions per pixel).  A comparison a < b of two magnitudes (0 .. 2040) is the sign bit of the 16-bit
+        // difference a - b; the magnitudes arrive packed two per dword, so v_pk_sub_i16 compares a PAIR of pixels with their
+        // neighbours, the four direction classes' tests are combined on those sign bits (bits 15 and 31; the others carry garbage
+        // and are masked at the end) and the pixel's own class picks one with two bit-field selects.
+        {
+            typedef short s2v __attribute__((ext_vector_type(2)));
+            auto sub2 = [](unsigned a, unsigned b) -> unsigned { return __builtin_bit_cast(unsigned, (s2v)(__builtin_bit_cast(s2v, a) - __builtin_bit_cast(s2v, b))); };
+            auto bsel = [](unsigned mask, unsigned a, unsigned b) -> unsigned { return (mask & a) | (~mask & b); };   // v_bfi_b32
+            const int lo_c = min(max(p.edge_low, -1), 32767), hi_c = min(max(p.edge_high, -1), 32767);   // magnitudes are <= 2040: any larger threshold behaves like 32767
+            const unsigned low2 = (unsigned)(lo_c & 0xFFFF) * 0x10001u, high2 = (unsigned)(hi_c & 0xFFFF) * 0x10001u;
+            // (row, column group) of this thread's groups without a division per group: g advances by 1024 = dy rows + dc column groups
+            const int dy = kEdgeBlock / p.gpr, dc = kEdgeBlock - dy * p.gpr;
+            int g = fresh(tid), y = g / p.gpr, cg = g - y * p.gpr;
+            for (; g < p.gpe; g += kEdgeBlock, y += dy, cg += dc) {
+                if (cg >= p.gpr) { cg -= p.gpr; ++y; }
+                const int x0 = cg * 4;
+                unsigned ctr[3][2], lft[3][2], rgt[3][2];                    // per row: the pair itself, its left and its right neighbours
 #pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                const unsigned* mr = reinterpret_cast<const unsigned*>(mag + (y + rr) * MW + x0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const unsigned w = mr[k]; m3[rr][2 * k] = (int)(w & 0xFFFFu); m3[rr][2 * k + 1] = (int)(w >> 16); }
-            }
-            const unsigned cls4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
-            unsigned out4 = 0u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = q + 1, m = m3[1][j], cls = (int)((cls4 >> (8 * q)) & 255u);
-                bool ismax = false;
-                if (m > p.edge_low) {
-                    if (cls == 0) ismax = m > m3[1][j - 1] && m >= m3[1][j + 1];
-                    else if (cls == 1) ismax = m > m3[0][j] && m >= m3[2][j];
-                    else if (cls == 2) ismax = m > m3[0][j - 1] && m > m3[2][j + 1];
-                    else ismax = m > m3[0][j + 1] && m > m3[2][j - 1];
+                for (int rr = 0; rr < 3; ++rr) {
+                    const short* mr = mag + (y + rr) * MP + x0;              // shorts x0 .. x0 + 9 hold columns x0 - 4 .. x0 + 5
+                    const uint2 a = *reinterpret_cast<const uint2*>(mr), b = *reinterpret_cast<const uint2*>(mr + 4);
+                    const unsigned c = *reinterpret_cast<const unsigned*>(mr + 8);
+                    ctr[rr][0] = b.x; ctr[rr][1] = b.y;                       // columns (x0, x0 + 1), (x0 + 2, x0 + 3)
+                    lft[rr][0] = __builtin_amdgcn_alignbit(b.x, a.y, 16);     // (x0 - 1, x0)
+                    lft[rr][1] = __builtin_amdgcn_alignbit(b.y, b.x, 16);     // (x0 + 1, x0 + 2)
+                    rgt[rr][0] = lft[rr][1];
+                    rgt[rr][1] = __builtin_amdgcn_alignbit(c, b.y, 16);       // (x0 + 3, x0 + 4)
                 }
-                out4 |= (unsigned)(ismax ? (m > p.edge_high ? 2 : 0) : 1) << (8 * q);
+                const unsigned cls4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
+                unsigned out4 = 0u;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned M = ctr[1][pr];
+                    const unsigned t0 = sub2(lft[1][pr], M) & ~sub2(M, rgt[1][pr]);     // class 0: m > left  && m >= right
+                    const unsigned t1 = sub2(ctr[0][pr], M) & ~sub2(M, ctr[2][pr]);     // class 1: m > up    && m >= down
+                    const unsigned t2 = sub2(lft[0][pr], M) & sub2(rgt[2][pr], M);      // class 2: m > up-left  && m > down-right
+                    const unsigned t3 = sub2(rgt[0][pr], M) & sub2(lft[2][pr], M);      // class 3: m > up-right && m > down-left
+                    const unsigned c2 = (cls4 >> (16 * pr)) & 0xFFFFu;                  // the pair's classes: byte 0, byte 1
+                    const unsigned b0 = (c2 << 15) | (c2 << 23), b1 = (c2 << 14) | (c2 << 22);   // class bit 0 / bit 1 of the two pixels at bits 15 and 31
+                    const unsigned sel = bsel(b1, bsel(b0, t3, t2), bsel(b0, t1, t0));
+                    const unsigned ismax = TRS_EDGE_ABLATE == 6 ? 0u : (sel & sub2(low2, M));   // ... && m > low
+                    const unsigned strong = ismax & sub2(high2, M);                              // ... && m > high
+                    const unsigned h = ((~ismax >> 15) & 0x00010001u) | ((strong >> 14) & 0x00020002u);   // per half: 1 = no, 0 = weak, 2 = edge
+                    out4 |= ((h & 0xFFu) | ((h >> 8) & 0xFF00u)) << (16 * pr);
+                }
+                *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = out4;
             }
-            *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = out4;
         }
         __syncthreads();
+        EDGE_STAMP(5);
         // ---- hysteresis: weak pixels 8-connected to an edge become edges.  A thread owns a contiguous run of pixels and walks it
         // forwards, then backwards: a chain along a row closes in one sweep instead of one pixel per sweep (the closure does not
         // depend on the order: only weak -> edge transitions); sweeps repeat until a block-wide OR reports no change ----
         {
-            const int strip = 4 * ((p.gpe + kEdgeBlock - 1) / kEdgeBlock), s0 = tid * strip, s1 = min(npx, s0 + strip);
+            const int strip = 4 * ((p.gpe + kEdgeBlock - 1) / kEdgeBlock), s0 = fresh(tid) * strip, s1 = min(npx, s0 + strip);
             auto visit = [&](int px) -> int {
                 const int y = px / W, x = px - y * W;
                 bool hit = false;
@@ -743,7 +891,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                 if (hit) map[px] = 2;
                 return hit ? 1 : 0;
             };
-            for (int iter = 0; iter < npx; ++iter) {
+            for (int iter = 0; iter < (TRS_EDGE_ABLATE == 3 ? 0 : npx); ++iter) {
                 int changed = 0;
                 for (int q = s0; q < s1; q += 4) {
                     if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
@@ -756,18 +904,23 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                 if (!__syncthreads_or(changed)) break;
             }
         }
+        EDGE_STAMP(6);
         // ---- colour masks on the trimmed frame, merge, edge layer last (img_preprocessing.py:43-53) ----
-        for (int g = tid; g < p.gpe; g += kEdgeBlock) {
-            unsigned ob[12];
+        // (the switch p.color is tested once per group, not per pixel: four independent chains of dependent table lookups then
+        // interleave instead of running one after the other)
+        for (int g = fresh(tid); g < (TRS_EDGE_ABLATE == 4 ? 0 : p.gpe); g += kEdgeBlock) {
             const unsigned* sw = reinterpret_cast<const unsigned*>(simg + (size_t)g * 12);
             const unsigned w3[3] = {sw[0], sw[1], sw[2]};
             const unsigned e4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
+            auto byte_of = [&](int bi) -> unsigned { return (w3[bi >> 2] >> (8 * (bi & 3))) & 255u; };
+            unsigned ob[12];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                auto byte_of = [&](int bi) -> int { return (int)((w3[bi >> 2] >> (8 * (bi & 3))) & 255u); };
-                const int r = byte_of(3 * q), gg = byte_of(3 * q + 1), b = byte_of(3 * q + 2);
-                int o0 = r, o1 = gg, o2 = b;
-                if (p.color) {
+            for (int k = 0; k < 12; ++k) ob[k] = byte_of(k);
+            if (p.color) {
+                unsigned inr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = (int)ob[3 * q], gg = (int)ob[3 * q + 1], b = (int)ob[3 * q + 2];
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
                     const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
                     const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
@@ -775,24 +928,34 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                     h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
-                    for (int f = 0; f < p.n_filters; ++f) {
-                        const int lh = p.lo[f] & 255, ls = (p.lo[f] >> 8) & 255, lv = (p.lo[f] >> 16) & 255;
-                        const int uh = p.hi[f] & 255, us = (p.hi[f] >> 8) & 255, uv = (p.hi[f] >> 16) & 255;
-                        const int mk = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
-                        const int dc = p.dst_ch[f];
-                        o0 = dc == 0 ? mk : o0; o1 = dc == 1 ? mk : o1; o2 = dc == 2 ? mk : o2;
-                    }
+                    inr[q] = s_rng[hh] & s_rng[256 + ss] & s_rng[512 + v];
                 }
-                const int ev = ((e4 >> (8 * q)) & 255u) == 2u ? 255 : 0;
-                o0 = p.edge_ch == 0 ? ev : o0; o1 = p.edge_ch == 1 ? ev : o1; o2 = p.edge_ch == 2 ? ev : o2;
-                ob[3 * q] = (unsigned)o0; ob[3 * q + 1] = (unsigned)o1; ob[3 * q + 2] = (unsigned)o2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (fsel0 >= 0) ob[3 * q] = (inr[q] >> fsel0) & 1u ? 255u : 0u;
+                    if (fsel1 >= 0) ob[3 * q + 1] = (inr[q] >> fsel1) & 1u ? 255u : 0u;
+                    if (fsel2 >= 0) ob[3 * q + 2] = (inr[q] >> fsel2) & 1u ? 255u : 0u;
+                }
+            }
+            if (p.edge_ch >= 0 && p.edge_ch <= 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned ev = ((e4 >> (8 * q)) & 255u) == 2u ? 255u : 0u;
+                    ob[3 * q] = p.edge_ch == 0 ? ev : ob[3 * q]; ob[3 * q + 1] = p.edge_ch == 1 ? ev : ob[3 * q + 1]; ob[3 * q + 2] = p.edge_ch == 2 ? ev : ob[3 * q + 2];
+                }
             }
             const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
                              ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
         __syncthreads();   // LDS is reused by the next frame of this workgroup
+        EDGE_STAMP(7);
     }
+#ifdef TRS_EDGE_STAMPS
+    if (blockIdx.x == 7 && tid == 0)
+        printf("edge phases [clocks, workgroup 7, all its frames]: sums %llu | delta+table %llu | trim %llu | sobel %llu | nms %llu | hysteresis %llu | output %llu\n",
+               ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
 }
 
 // float32(img) / 255 (keras_pilot.py:49-50): 4 bytes in, one 16-B store out per lane
@@ -1746,9 +1909,9 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
         p.edge_high = std::max(c->edge_threshold_a, c->edge_threshold_b);
         const size_t npx = (size_t)e->H * e->W;
         p.off_mag = (int)align_up(npx * 3, 16);
-        p.off_map = p.off_mag + (int)align_up((size_t)(e->H + 2) * (e->W + 2) * 2, 16);
-        const size_t work = (size_t)p.off_map + align_up(npx, 16);
-        const int tables = 512 * 4 + 3 * (kEdgeBlock / 64) * 4 + 16;
+        p.off_map = p.off_mag + (int)align_up((size_t)(e->H + 2) * (e->W + 8) * 2, 16);   // rows of W + 8 int16: a 4-pixel group's values are 8-byte aligned
+        const size_t work = (size_t)p.off_map + align_up(npx, 16) + 16;
+        const int tables = kEdgeTables;
         const int grid = std::min(n_images, e->cu_count);
         if (work + tables <= 160 * 1024) {                                    // whole frame in LDS
             p.off_tab = (int)work;
