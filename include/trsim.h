@@ -350,7 +350,7 @@ int trs_pilot_set_tuning(trs_env* env, const trs_pilot_tuning* t_or_null);
 /* Load the weights of Keras_2D_CNN.get_model(input_shape=(img_h,img_w,3), num_outputs=2) (components/keras_train.py:127-174,
  * selected for cnn_2d_speed_control at :393-395): 11 layers, in order conv1..conv7, dense1, dense2, dense3, output_layer;
  * h_arrays[2*i] = kernel in Keras layout ([KH][KW][CIN][COUT] / [IN][OUT], float32), h_arrays[2*i+1] = bias.  Replaces
- * load_model(model_path) (components/keras_pilot.py:26); weights are rounded to bfloat16 for the MFMA convolutions. */
+ * load_model(model_path) (components/keras_pilot.py:26); weights are rounded to binary16 (fp16) for the MFMA convolutions (bfloat16 until round 2: the same MFMA rate, 3 fewer mantissa bits). */
 int trs_pilot_load(trs_env* env, const float* const* h_arrays, int n_arrays);
 /* n_arrays selects the architecture (kernel, bias per layer, Keras layouts; BY LAYER NAME, in this order — the order of
  * model.get_weights() of a functional model with several inputs depends on Keras's layer sorting, so bind by name):
@@ -358,7 +358,7 @@ int trs_pilot_load(trs_env* env, const float* const* h_arrays, int n_arrays);
  *   28  ... as above (dense1 has 16 more input rows), feature1, feature2, feature3     cnn_2d_speed_as_feature
  *   42  conv1..conv7, dense1 (+64 rows), dense2, dense3, output_speed, feature1..3, current_spd_1..3,
  *       dense4 (+128 rows), dense5, dense6, out_steering                              cnn_2d_full_house
- * The rows of dense1 / dense4 over the flattened conv7 output run on the matrix cores (bf16 weights); the small branches and
+ * The rows of dense1 / dense4 over the flattened conv7 output run on the matrix cores (fp16 weights); the small branches and
  * everything behind them are fp32. */
 
 /* model(img_arr) of KerasPilot.step (keras_pilot.py:49-55,81): uint8 frames -> raw outputs float[n_images][2]

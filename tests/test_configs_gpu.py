@@ -73,10 +73,10 @@ def test_configs4_closed_loop_240x320_depth_pilot_in_the_loop(make_env):
 
 def test_configs4_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
     """configs[4]'s closed loop against a loop that shares NO code with the product: the env half is the
-    CPU oracle, the pilot half is PyTorch — the fp32 "mirror" of tests/test_pilot.py (fp32 arithmetic on bf16-rounded weights
+    CPU oracle, the pilot half is PyTorch — the fp32 "mirror" of tests/test_pilot.py (fp32 arithmetic on fp16-rounded weights
     and activations, i.e. the product's stated arithmetic, any summation order) — and KerasPilot's post-processing is the
     reference's scalar Python (keras_pilot.py:78-95).  6 ticks, 240x320 RGB + depth.
-    Tolerances: the two pilots differ by fp32 summation order in front of bf16 roundings: raw outputs within 2e-2 (stated bound
+    Tolerances: the two pilots differ by fp32 summation order in front of fp16 roundings: raw outputs within 2e-2 (stated bound
     of tests/test_pilot.py is 5e-2 against PURE fp32; the mirror is closer), controls within 3e-2; six ticks of 0.05 s at
     <= 3 units/s turn that into <= 5e-3 in pose and 2e-2 in speed; the tracker index may differ where a car sits on the
     boundary between two track points (at most one env), and frames are compared through the pose (<= 2 % of the pixels)."""

@@ -295,7 +295,7 @@ class HipKerasPilot(Component):
     """``KerasPilot`` for ``ModelType.CNN_2D_SPD_CTL`` and ``ModelType.CNN_2D`` (reference ``components/keras_pilot.py:17-153``;
     both run the same network, ``keras_train.py:386-395``): same ports, same
     ``spd_ctl_*`` / ``smooth_steering_*`` config keys, same rule "``(0.0, 0.0, 0.0)`` without a frame or outside the two AI
-    modes".  The network (``Keras_2D_CNN.get_model``, ``keras_train.py:127-174``) runs on the GPU in bf16 MFMA
+    modes".  The network (``Keras_2D_CNN.get_model``, ``keras_train.py:127-174``) runs on the GPU in fp16 MFMA
     convolutions (``trs_pilot_forward_host``); the post-processing (cap, x20, ``calcThrottle`` / ``calcBreak``, smooth
     steering; ``:78-95``) is the reference's scalar arithmetic on the host.
 

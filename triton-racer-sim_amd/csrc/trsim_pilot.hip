@@ -7,19 +7,21 @@
 //
 // Convolutions are implicit GEMMs on the matrix cores, one kernel for every layer:
 //   C[pixel][cout] = sum_k A[pixel][k] * B[k][cout],  k = (kh, kw, cin) cut into granules of 8 input channels
-//   v_mfma_f32_32x32x16_bf16: a wave owns 32 output pixels x all (padded) output channels; per 16-deep k-step the
+//   v_mfma_f32_32x32x16_f16: a wave owns 32 output pixels x all (padded) output channels; per 16-deep k-step the
 //   lane (row r = lane & 31, half h = lane >> 5) needs A[r][8h .. 8h+7] = ONE granule = one 16-byte load straight
-//   from the NHWC bf16 activation in global memory (no im2col buffer, no LDS for A); B granules [g][cout][8] are
+//   from the NHWC fp16 activation in global memory (no im2col buffer, no LDS for A); B granules [g][cout][8] are
 //   staged per workgroup in LDS in exactly the fragment order, so a B fragment is one ds_read_b128.
 //   conv1 reads the uint8 frame directly: a k-step is one kernel row = 15 contiguous bytes (5 px x RGB) + 1 pad,
-//   fetched with 3 aligned dwords + v_alignbyte, converted exactly to bf16; the 1/255 of the pilot's normalisation
-//   (components/keras_pilot.py:49-50) is folded into conv1's weights.
+//   fetched with 3 aligned dwords + v_alignbyte, converted exactly to binary16; the 1/255 of the pilot's normalisation
+//   (components/keras_pilot.py:49-50) is folded into conv1's weights as 256/255, with 2^-8 in its epilogue (kConv1Scale).
 //   dense1 (4608 -> 100) is the same kernel as a 1x1 convolution over "pixels" = frames.
 // The fp32 tail (dense2, dense3, output) and KerasPilot's post-processing (keras_pilot.py:78-95; calcThrottle /
 // calcBreak of utils/mapping.py:23-35) run in one small kernel that writes the env's next controls.
 //
-// Numerics: bf16 operands, fp32 accumulate, activations stored as bf16 — checked against a PyTorch fp32 reference
-// with the same bf16-rounded weights (tests/test_pilot.py, tolerance stated there).  Bound: MFMA.
+// Numerics: binary16 (fp16) operands, fp32 accumulate, activations stored as binary16 (saturating at 65504) — checked against a
+// PyTorch fp32 reference with the same fp16-rounded weights (tests/test_pilot.py, tolerance stated there).  Until round 2 the
+// 16-bit format was bfloat16: the same MFMA rate, but 8 significant bits instead of 11 — measured max |output - fp32| 5.0e-4 against
+// 4.4e-5 (profiles/r03_pilot_precision.txt); the reference's arithmetic is fp32 (keras_pilot.py:49-55).  Bound: MFMA.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,7 +41,8 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;   // 8 binary16 values: one MFMA operand fragment per lane (round 3: binary16 instead of bfloat16 —
+                                                              // the same MFMA rate, 3 more mantissa bits: max |output - fp32| 5e-4 -> 4e-5, profiles/r03_pilot_precision.txt)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
@@ -53,11 +56,11 @@ constexpr int kConvPrefetch = 4;           // trips (pairs of k-steps) of pixel 
 constexpr int kLdsWeightBytes = 32 * 1024;   // per weight stage; 32 KB measured best of 8/16/32/64 (more workgroups per CU hide the A-load latency)
 
 struct ConvParams {
-    const void* in;            // bf16 NHWC [N][IH][IW][CIN]   (conv1: uint8 [N][IH][IW][3])
-    const u4v* w;              // [G_pad][COUT_PAD] granules of 8 bf16
+    const void* in;            // fp16 NHWC [N][IH][IW][CIN]   (conv1: uint8 [N][IH][IW][3])
+    const u4v* w;              // [G_pad][COUT_PAD] granules of 8 fp16
     const float* bias;         // [COUT_PAD]
     const int* goff;           // [G_pad] byte offset of granule g relative to the output pixel's input base
-    void* out;                 // bf16 NHWC [N][OH][OW][COUT]  or float when out_f32
+    void* out;                 // fp16 NHWC [N][OH][OW][COUT]  or float when out_f32
     int in_bytes;              // size of `in` (buffer-load bounds)
     int N, IH, IW, CIN, OH, OW, COUT, COUT_PAD, S;
     int G, G_pad, M;           // granules (even-padded), GEMM rows = N*OH*OW
@@ -66,38 +69,46 @@ struct ConvParams {
     int ksplit;                // > 1: blockIdx.y owns a slice of the granules and writes its partial sums to slab blockIdx.y of `out` (fp32 [ksplit][M][COUT], no ReLU)
     int nt_out;                // non-temporal activation stores (outputs far larger than L2; measured: conv1 86 -> 80 us, small layers lose)
     int KH, KW, run_pad, cg, span_nl;   // span kernel: kernel rows, granules per kernel row (padded), granules per pixel, load instructions per kernel row
+    float oscale;              // the sums are multiplied by this power of two inside the bias FMA: 2^-8 for conv1 (kConv1Scale), 1 elsewhere
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
 
-__device__ __forceinline__ unsigned short f2bf(float f)
-{   // round to nearest even (inputs are finite)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned short f2h(float f)
+{   // round to nearest even; beyond binary16's range: 65504 (the activations saturate, they never become infinite)
+    const _Float16 h = (_Float16)__builtin_fminf(__builtin_fmaxf(f, -65504.0f), 65504.0f);
+    return __builtin_bit_cast(unsigned short, h);
 }
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
-{   // round to nearest even, two values per dword: v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned pack_h16x2(float lo, float hi)
+{   // round to nearest even, two values per dword: v_cvt_pk_f16_f32 on gfx950 (beyond 65504: +-infinity; the ReLU form below saturates)
     const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2));
 }
 
+// two uint8 values (already binary32, 0..255: exact in binary16 under any rounding) as a binary16 pair: v_cvt_pkrtz_f16_f32
+__device__ __forceinline__ unsigned u8pair_h16(float f0, float f1) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(f0, f1)); }
+
+constexpr float kConv1Scale = 1.0f / 256.0f;   // conv1's weights carry 256 / 255 (the pilot's / 255 of keras_pilot.py:49-50 x 2^8, so that small weights stay normal
+                                               // binary16 numbers); its epilogues multiply the sum by 2^-8 inside the bias FMA: exact, no extra instruction
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-// ReLU on two packed bf16: a bf16's sign bit is the int16's, so max(., 0) as int16 zeroes the negatives (and -0).  One v_pk_max_i16
+// ReLU on two packed binary16: the sign bit is the int16's, so max(., 0) as int16 zeroes the negatives (and -0).  One v_pk_max_i16
 // for two values instead of a v_max_f32 each in front of the conversion; round-to-nearest keeps the sign, so the bits are the same.
+// Non-negative binary16 values order like their int16 patterns, so min(., 0x7BFF) turns an overflowed +infinity (0x7C00) into 65504:
+// activations saturate instead of poisoning the next layer (one more v_pk_min_i16 per pair).
 // (The epilogues are vector-ALU work between short MFMA runs: conv1's tile of 5 MFMAs carried ~65 VALU instructions.)
-__device__ __forceinline__ unsigned relu_bf16x2(unsigned packed)
+__device__ __forceinline__ unsigned relu_h16x2(unsigned packed)
 {
-    const s16x2 v = __builtin_bit_cast(s16x2, packed), z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, z));
+    const s16x2 v = __builtin_bit_cast(s16x2, packed), z = {0, 0}, top = {0x7BFF, 0x7BFF};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(v, z), top));
 }
 __device__ __forceinline__ uint2 relu_pack4(float v0, float v1, float v2, float v3)
 {
-    return make_uint2(relu_bf16x2(pack_bf16x2(v0, v1)), relu_bf16x2(pack_bf16x2(v2, v3)));
+    return make_uint2(relu_h16x2(pack_h16x2(v0, v1)), relu_h16x2(pack_h16x2(v2, v3)));
 }
 
 template <int NB, bool U8IN>
@@ -126,17 +137,17 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
     f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const float b = blockIdx.y == 0 ? p.bias[nb * 32 + r] : 0.0f;      // C/D layout: column = lane & 31 in every register
+        const float b = blockIdx.y == 0 ? p.bias[nb * 32 + r] * (1.0f / p.oscale) : 0.0f;      // C/D layout: column = lane & 31 in every register (oscale is a power of two: exact)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = b;
     }
     __syncthreads();                                                        // lgoff visible
     if (gs >= ge) return;                                                   // empty K slice (uniform per workgroup)
 
-    auto load_a = [&](int g) -> bf16x8 {
+    auto load_a = [&](int g) -> h16x8 {
         if constexpr (U8IN) {
-            // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, byte-align, exact u8 -> bf16
-            // (0..255 is exact in bf16, so the upper half of the float IS the bf16)
+            // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, byte-align, exact u8 -> fp16
+            // (0..255 is exact in binary16)
             const int addr = pixbase + lgoff[g];
             const int al = addr & ~3;
             const unsigned sh = (unsigned)addr & 3u;
@@ -147,13 +158,13 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
             const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
             auto pair = [](unsigned w, int j) -> unsigned {
                 const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // (f0 >> 16) | (f1 & 0xffff0000)
+                return u8pair_h16(f0, f1);
             };
             const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-            return __builtin_bit_cast(bf16x8, packed);
+            return __builtin_bit_cast(h16x8, packed);
         } else {
             const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
-            return __builtin_bit_cast(bf16x8, raw);
+            return __builtin_bit_cast(h16x8, raw);
         }
     };
 
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
     // index.  Every group of kPf trips but the last reloads UNCONDITIONALLY (clamped granule index): a load inside a
     // branch makes hipcc drain the whole queue (vmcnt(0)) at the loop head; the last group has no loads and may be ragged.
     constexpr int kPf = kConvPrefetch;
-    bf16x8 ring[2 * kPf];
+    h16x8 ring[2 * kPf];
 #pragma unroll
     for (int t = 0; t < kPf; ++t) {
         if (gs + 4 * t < ge) { ring[2 * t] = load_a(gs + 4 * t + h); ring[2 * t + 1] = load_a(gs + 4 * t + 2 + h); }
@@ -171,13 +182,13 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
     auto trip_mfma = [&](int gt, int t) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + h) * p.COUT_PAD + nb * 32 + r]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[2 * t], w, acc[nb], 0, 0, 0);
+            const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + h) * p.COUT_PAD + nb * 32 + r]);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * t], w, acc[nb], 0, 0, 0);
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + 2 + h) * p.COUT_PAD + nb * 32 + r]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[2 * t + 1], w, acc[nb], 0, 0, 0);
+            const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + 2 + h) * p.COUT_PAD + nb * 32 + r]);
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * t + 1], w, acc[nb], 0, 0, 0);
         }
     };
     for (int c0 = gs; c0 < ge; c0 += p.gchunk) {
@@ -212,14 +223,14 @@ __global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvPar
         for (int i = 0; i < 16; ++i) {
             const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (row >= p.M) continue;
-            float v = acc[nb][i];
+            float v = acc[nb][i] * p.oscale;
             if (p.ksplit > 1) {   // this K slice's partial sums go to its own slab; the consumer adds the slabs in slice order (deterministic, no atomics)
                 static_cast<float*>(p.out)[((size_t)blockIdx.y * p.M + row) * p.COUT + col] = v;
                 continue;
             }
             if (p.relu) v = v > 0.0f ? v : 0.0f;
             if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
-            else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2bf(v);
+            else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2h(v);
         }
     }
 }
@@ -238,7 +249,7 @@ __device__ __forceinline__ int window_base(const ConvParams& p, int n0, int rem0
     return ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
 }
 
-// Epilogue of a 32-pixel tile: bias + ReLU + bf16, transposed through the wave's 2 KB LDS stage so that the global stores
+// Epilogue of a 32-pixel tile: bias + ReLU + fp16, transposed through the wave's 2 KB LDS stage so that the global stores
 // are 16 bytes per lane and contiguous across lanes (the direct 8-byte stores of the C/D layout cost the addresser one
 // lookup per lane: 31 us of conv2's 131).  Stage layout: [pixel][16-B chunk ^ f(pixel)], f spreads the 16 lanes of a
 // ds_write_b64 / ds_read_b128 group over the bank row.  NB = 2 (128 B per pixel) goes in two passes of 16 pixels.
@@ -261,8 +272,9 @@ __device__ __forceinline__ void store_tile_at(u4v* stage, const f32x16 (&acc)[NB
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[nb * 8 + 2 * q + h];
-                    float v0 = acc[nb][4 * q] + b.x, v1 = acc[nb][4 * q + 1] + b.y, v2 = acc[nb][4 * q + 2] + b.z, v3 = acc[nb][4 * q + 3] + b.w;
-                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    const float os = p.oscale;
+                    float v0 = __builtin_fmaf(acc[nb][4 * q], os, b.x), v1 = __builtin_fmaf(acc[nb][4 * q + 1], os, b.y), v2 = __builtin_fmaf(acc[nb][4 * q + 2], os, b.z), v3 = __builtin_fmaf(acc[nb][4 * q + 3], os, b.w);
+                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
                 }
             }
         }
@@ -310,8 +322,9 @@ __device__ __forceinline__ void store_tile_rows(u4v* stage, const f32x16 (&acc)[
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 b = lbias[2 * q + h];
-            float v0 = acc[0][4 * q] + b.x, v1 = acc[0][4 * q + 1] + b.y, v2 = acc[0][4 * q + 2] + b.z, v3 = acc[0][4 * q + 3] + b.w;
-            st2[(r * CR + (q ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            const float os = p.oscale;
+            float v0 = __builtin_fmaf(acc[0][4 * q], os, b.x), v1 = __builtin_fmaf(acc[0][4 * q + 1], os, b.y), v2 = __builtin_fmaf(acc[0][4 * q + 2], os, b.z), v3 = __builtin_fmaf(acc[0][4 * q + 3], os, b.w);
+            st2[(r * CR + (q ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
         }
     }
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out), 0, p.M * p.COUT * 2, 0x00020000);
@@ -377,9 +390,8 @@ __global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
     };
     request(pixbase);
     while (true) {
-        // 8 of the 16 bytes of a kernel row at any byte alignment: byte-align, then exact u8 -> bf16 (0..255 is exact in
-        // bf16, so the upper half of the float IS the bf16)
-        bf16x8 x[kGr];
+        // 8 of the 16 bytes of a kernel row at any byte alignment: byte-align, then exact u8 -> binary16 (0..255 is exact)
+        h16x8 x[kGr];
 #pragma unroll
         for (int s = 0; s < kGr; ++s) {
             const unsigned sh = (unsigned)(pixbase + goffs[s]) & 3u;
@@ -387,10 +399,10 @@ __global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
             const unsigned hi = __builtin_amdgcn_alignbyte(raw[s][2], raw[s][1], sh);
             auto pair = [](unsigned w, int j) -> unsigned {
                 const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);   // (f0 >> 16) | (f1 & 0xffff0000)
+                return u8pair_h16(f0, f1);
             };
             const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-            x[s] = __builtin_bit_cast(bf16x8, packed);
+            x[s] = __builtin_bit_cast(h16x8, packed);
         }
         const int next = tile + stride;                                     // uniform
         const int nbase = base_of(min(next, ntiles - 1));
@@ -401,8 +413,8 @@ __global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
 #pragma unroll
         for (int s = 0; s < kGr; ++s) {
             if (2 * s < p.G_pad) {
-                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(2 * s + h) * NBW + r]);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x[s], acc[0], 0, 0, 0);
+                const h16x8 w = __builtin_bit_cast(h16x8, lw[(2 * s + h) * NBW + r]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x[s], acc[0], 0, 0, 0);
             }
         }
         store_tile<1>(stage, acc, lbias, p, tile, 0, lane);
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
     }
 }
 
-// conv2..conv7 (bf16 input): resident weights + QUAD-COALESCED pixel loads.  Counters showed the per-lane 16-byte loads of
+// conv2..conv7 (fp16 input): resident weights + QUAD-COALESCED pixel loads.  Counters showed the per-lane 16-byte loads of
 // the kernel above cost the texture addresser one tag lookup per lane (56-88 per instruction: every lane another line) and
 // bound every layer.  Here the four lanes of a quad fetch the four consecutive granules (64 contiguous bytes) of ONE pixel,
 // so an instruction is 16 pixels x 64 B; the fragments reach the MFMA layout through a 2 KB wave-private LDS stage:
@@ -484,30 +496,30 @@ __global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
             for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
         auto trip_mfma = [&](int gt, int t) {
 #if TRS_CONV_ABLATE == 2
-            const bf16x8 x0 = __builtin_bit_cast(bf16x8, ring[2 * t]);
-            const bf16x8 x1 = __builtin_bit_cast(bf16x8, ring[2 * t + 1]);
+            const h16x8 x0 = __builtin_bit_cast(h16x8, ring[2 * t]);
+            const h16x8 x1 = __builtin_bit_cast(h16x8, ring[2 * t + 1]);
 #else
             stage[lane] = ring[2 * t];                                      // transpose through the wave's LDS stage (in-order per wave)
             stage[64 + lane] = ring[2 * t + 1];
-            const bf16x8 x0 = __builtin_bit_cast(bf16x8, stage[rd0]);
-            const bf16x8 x1 = __builtin_bit_cast(bf16x8, stage[rd1]);
+            const h16x8 x0 = __builtin_bit_cast(h16x8, stage[rd0]);
+            const h16x8 x1 = __builtin_bit_cast(h16x8, stage[rd1]);
 #endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + h) * NBW + nb * 32 + r]);
+                const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + h) * NBW + nb * 32 + r]);
 #if TRS_CONV_ABLATE == 3
                 acc[nb][0] += (float)w[0] * (float)x0[0];
 #else
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x0, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x0, acc[nb], 0, 0, 0);
 #endif
             }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gt + 2 + h) * NBW + nb * 32 + r]);
+                const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + 2 + h) * NBW + nb * 32 + r]);
 #if TRS_CONV_ABLATE == 3
                 acc[nb][1] += (float)w[0] * (float)x1[0];
 #else
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x1, acc[nb], 0, 0, 0);
 #endif
             }
         };
@@ -550,12 +562,12 @@ __global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
 //             L2 (A operand, 512 contiguous bytes per half wave, prefetched kFrameRing k-steps ahead in registers), NT x NB MFMAs.
 //             Each pixel fragment feeds NB MFMAs and each weight fragment NT: LDS and L2 each supply half of what one-to-one
 //             feeding would need (LDS 128 B/clk and L2 64 B/clk per CU are what bound a 32x32x16 MFMA stream otherwise)
-//   epilogue  bias + ReLU + bf16, 8-byte stores (these activations are small: 9-19 KB per frame)
+//   epilogue  bias + ReLU + fp16, 8-byte stores (these activations are small: 9-19 KB per frame)
 struct FrameConvParams {
-    const u4v* in;             // bf16 NHWC [N][IH][IW][CIN] as 16-B granules
+    const u4v* in;             // fp16 NHWC [N][IH][IW][CIN] as 16-B granules
     const u4v* w;              // [KH*KW*cg][COUT_PAD] granules (kernel-row major, then tap, then channel granule)
     const float* bias;
-    unsigned short* out;       // bf16 NHWC [N][OH][OW][COUT]
+    unsigned short* out;       // fp16 NHWC [N][OH][OW][COUT]
     int N, IH, IW, OH, OW, COUT, COUT_PAD, KH, KW;
     int F, cg, cgs;            // units (frames, or row bands of frames) per workgroup; granules per pixel (8 / 16) and log2 of it
     int bands, ohb, ihb;       // a frame whose activation does not fit LDS is cut into `bands` bands of ohb output rows = ohb + KH - 1 input rows
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * p.COUT_PAD + nb * 32];
         const u4v* wnext = wl + (size_t)(2 * R + h) * p.COUT_PAD;
-        [[maybe_unused]] bf16x8 xkeep[NT];
+        [[maybe_unused]] h16x8 xkeep[NT];
         f32x16 acc[NT][NB];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -641,32 +653,32 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
         // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
         // that keeps "MFMAs of k, then the refill of k's ring slot" in place would otherwise also pin each k-step's LDS reads
         // right in front of its own MFMAs: one LDS latency per 4 MFMAs).
-        auto pixels = [&](int k, bf16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
+        auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
             const int tap = k / HALF, g = 2 * (k % HALF) + h;
             const int tap_off = (tap / 3) * p.IW + tap % 3;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pix = lbase[nt] + tap_off;
 #if TRS_FRAME_ABLATE == 2
-                if (k == 0) xkeep[nt] = __builtin_bit_cast(bf16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
+                if (k == 0) xkeep[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
                 x[nt] = xkeep[nt];
 #else
-                x[nt] = __builtin_bit_cast(bf16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
+                x[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
 #endif
             }
         };
-        bf16x8 xa[NT], xb[NT];
+        h16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
         for (int k = 0; k < ksteps; ++k) {
             const int d = k % R;
-            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
-            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
             if (k + 1 < ksteps) pixels(k + 1, xn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
             if (k + R < ksteps && TRS_FRAME_ABLATE != 1) {                  // (compile-time) refill the slot with the k-step R ahead:
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];   // a running pointer — one live address, not one per k-step
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
                 for (int q = 0; q < 4; ++q) {
                     const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
-                    w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
                 }
                 const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores
                 const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
@@ -723,7 +735,7 @@ struct ChainLayer {
     int nt;                                // 32-pixel tiles per wave item: 2 or 3, whichever leaves the busiest SIMD fewer MFMAs (3 also streams 1/3 less weights)
 };
 struct ChainParams {
-    const u4v* in;             // the first layer's input activation, bf16 NHWC
+    const u4v* in;             // the first layer's input activation, fp16 NHWC
     unsigned short* out;       // the last layer's output activation
     int N, F, nl, split_first; // frames, frames per workgroup, layers (3 = conv5..7, 4 = conv4..7), first layer in two passes of F / 2 frames
     int offA, offB, off_bias;  // LDS byte offsets
@@ -768,28 +780,28 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
-        auto pixels = [&](int k, bf16x8 (&x)[NT]) {
+        auto pixels = [&](int k, h16x8 (&x)[NT]) {
             const int tap = k / HALF, g = 2 * (k % HALF) + h;
             const int tap_off = (tap / 3) * L.IW + tap % 3;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pix = lbase[nt] + tap_off;
 #if TRS_CHAIN_ABLATE == 2
-                if (k == 0) xkeep[nt] = __builtin_bit_cast(bf16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+                if (k == 0) xkeep[nt] = __builtin_bit_cast(h16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
                 x[nt] = xkeep[nt];
 #else
-                x[nt] = __builtin_bit_cast(bf16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+                x[nt] = __builtin_bit_cast(h16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
 #endif
             }
         };
-        [[maybe_unused]] bf16x8 xkeep[NT];
-        bf16x8 xa[NT], xb[NT];
+        [[maybe_unused]] h16x8 xkeep[NT];
+        h16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
         for (int k = 0; k < ksteps; ++k) {
             const int d = k % R;
-            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
-            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
             if (k + 1 < ksteps) pixels(k + 1, xn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -798,7 +810,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #if TRS_CHAIN_ABLATE == 3
                     asm volatile("" :: "v"(ring[d][nb]), "v"(xc[nt]));
 #else
-                    acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+                    acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
 #endif
                 }
             if (k + R < ksteps && TRS_CHAIN_ABLATE != 1) {
@@ -913,10 +925,10 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
 // output pixels are consecutive 64-byte slots for every tap; granule g of slot s sits at g ^ ((s >> 2) & 3) — 16 consecutive
 // slots of one logical granule cover all 64 banks.
 struct Frame5Params {
-    const u4v* in;             // bf16 NHWC [N][IH][IW][32]
+    const u4v* in;             // fp16 NHWC [N][IH][IW][32]
     const u4v* w;              // [KH*KW*4][64] granules: row (kh, kw, c8), 2 k + h = granule of k-step k, half h
     const float* bias;
-    unsigned short* out;       // bf16 NHWC [N][OH][OW][64]
+    unsigned short* out;       // fp16 NHWC [N][OH][OW][64]
     int N, IH, IW, OH, OW, F, ev, COUT;   // ev = even columns per row = (IW + 1) / 2
     int bands, ohb, ihb;                  // a frame that does not fit LDS is cut into `bands` bands of ohb output rows = ihb = 2 ohb + 3 input rows (bands == 1: ohb = OH, ihb = IH)
 };
@@ -982,28 +994,28 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
-        auto pixels = [&](int k, bf16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
+        auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
             const int tap = k / 2, g = 2 * (k % 2) + h;
             const int kh = tap / KW, kw = tap % KW;
             const int tap_off = kh * p.IW + ((kw & 1) ? p.ev : 0) + (kw >> 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pix = lbase[nt] + tap_off;
-                x[nt] = __builtin_bit_cast(bf16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
+                x[nt] = __builtin_bit_cast(h16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
             }
         };
-        bf16x8 xa[NT], xb[NT];
+        h16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
         for (int k = 0; k < ksteps; ++k) {
             const int d = k % R;
-            bf16x8 (&xc)[NT] = (k & 1) ? xb : xa;
-            bf16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+            h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+            h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
             if (k + 1 < ksteps) pixels(k + 1, xn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
             if (k + R < ksteps) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
@@ -1128,11 +1140,11 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
             else { setup(min(next, ntiles - 1), roff_next); request(0); }   // ... or the next tile's first row (the last tile re-requests itself)
             const int gbase = kh * p.run_pad;
             for (int t = 0; t < p.run_pad; t += 2) {                        // (fetching step t + 1's fragments by hand before step t's MFMAs measured 5-10 % slower)
-                const bf16x8 x = __builtin_bit_cast(bf16x8, stage[swz(roff_cur + t)]);
+                const h16x8 x = __builtin_bit_cast(h16x8, stage[swz(roff_cur + t)]);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const bf16x8 w = __builtin_bit_cast(bf16x8, lw[(gbase + t + h) * NBW + nb * 32 + r]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc[nb], 0, 0, 0);
+                    const h16x8 w = __builtin_bit_cast(h16x8, lw[(gbase + t + h) * NBW + nb * 32 + r]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc[nb], 0, 0, 0);
                 }
             }
         }
@@ -1144,7 +1156,7 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
 
 // conv1 -> conv2 fused: conv1's activation (217 KB per 120x160 frame, the largest tensor of the network: 222 MB per 1024
 // frames, written once and read once) never leaves the CU.  A workgroup takes a band of R2 conv2 output rows of one
-// frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + bf16 rounding as the unfused
+// frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + fp16 rounding as the unfused
 // layer, so conv2's result is bit-identical), and runs conv2 on that tile with its fragments read by ds_read_b128.
 // Neighbouring bands recompute 3 conv1 rows each ((2 R2 + 3) / (2 R2) of the conv1 work).
 // Measured and dropped (1024 frames of 120x160; this form: 128-131 us):
@@ -1164,7 +1176,7 @@ struct Fuse12Params {
     int N, IH, IW, OH1, OW1, OH2, OW2, R2, bands;
     int off_w2, off_b, off_goff, off_tile, off_stage;       // LDS layout
     int tile_bytes;
-    int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as bf16 [rows][IW * 3]
+    int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as fp16 [rows][IW * 3]
     int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
     unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
 };
@@ -1178,7 +1190,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
     float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
     float4* lb2 = lb1 + 8;                                                 // [8]
     int* lgoff1 = reinterpret_cast<int*>(psmem + q.off_goff);              // [12]
-    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] bf16 (+ padding)
+    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] fp16 (+ padding)
     u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + wave * 128;
     for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
     for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
@@ -1200,7 +1212,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
         const int n = wt / q.bands, b = wt - n * q.bands;
         const int y2_0 = b * q.R2, r2 = min(q.R2, q.OH2 - y2_0);
         const int y1_0 = 2 * y2_0, r1 = 2 * (r2 - 1) + 5;
-        // ---- phase 1: conv1 rows y1_0 .. y1_0 + r1 - 1 of frame n -> LDS tile (bf16 NHWC) ----
+        // ---- phase 1: conv1 rows y1_0 .. y1_0 + r1 - 1 of frame n -> LDS tile (fp16 NHWC) ----
         const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1   /* diagnostic build 1: no conv1 phase */
         for (int t1 = wave; t1 < ntile1; t1 += nwaves) {                    // (requesting the next tile's dwords ahead measured 6 % slower)
@@ -1208,7 +1220,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
             int yl, x;
             divmod(pp, q.OW1, inv_ow1, yl, x);
             const int fbase = ((n * q.IH + (y1_0 + yl) * 2) * q.IW + x * 2) * 3;
-            bf16x8 xf[6];
+            h16x8 xf[6];
 #pragma unroll
             for (int s6 = 0; s6 < 6; ++s6) {
                 const int addr = fbase + goffs[s6], al = addr & ~3;
@@ -1220,25 +1232,25 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
                 const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
                 auto pair = [](unsigned w, int j) -> unsigned {
                     const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                    return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                    return u8pair_h16(f0, f1);
                 };
                 const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-                xf[s6] = __builtin_bit_cast(bf16x8, packed);
+                xf[s6] = __builtin_bit_cast(h16x8, packed);
             }
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
             for (int s6 = 0; s6 < 6; ++s6) {
-                const bf16x8 w = __builtin_bit_cast(bf16x8, lw1[(2 * s6 + h) * 32 + r]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xf[s6], acc, 0, 0, 0);
+                const h16x8 w = __builtin_bit_cast(h16x8, lw1[(2 * s6 + h) * 32 + r]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xf[s6], acc, 0, 0, 0);
             }
             if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
                 uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)pp * 48);
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = lb1[2 * qd + h];
-                    float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
+                    float v0 = __builtin_fmaf(acc[4 * qd], kConv1Scale, bb.x), v1 = __builtin_fmaf(acc[4 * qd + 1], kConv1Scale, bb.y), v2 = __builtin_fmaf(acc[4 * qd + 2], kConv1Scale, bb.z), v3 = __builtin_fmaf(acc[4 * qd + 3], kConv1Scale, bb.w);
                     dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
                 }
             }
@@ -1261,9 +1273,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
                 const unsigned char* arow = abase + (size_t)kh * q.OW1 * 48;
 #pragma unroll
                 for (int t = 0; t < 16; t += 2) {
-                    const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
-                    const bf16x8 w = __builtin_bit_cast(bf16x8, lw2[(kh * 16 + t + h) * 32 + r]);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
+                    const h16x8 xa = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
+                    const h16x8 w = __builtin_bit_cast(h16x8, lw2[(kh * 16 + t + h) * 32 + r]);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xa, acc2[0], 0, 0, 0);
                 }
             }
             store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
@@ -1274,10 +1286,10 @@ __global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
 }
 
 // The same fused head with conv1's input staged once per band.  In the kernel above every conv1 tile fetches its windows
-// straight from the frame: 18 scattered dword loads and ~100 VALU ops (byte alignment, u8 -> bf16) per lane and 32-pixel tile
+// straight from the frame: 18 scattered dword loads and ~100 VALU ops (byte alignment, u8 -> fp16) per lane and 32-pixel tile
 // for 6 MFMAs, each frame byte fetched and unpacked ~6 times - conv1's phase is 70 of the 131 us and bound by the texture
 // addresser.  Here the workgroup loads the band's frame rows ONCE (contiguous in the frame: one coalesced 16-byte load per
-// thread, requested one item ahead so that its latency hides behind conv1 of the current item), unpacks them once into a bf16
+// thread, requested one item ahead so that its latency hides behind conv1 of the current item), unpacks them once into a fp16
 // image in LDS, and conv1 reads its k-steps (8 consecutive values, 4-byte aligned) from there with two ds_read2_b32.
 // Same values into the same MFMA order: bit-identical to the kernel above and to the separate layers.
 constexpr int kBandPf = 2;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads; 4 until round 2:
@@ -1291,7 +1303,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     u4v* lw2 = reinterpret_cast<u4v*>(psmem + q.off_w2);                   // [80][32]
     float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
     float4* lb2 = lb1 + 8;                                                 // [8]
-    // conv1 tile in LDS: [r1 rows][2 planes: even / odd conv1 columns][plane_px][24] bf16.  conv2 (stride 2) reads, per output
+    // conv1 tile in LDS: [r1 rows][2 planes: even / odd conv1 columns][plane_px][24] fp16.  conv2 (stride 2) reads, per output
     // pixel x2 and kernel row, the conv1 columns 2 x2 .. 2 x2 + 4: with the columns interleaved the 16 lanes of a ds_read_b128
     // group sit 96 bytes apart — an EVEN number of 16-byte slots, so only 8 of the 16 bank groups are hit (2-way conflict on
     // every fragment read, and no padding changes the parity).  Split by column parity, consecutive x2 are 48 bytes = 3 slots
@@ -1299,7 +1311,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     // slots) — conv2's granules are packed in that order for this kernel (w2 = the handle's parity-ordered copy).
     unsigned char* tile1 = psmem + q.off_tile;
     const int plane_px = SPLIT ? q.w2p + 2 : (q.OW1 + 1) >> 1, plane_bytes = plane_px * 48, tile_pitch = 2 * plane_bytes;   // (a part's conv1 width is 2 w2p + 3)
-    unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] bf16 (+ padding)
+    unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] fp16 (+ padding)
     u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + (wave & 7) * 128;   // conv2's output transpose: waves 0..7 only
     for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
     for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
@@ -1352,14 +1364,14 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
         }
     };
-    auto unpack = [&](const uint2 (&raw)[2 * kBandPf]) {                     // 8 uint8 -> 8 bf16 (exact), 16 bytes of the band image
+    auto unpack = [&](const uint2 (&raw)[2 * kBandPf]) {                     // 8 uint8 -> 8 fp16 (exact), 16 bytes of the band image
 #pragma unroll
         for (int j = 0; j < 2 * kBandPf; ++j) {
             const int hc = (tid - 512) + j * 512;
             if (hc * 16 + 16 > q.band_bytes) continue;
             auto pair = [](unsigned w, int k) -> unsigned {
                 const float f0 = (float)((w >> (8 * k)) & 255u), f1 = (float)((w >> (8 * k + 8)) & 255u);
-                return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+                return u8pair_h16(f0, f1);
             };
             *reinterpret_cast<u4v*>(band + (size_t)hc * 16) = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
         }
@@ -1399,7 +1411,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         int n, y2_0, r2, r1, x2_0, w2, w1;
         geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
         const unsigned magic = SPLIT ? (w2 == q.w2p ? q.magic_full : q.magic_last) : magic1;
-        // ---- phase 1: conv1 rows of the band, from the bf16 image ----
+        // ---- phase 1: conv1 rows of the band, from the fp16 image ----
         const int npx1 = r1 * w1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1
         for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
@@ -1422,7 +1434,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
 #pragma unroll
             for (int s6 = 0; s6 < 5; ++s6)                                  // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wv[s6]), __builtin_bit_cast(bf16x8, xv[s6]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
             if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
                 // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
                 // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
@@ -1431,7 +1443,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = bb1[qd];
-                    float v0 = acc[4 * qd] + bb.x, v1 = acc[4 * qd + 1] + bb.y, v2 = acc[4 * qd + 2] + bb.z, v3 = acc[4 * qd + 3] + bb.w;
+                    float v0 = __builtin_fmaf(acc[4 * qd], kConv1Scale, bb.x), v1 = __builtin_fmaf(acc[4 * qd + 1], kConv1Scale, bb.y), v2 = __builtin_fmaf(acc[4 * qd + 2], kConv1Scale, bb.z), v3 = __builtin_fmaf(acc[4 * qd + 3], kConv1Scale, bb.w);
                     dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
                 }
             }
@@ -1468,9 +1480,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                         // slot t + h of the window: 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero weights: the odd run's next 16 bytes)
                         const int slot = t + h;
                         const unsigned char* src = slot < 9 ? arow + slot * 16 : arow + plane_bytes + (slot - 9) * 16;
-                        const bf16x8 xa = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(src));
-                        const bf16x8 w = __builtin_bit_cast(bf16x8, lw2[(kh * 16 + t + h) * 32 + r]);
-                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xa, acc2[0], 0, 0, 0);
+                        const h16x8 xa = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4v*>(src));
+                        const h16x8 w = __builtin_bit_cast(h16x8, lw2[(kh * 16 + t + h) * 32 + r]);
+                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xa, acc2[0], 0, 0, 0);
                     }
                 }
                 if constexpr (SPLIT) store_tile_rows(stage, acc2, lb2, q.c2, t2 * 32, npx2, w2, inv_w2, m0, q.OW2, lane);
@@ -1611,7 +1623,7 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_kernel(const TailParams p)
 // between XCDs costs a write-through drain (2.2 us) and an sc1 read (4 us) and leaves 32 workgroups to do what 256 do in the
 // tail kernel: 17 us in one launch against 7.3 + 5.8 in two.
 struct DenseParams {
-    const u4v* act;            // conv7's output: bf16 [n][G] granules (the NHWC flatten)
+    const u4v* act;            // conv7's output: fp16 [n][G] granules (the NHWC flatten)
     const u4v* w;              // [G][128] granules
     const float* bias;         // [128]
     float* slab;               // [KS][n][100] fp32
@@ -1675,7 +1687,7 @@ __global__ __launch_bounds__(256) void trs_pilot_dense_kernel(const DenseParams 
         for (int j = 0; j < kDenseSteps; ++j) {
             u4v a = sb[2 * j];
             if (c0 + 2 * j >= ge) a = u4v{0u, 0u, 0u, 0u};                  // ragged last chunk: a zero fragment instead of a branch
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[j]), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
             if constexpr (decltype(prefetch)::value) ring_load(j, c0 + kDenseChunk);
         }
     };
@@ -1895,7 +1907,7 @@ struct ConvLayer {
 struct PilotCtx {
     int n_cap = 0, H = 0, W = 0, cu_count = 256;
     ConvLayer L[9];                       // conv1..7 + dense1 (1x1 "conv" over frames) [+ dense4: the second head of cnn_2d_full_house]
-    void* act[9] = {};                    // outputs of L[i] for n_cap frames (bf16; act[7], act[8] float)
+    void* act[9] = {};                    // outputs of L[i] for n_cap frames (fp16; act[7], act[8] float)
     size_t act_elems[9] = {};             // per frame
     int arch = 0;                         // TRS_PILOT_SPD_CTL / CNN_2D share Keras_2D_CNN(2 outputs); TRS_PILOT_SPD_FTR (+1 feature vector); TRS_PILOT_FULL_HOUSE
     int n_layers = 8;
@@ -1917,12 +1929,13 @@ struct PilotCtx {
     trs_pilot_tuning tun{};               // the kernel choices this context was loaded with (trs_pilot_set_tuning, else the defaults)
 };
 
-unsigned short host_f2bf(float f)
-{
-    uint32_t u; std::memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+unsigned short host_f2h(float f)
+{   // round to nearest even; weights beyond binary16's range saturate (|w| > 65504 does not occur in a trained network)
+    const _Float16 h = (_Float16)std::min(std::max(f, -65504.0f), 65504.0f);
+    unsigned short u; std::memcpy(&u, &h, 2);
+    return u;
 }
+float host_h2f(unsigned short u) { _Float16 h; std::memcpy(&h, &u, 2); return (float)h; }
 
 void free_ctx(PilotCtx* c)
 {
@@ -1965,6 +1978,7 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
     p.ksplit = l.ksplit;
+    p.oscale = l.u8in ? kConv1Scale : 1.0f;
     {
         const size_t nt_mb = (size_t)std::max(0, T.nt_mb);                 // outputs above this many MB (128) leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
         const int nt_kind = T.nt_kind;
@@ -2303,7 +2317,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             l.resident = true;
             l.res_nb = std::min(2, l.COUT_PAD / 32);
             l.res_ysplit = l.COUT_PAD / (32 * l.res_nb);
-            l.res_lt = !l.u8in;                                               // bf16 inputs: quad-coalesced loads + LDS transpose
+            l.res_lt = !l.u8in;                                               // fp16 inputs: quad-coalesced loads + LDS transpose
             l.run_pad = run_pad;
             // stride-2 layers with wide kernels re-fetch every byte ~2.5x through overlapping windows: span staging instead
             const int cgr = l.CIN / 8, pix_gran = l.S * cgr;
@@ -2376,7 +2390,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
             }
         }
-        // ---- pack the kernel into granules [g][cout_pad][8] of bf16 and the per-granule input offsets ----
+        // ---- pack the kernel into granules [g][cout_pad][8] of fp16 and the per-granule input offsets ----
         const int ai = i == 8 ? 34 : 2 * i;                               // dense4 of the full-house model
         const float* K = arr[ai];
         const float* B = arr[ai + 1];
@@ -2391,7 +2405,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                     if (f >= 15) continue;
                     const int kw = f / 3, ch = f % 3;
                     for (int co = 0; co < l.COUT; ++co)
-                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + ch) * l.COUT + co] / 255.0f);
+                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2h(K[((kh * l.KW + kw) * l.CIN + ch) * l.COUT + co] * (256.0f / 255.0f));   // x 2^-8 in the epilogue (kConv1Scale)
                 }
             } else {
                 const int kh = g / run_pad, gi = g % run_pad;                 // granule gi of kernel row kh
@@ -2400,7 +2414,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 const int c8n = l.CIN / 8, kw = gi / c8n, c8 = gi % c8n;
                 for (int j = 0; j < 8; ++j)
                     for (int co = 0; co < l.COUT; ++co)
-                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2bf(K[((kh * l.KW + kw) * l.CIN + c8 * 8 + j) * l.COUT + co]);
+                        wp[((size_t)g * l.COUT_PAD + co) * 8 + j] = host_f2h(K[((kh * l.KW + kw) * l.CIN + c8 * 8 + j) * l.COUT + co]);
             }
         }
         for (int g = l.G; g < l.G_pad; ++g) goff[g] = goff[l.G - 1];       // padding granule: valid address, zero weights
@@ -2446,13 +2460,13 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q = Fuse12Params{};
         q.w1 = l0.w; q.b1 = l0.bias; q.goff1 = l0.goff; q.w2 = l1.w;
         q.c2 = ConvParams{};
-        q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1;
+        q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1; q.c2.oscale = 1.0f;
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
         const int want_r2 = std::max(1, (int)T.fuse_r2);                  // 6: measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
         c->fuse12 = false; c->fuse_band = false; c->no_fuse = T.no_fuse != 0;
-        // band form (conv1's input staged once per band as a bf16 image): tile + band image + 8 wave stages
+        // band form (conv1's input staged once per band as a fp16 image): tile + band image + 8 wave stages
         // (measured, 1024 frames of 120x160: R2 = 7 / 6 / 5 -> 129 / 114 / 125 us against 131 for the direct form; 512 frames of
         // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
         const int band_r2 = T.fuse_band_r2;                               // 6; 0 = use the direct form
@@ -2694,7 +2708,7 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     }
     std::vector<unsigned short> tmp(total);
     HIPCHK(hipMemcpy(tmp.data(), c->act[layer], total * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < total; ++i) { uint32_t u = (uint32_t)tmp[i] << 16; std::memcpy(&h_dst[i], &u, 4); }
+    for (size_t i = 0; i < total; ++i) h_dst[i] = host_h2f(tmp[i]);
     return TRS_OK;
 }
 
