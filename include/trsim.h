@@ -159,7 +159,8 @@ int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h
  *     pilot, events) first asks the worker to leave.  Frames and telemetry of a completed step are in HBM (written through);
  *     a consumer that reads them on its own stream does so after trs_sync.  Device-resident controls must be complete
  *     (their producer synchronised) when trs_step is called, and stay untouched until that step is done.  Needs a camera
- *     (cfg.render); with the in-kernel dynamic-brightness filter (trs_set_frame_filter) calls fall back to launches.
+ *     (cfg.render).  Every frame filter of trs_set_frame_filter is rendered by the worker (the dynamic-brightness one by its own
+ *     instantiation since round 3).
  *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident. */
 enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
 int trs_set_step_mode(trs_env* env, int mode, int idle_us);

@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Phase clocks of the fused head (a -DTRS_BAND_STAMPS build given in TRS_HIP_LIB prints them from the device)."""
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from test_pilot import make_weights
+from triton_racer_sim_amd.env import BatchedEnv
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 160
+env = BatchedEnv(n_envs=N, auto_reset=True, img_h=H, img_w=W)
+env.pilot_load(make_weights(H, W, seed=1))
+env.step_synthetic(4, 1)
+for _ in range(3):
+    env.step_pilot(1)
+    env.sync()

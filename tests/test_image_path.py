@@ -270,3 +270,44 @@ def test_gpu_fused_dynamic_brightness_equals_oracle(make_env, cfg, shape):
     for env in (g, o):
         env.set_frame_filter(enabled=False); env.step_synthetic(2, 1)
     assert np.array_equal(g.fetch("img"), o.fetch("img"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", DYNAMIC)
+@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (120, 160, 1024, False), (64, 64, 300, False)])
+def test_gpu_dynamic_brightness_in_resident_mode_equals_oracle(make_env, cfg, shape):
+    """Round 3: the dynamic-brightness frame filter has its own instantiation of the resident worker (until round 2 resident-mode
+    calls silently fell back to launches, include/trsim.h).  Every step posted on its own, lock-step calls, a step sequence, a filter
+    change while the worker is resident, host-array controls: frames and state bit for bit the oracle's render-then-filter."""
+    h, w, n, depth = shape
+    g = make_env("hip", n_envs=n, auto_reset=True, img_h=h, img_w=w, depth=depth)
+    o = make_env("oracle", n_envs=n, auto_reset=True, img_h=h, img_w=w, depth=depth)
+    g.set_step_mode(True)
+    before = int(g.fetch("stats")[2])
+    for env in (g, o):
+        env.set_frame_filter(cfg)
+        env.step_synthetic(1, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.step_synthetic(23, 1)                                       # a queue of posts: the physics team runs ahead, arrivals lag
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for k in range(4):                                                  # lock step: post, wait for the frame
+        for env in (g, o):
+            env.step_synthetic(1, 1)
+        assert np.array_equal(g.fetch("img"), o.fetch("img")), k
+    steer = np.linspace(-1, 1, n).astype(np.float32)
+    for env in (g, o):
+        env.step(steer, 0.6, 0.0)                                       # host arrays through the pinned staging ring
+        env.step_synthetic(3, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    if depth:
+        assert np.array_equal(g.fetch("depth"), o.fetch("depth"))
+    for name in ("seg_idx", "done", "ep_len"):
+        assert np.array_equal(g.fetch(name), o.fetch(name)), name
+    for env in (g, o):                                                  # the filter changes under a resident worker: it leaves, the next post starts the other instantiation
+        env.set_frame_filter(FUSED[1]); env.step_synthetic(3, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    for env in (g, o):
+        env.set_frame_filter(cfg); env.step_synthetic(2, 1)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
+    assert int(g.fetch("stats")[2]) == before                           # no layout fault

@@ -53,6 +53,16 @@ struct RParams {                        // raster side of the step kernel
     int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane)
 };
 
+struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernels (their DYN instantiations)
+    double baseline;
+    float contrast, offset;
+    int color, n_filters;
+    int lo[4], hi[4], dst_ch[4];
+    int w0, w1;                         // brightness window: image rows [w0, w1) = img[40:119] (img_preprocessing.py:88)
+    int lds_off;                        // LDS: uint32 penv[4][H][4] | int esum[2][4][3] | int dbar | float edelta[4]
+    const int* hsv_tab;                 // [512] OpenCV's sdiv | hdiv fixed-point reciprocals (global, 2 KB, cache resident)
+};
+
 }  // namespace trsim
 
 namespace {
@@ -72,6 +82,7 @@ constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;
 
 using trsim::PParams;
 using trsim::RParams;
+using trsim::FParams;
 
 // ---------------------------------------------------------------------------------------------
 // device pieces of the spec
@@ -485,6 +496,193 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
         }
 #endif
         rt = rtn;
+    }
+}
+
+// ImgPreprocessing.__process of ONE colour with this frame's brightness delta (img_preprocessing.py:37-74,92-99): the
+// per-pixel arithmetic of trs_preprocess_kernel (OpenCV's fixed-point reciprocal tables are read from global memory)
+__device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t bgr, float deltaf)
+{
+    int t[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float x = (float)((bgr >> (8 * ch)) & 255u);
+        x = x + deltaf;
+        x = x - f.offset;
+        x = x * f.contrast;
+        x = x + f.offset;
+        x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+        t[ch] = (int)x;
+    }
+    int o0 = t[0], o1 = t[1], o2 = t[2];
+    if (f.color) {
+        const int r = t[0], g = t[1], b = t[2];
+        const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+        const int sdiv = f.hsv_tab[v], hdiv = f.hsv_tab[256 + diff];
+        const int sat = (diff * sdiv + (1 << 11)) >> 12;
+        int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+        h = (h * hdiv + (1 << 11)) >> 12;
+        if (h < 0) h += 180;
+        const int hh = min(h, 255), ss = min(sat, 255);
+        for (int k = 0; k < f.n_filters; ++k) {
+            const int lh = f.lo[k] & 255, ls = (f.lo[k] >> 8) & 255, lv = (f.lo[k] >> 16) & 255;
+            const int uh = f.hi[k] & 255, us = (f.hi[k] >> 8) & 255, uv = (f.hi[k] >> 16) & 255;
+            const int m = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
+            const int dc = f.dst_ch[k];
+            o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
+        }
+    }
+    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+}
+
+
+
+// ---- dynamic brightness behind the rasteriser (trs_set_frame_filter with dynamic_brightness; img_preprocessing.py:88-99): the frame's
+// own mean over rows [w0, w1) only needs the class of every pixel there, so, for up to kDynBatch envs at a time: (A) classify those
+// rows once (classes kept in registers), sum the RAW colours per channel, reduce over the raster team; (B) every thread filters
+// entries of the per-env palettes with each frame's delta; (C) shade all rows from those palettes.  No extra pass over HBM, each pixel
+// classified once, two team barriers per batch (an LDS counter: the physics waves of the workgroup take no part).  `it` = batches
+// this launch has done before this one (the same in every raster wave): the barrier counter and the parity of the sum slots follow it.
+// LDS at f.lds_off: uint32 penv[kDynBatch][H][4] | int esum[2][kDynBatch][3] | int dbar — zeroed (esum, dbar) once per launch.
+// Shared by trs_step_kernel<., true> and trs_worker_kernel<., true>: the same instructions, bit-identical frames.
+constexpr int kDynBatch = 4;
+__host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128; }
+
+template <bool DEPTH>
+__device__ __forceinline__ void raster_dyn_batch(const RParams& p, const FParams& f, const RasterThread& rth, unsigned char* lds_base, const float4 (&cams)[kDynBatch],
+                                                 int nb, uint8_t* img, float* dep, int e, int it, int tid, int lane)
+{
+    uint32_t* const penv = reinterpret_cast<uint32_t*>(lds_base + f.lds_off);                          // [kDynBatch][H][4]
+    int* const esum = reinterpret_cast<int*>(lds_base + f.lds_off + kDynBatch * p.H * 16);           // [2][kDynBatch][3]
+    int* const dbar = esum + 2 * kDynBatch * 3;
+    const int par = it & 1;
+    const int nrw = kRasterThreads / 64;
+    const f2v* const lrow = rth.lrow;
+    unsigned cbits[kDynBatch][4];
+#pragma unroll
+    for (int bi = 0; bi < kDynBatch; ++bi)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cbits[bi][k] = 0u;
+    auto classify4 = [&](int v, const float4& cam) -> unsigned {       // classes of this thread's 4 pixels of row v, 2 bits each
+        const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
+        const f2v rt = lrow[v];
+        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
+        const f2v d = ray_step(kk2, cns);
+        auto cls_of = [&](f2v uf) -> unsigned {
+            const f2v g = __builtin_elementwise_fma(uf, d, a);
+            const unsigned ix = min(cvt_u32_sat(g.x), rth.gwm1);
+            const unsigned iz = min(cvt_u32_sat(g.y), rth.ghm1);
+            unsigned waddr;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(rth.pitch), "v"((ix >> 2) & ~3u));
+            const uint32_t w = *(lds_u32p)(uintptr_t)waddr;
+            return __builtin_amdgcn_ubfe(w, ix << 1, 2);
+        };
+        return cls_of(rth.ufa) | (cls_of(rth.ufb) << 2) | (cls_of(rth.ufc) << 4) | (cls_of(rth.ufd) << 6);
+    };
+    // (A) rows outside, envs inside: the (up to) four envs' lookups of one row are independent chains (row table -> map
+    // -> palette are three dependent LDS round trips per row, and two waves per SIMD cannot hide them one env at a time)
+    unsigned srb[kDynBatch], sgs[kDynBatch];                          // R | B << 16 and G: <= 24 rows x 4 px x 255 per thread fits 16 bits
+#pragma unroll
+    for (int bi = 0; bi < kDynBatch; ++bi) { srb[bi] = 0u; sgs[bi] = 0u; }
+    {
+        int slot = 0;
+        for (int v = rth.vstart; v < f.w1; v += p.rows_per_pass) {
+            if (v < f.w0) continue;
+            const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+            const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
+            unsigned packs[kDynBatch];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = (v >= p.uni_rows && bi < nb) ? classify4(v, cams[bi]) : 0u;
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cbits[bi][k] |= word == (unsigned)k ? packs[bi] << sh : 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = *(lds_u32p)(uintptr_t)(pal_a + (((packs[bi] >> (2 * k)) & 3u) << 2));
+                    srb[bi] += c & 0x00FF00FFu; sgs[bi] += (c >> 8) & 255u;
+                }
+            }
+            ++slot;
+        }
+    }
+#pragma unroll
+    for (int bi = 0; bi < kDynBatch; ++bi) {
+        if (bi >= nb) continue;
+        unsigned sr = srb[bi] & 0xFFFFu, sb = srb[bi] >> 16, sg = sgs[bi];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+        if (lane == 0) {
+            int* const es = esum + (par * kDynBatch + bi) * 3;
+            atomicAdd(&es[0], (int)sr); atomicAdd(&es[1], (int)sg); atomicAdd(&es[2], (int)sb);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 1)) __builtin_amdgcn_s_sleep(1);
+    // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then the palette entries
+    {
+        const double cnt = (double)(f.w1 - f.w0) * (double)p.W;
+        const int per_env = p.H * 4;
+        float dl = 0.0f;                                              // lane b of every wave computes env b's delta once (binary64 divisions)
+        if (lane < kDynBatch && lane < nb) {
+            const int* const es = esum + (par * kDynBatch + lane) * 3;
+            double cur = 0.0;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) cur = cur + (cnt > 0 ? (double)es[ch] / cnt : 0.0);
+            cur = cur + 0.0;
+            dl = (float)((f.baseline - cur) / 3);
+        }
+        float dlt[kDynBatch];
+#pragma unroll
+        for (int bi = 0; bi < kDynBatch; ++bi) dlt[bi] = __shfl(dl, bi, 64);
+        for (int t = tid; t < kDynBatch * per_env; t += kRasterThreads) {
+            const int bi = t / per_env, ent = t - bi * per_env;
+            if (bi >= nb) break;
+            const float deltaf = bi == 0 ? dlt[0] : (bi == 1 ? dlt[1] : (bi == 2 ? dlt[2] : dlt[3]));
+            penv[t] = filter_colour_dev(f, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)), deltaf);
+        }
+        if (tid < kDynBatch * 3) esum[(par ^ 1) * kDynBatch * 3 + tid] = 0;   // the next batch's sums start from zero (nobody reads that half now)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 2)) __builtin_amdgcn_s_sleep(1);
+    // (C)
+#pragma unroll
+    for (int bi = 0; bi < kDynBatch; ++bi) {
+        const int eb = e + bi;
+        if (bi >= nb) continue;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            img + (size_t)eb * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
+        __amdgpu_buffer_rsrc_t drs = rsrc;
+        if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)eb * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
+        int slot = 0;
+        const unsigned penv_a = (unsigned)f.lds_off + (unsigned)(bi * p.H * 16);
+        for (int v = rth.vstart; v < p.H; v += p.rows_per_pass) {
+            const bool in_win = v >= f.w0 && v < f.w1;
+            unsigned pack = 0;
+            if (v >= p.uni_rows) {
+                if (in_win) {
+                    const unsigned word = (unsigned)slot >> 2;
+                    const unsigned wv = word == 0 ? cbits[bi][0] : (word == 1 ? cbits[bi][1] : (word == 2 ? cbits[bi][2] : cbits[bi][3]));
+                    pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
+                } else {
+                    pack = classify4(v, cams[bi]);
+                }
+            }
+            if (in_win) ++slot;
+            const unsigned row_a = penv_a + ((unsigned)v << 4);
+            const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
+            const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
+            const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
+            __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, rth.col_off + v * rth.row_bytes, 0, TRS_STORE_AUX);
+            if constexpr (DEPTH) {
+                const unsigned dz = __float_as_uint(rth.lrowdepth[v]);
+                const u4v d4 = {dz, dz, dz, dz};
+                __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (rth.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+            }
+        }
     }
 }
 

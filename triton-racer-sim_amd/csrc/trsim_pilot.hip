@@ -1406,7 +1406,14 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
 #pragma unroll
     for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
+#ifdef TRS_BAND_STAMPS   /* diagnostic build: shader clocks of workgroup 7's wave 0 (a conv2 wave) and wave 8 (a loader), summed over its items */
+    unsigned long long bst[6] = {0, 0, 0, 0, 0, 0}, bprev = 0; int bitems = 0;
+#define BAND_STAMP(k) do { if (blockIdx.x == 7 && (tid == 0 || tid == 512)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) bst[k] += tn - bprev; bprev = tn; } } while (0)
+#else
+#define BAND_STAMP(k) do { } while (0)
+#endif
     while (wt < total) {
+        BAND_STAMP(0);
         const int nxt = wt + gridDim.x;                                     // uniform per workgroup
         int n, y2_0, r2, r1, x2_0, w2, w1;
         geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
@@ -1449,7 +1456,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
         }
 #endif
+        BAND_STAMP(1);
         __syncthreads();                                                    // the tile is complete, the band image is free
+        BAND_STAMP(2);
         if (loader) {
             if (nxt < total) {
                 unpack(raw);                                                // the next item's band (requested an item ago)
@@ -1490,9 +1499,18 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
 #endif
         }
+        BAND_STAMP(3);
         __syncthreads();                                                    // the tile is free, the next band image is complete
+        BAND_STAMP(4);
+#ifdef TRS_BAND_STAMPS
+        ++bitems;
+#endif
         wt = nxt;
     }
+#ifdef TRS_BAND_STAMPS
+    if (blockIdx.x == 7 && (tid == 0 || tid == 512))
+        printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %llu | wait at barrier %llu | phase 2 work %llu | wait at barrier %llu\n", wave, bitems, bst[1], bst[2], bst[3], bst[4]);
+#endif
 }
 
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)

@@ -89,6 +89,7 @@ struct WParams {
     unsigned long long start;                               // first step index this launch processes
     unsigned long long idle_ticks, life_ticks, safety_ticks;   // wall_clock64() ticks (100 MHz)
     int lds_off_phys, lds_off_ctl, n_blocks;
+    FParams fp;                                             // DYN instantiation: ImgPreprocessing with dynamic brightness behind the rasteriser (trs_set_frame_filter)
 };
 #ifndef TRS_RESIDENT_DIAG
 #define TRS_RESIDENT_DIAG 0   /* timing-only diagnostic builds (-DTRS_RESIDENT_DIAG=bits), never shipped, like TRS_ABLATE: 1 = arrive without the counted wait (WRONG completion flags), 2 = no telemetry stores, 4 = clock probe of one raster wave into stats[40..44] */
@@ -110,7 +111,7 @@ struct Resident {
     unsigned life_us = 500000;           // a worker leaves after this long whatever happens (trs_resident_debug_lifetime: tests force many generations)
     unsigned char* hctl = nullptr;       // pinned staging for host-array controls: [kSlots] x (3 float[n] + uint8[n])
     size_t hctl_slot = 0;
-    int lds_bytes = 0, lds_off_ctl = 0;
+    int lds_bytes = 0, lds_off_ctl = 0, lds_off_dyn = 0;
 };
 
 }  // namespace trsim
@@ -344,7 +345,7 @@ __device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, Dut
     }
 }
 
-template <bool DEPTH>
+template <bool DEPTH, bool DYN>
 __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
     if (tid < kSlots) l.arrive[tid] = 0;
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
+    if constexpr (DYN) { if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0; }   // channel sums, team-barrier counter
     if (!raster_team)
         for (int j = pw; j < n_loc; j += kPhysWaves) {
             EnvRegs st;
@@ -525,6 +527,41 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
         // uniform rows of ALL envs go first: they need no pose and are on their way while the physics team integrates.
         const u64 ahead = (lds_load64(l.word) & kCountMask) - 1 - s;
         const u64 keep = ahead + 1 < (u64)lag ? ahead + 1 : (u64)lag;       // the lag shrinks with the queue: a consumer that waits gets its flag early
+        if constexpr (DYN) {
+            // Dynamic-brightness frame filter: the envs of a step go through raster_dyn_batch four at a time (classify the brightness rows,
+            // team-reduce the channel sums, filter the palettes, shade), exactly as trs_step_kernel's DYN instantiation does — the same
+            // instructions on the same tables: bit-identical frames.  Arrivals owed are settled at the step's start: everything issued
+            // since the end of step `owed` is then (s - owed - 1) whole steps.
+            while (s - owed >= keep) {
+                wait_vmcnt_le((int)(s - owed - 1) * nstep);
+                raster_arrive(l, owed++, lane);
+            }
+            const int nbatch = (n_loc + kDynBatch - 1) / kDynBatch;
+            for (int b0 = 0; b0 < n_loc; b0 += kDynBatch) {
+                float4 cams[kDynBatch];
+                unsigned tel = 0; int mine_j = -1;
+#pragma unroll
+                for (int bi = 0; bi < kDynBatch; ++bi) {
+                    const int j = b0 + bi;
+                    cams[bi] = make_float4(0.f, 0.f, 0.f, 1.f);
+                    if (j < n_loc) {
+                        if (!wait_lds_ge(wp, l, nullptr, &l.pprog[j], r + 1, 3u, lane)) return;
+                        const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
+                        cams[bi] = *reinterpret_cast<const float4*>(sl);
+                        if ((j % (kRasterThreads / 64)) == wave) { mine_j = j; tel = __float_as_uint(sl[4 + min(lane, 12)]); }
+                        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cams[bi].x), "v"(cams[bi].y), "v"(cams[bi].z), "v"(cams[bi].w), "v"(tel) : "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                raster_dyn_batch<DEPTH>(p, wp.fp, rth, smem, cams, min(kDynBatch, n_loc - b0), img, dep, e_begin + b0, r * nbatch + b0 / kDynBatch, tid, lane);
+                if (mine_j >= 0 && !(kDiag & 2)) {                    // the step's telemetry of this wave's env of the batch (a wave owns at most one of four)
+                    const size_t e = (size_t)(e_begin + mine_j);
+                    if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            continue;
+        }
         const bool sweep = ahead == 0;
         if (sweep)
             for (int j = 0; j < n_loc; ++j) raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j));
@@ -579,11 +616,13 @@ inline uint64_t host_load(const uint64_t* p) { return __atomic_load_n(p, __ATOMI
 inline void host_store(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 
 // the worker's LDS need with the track that is loaded NOW (a larger track may have been loaded since resident mode was selected)
+// and the frame filter that is set NOW (the dynamic-brightness filter adds the per-env palettes of a batch of four envs)
 int worker_fits(trs_env* e)
 {
     Resident* R = e->res;
     R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables
     R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
+    if (e->has_frame_filter && e->filter_dynamic) { R->lds_off_dyn = (R->lds_bytes + 15) & ~15; R->lds_bytes = R->lds_off_dyn + dyn_lds_bytes(e->H); }
     if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
     return TRS_OK;
 }
@@ -608,8 +647,24 @@ int worker_launch(trs_env* e, uint64_t start)
     const int grid = (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg;
     wp.n_blocks = grid;
     hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)start);
-    if (e->rp.depth) hipLaunchKernelGGL(trs_worker_kernel<true>, dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
-    else hipLaunchKernelGGL(trs_worker_kernel<false>, dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
+    const bool dyn = e->has_frame_filter && e->filter_dynamic;
+    if (dyn) {                                              // the fields trs_step_kernel's DYN instantiation gets (trsim_hip.hip, launch_step)
+        const trs_pre_config& c = e->frame_filter;
+        wp.fp.baseline = c.brightness_baseline; wp.fp.contrast = c.contrast_ratio; wp.fp.offset = c.contrast_offset;
+        wp.fp.color = c.color_filter_enabled; wp.fp.n_filters = c.n_filters;
+        for (int k = 0; k < 4; ++k) {
+            wp.fp.lo[k] = c.hsv_lo[k][0] | (c.hsv_lo[k][1] << 8) | (c.hsv_lo[k][2] << 16);
+            wp.fp.hi[k] = c.hsv_hi[k][0] | (c.hsv_hi[k][1] << 8) | (c.hsv_hi[k][2] << 16);
+            wp.fp.dst_ch[k] = c.dst_channel[k];
+        }
+        wp.fp.w0 = std::min(40, e->H); wp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
+        wp.fp.hsv_tab = e->hsv_tab;
+        wp.fp.lds_off = R->lds_off_dyn;
+    }
+    if (e->rp.depth) { if (dyn) hipLaunchKernelGGL((trs_worker_kernel<true, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
+                       else hipLaunchKernelGGL((trs_worker_kernel<true, false>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp); }
+    else { if (dyn) hipLaunchKernelGGL((trs_worker_kernel<false, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
+           else hipLaunchKernelGGL((trs_worker_kernel<false, false>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp); }
     RCHK(hipGetLastError());
     R->running = true;
     return TRS_OK;
@@ -828,11 +883,11 @@ TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
     int rc = ensure_resident(e);
     if (rc) return rc;
     Resident* R = e->res;
-    R->lds_off_ctl = (e->lds_step + 15) & ~15;
-    R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
-    if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
-    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    { int rf = worker_fits(e); if (rf) return rf; }
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (idle_us > 0) R->idle_us = (unsigned)std::min(idle_us, 1000000);
     if (!R->enabled) { R->base = R->seen_done = e->step_count; host_store(&R->mb->posted, e->step_count); }
     R->enabled = true;
