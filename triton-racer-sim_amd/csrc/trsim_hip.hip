@@ -355,17 +355,18 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         }
         __syncthreads();
         // ---- pass 2: trim, masks, merge ----
+        // (p.color is tested once per 4-pixel group, not per pixel: the four pixels' chains of dependent table lookups — trim, OpenCV's
+        // reciprocal tables, the range bits — then interleave instead of running one behind the other)
         for (int g = tid; g < p.gpe; g += nthreads) {
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
-            unsigned t[12];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { t[k] = s_trim[(w.x >> (8 * k)) & 255u]; t[4 + k] = s_trim[(w.y >> (8 * k)) & 255u]; t[8 + k] = s_trim[(w.z >> (8 * k)) & 255u]; }
             unsigned ob[12];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                unsigned o0 = t[3 * px], o1 = t[3 * px + 1], o2 = t[3 * px + 2];
-                if (p.color) {
-                    const int r = (int)o0, gg = (int)o1, b = (int)o2;
+            for (int k = 0; k < 4; ++k) { ob[k] = s_trim[(w.x >> (8 * k)) & 255u]; ob[4 + k] = s_trim[(w.y >> (8 * k)) & 255u]; ob[8 + k] = s_trim[(w.z >> (8 * k)) & 255u]; }
+            if (p.color) {
+                unsigned inr[4];
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    const int r = (int)ob[3 * px], gg = (int)ob[3 * px + 1], b = (int)ob[3 * px + 2];
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
                     const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
                     const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
@@ -373,13 +374,15 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                     h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
-                    const unsigned inr = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
-                    // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it (fsel, -1 = none)
-                    if (fsel0 >= 0) o0 = (inr >> fsel0) & 1u ? 255u : 0u;
-                    if (fsel1 >= 0) o1 = (inr >> fsel1) & 1u ? 255u : 0u;
-                    if (fsel2 >= 0) o2 = (inr >> fsel2) & 1u ? 255u : 0u;
+                    inr[px] = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
                 }
-                ob[3 * px] = o0; ob[3 * px + 1] = o1; ob[3 * px + 2] = o2;
+                // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it (fsel, -1 = none)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    if (fsel0 >= 0) ob[3 * px] = (inr[px] >> fsel0) & 1u ? 255u : 0u;
+                    if (fsel1 >= 0) ob[3 * px + 1] = (inr[px] >> fsel1) & 1u ? 255u : 0u;
+                    if (fsel2 >= 0) ob[3 * px + 2] = (inr[px] >> fsel2) & 1u ? 255u : 0u;
+                }
             }
             const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
                              ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
