@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the informational 8-steps-per-launch leg (profiling runs: only the timed kernel in the trace)")
+    ap.add_argument("--profile-mode", action="store_true", help="for rocprofv3 runs (scripts/profile.sh): no clock pre-warm, and a resident worker is asked to leave after the "
+                                                                  "warm-up, so that every trs_worker_kernel dispatch of the trace serves exactly --steps (or --warmup) steps")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
     args = ap.parse_args()
 
@@ -198,7 +200,10 @@ def main():
     # the resident worker renders; physics-only envs and the pilot loop go through launches (the pilot's kernels need the CUs' LDS)
     resident = bool((args.resident or args.step_mode == "resident") and render and not args.pilot and spl == 1)
     if resident:
-        env.set_step_mode(True)
+        # idle_us: the worker leaves by itself after this long without a post.  The library's default (2 ms) suits an interactive loop; a
+        # benchmark whose host thread can be descheduled for milliseconds (a tracer attached, the GIL) would see its worker leave and be
+        # relaunched mid-run — every explicit boundary below asks it to leave (quiesce) instead.
+        env.set_step_mode(True, 100000)
 
     def barrier():
         # every step handed to the env so far is complete in memory (resident mode: completion flags; launch mode: the stream has drained),
@@ -226,10 +231,12 @@ def main():
     # the driver's --warmup 5 is 50 us, so the clocks are brought up first — with untimed steps of the same workload, for PREWARM_S
     # seconds — and the W warm-up steps follow.  `config.prewarm_s` says so in the line.
     t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < PREWARM_S:
+    while not args.profile_mode and time.perf_counter() - t_pw < PREWARM_S:
         run(50 if args.pilot else 400)
         env.sync()
     run(max(args.warmup, 1))
+    if args.profile_mode and resident:
+        env.quiesce()
 
     barrier()
     t0 = time.perf_counter()
@@ -369,7 +376,7 @@ def main():
             try:
                 from triton_racer_sim_amd.env import BatchedEnv
                 env3 = BatchedEnv(n_envs=512, env_id_base=3584, img_h=120, img_w=160, auto_reset=True, device=local_rank)
-                env3.set_step_mode(True)
+                env3.set_step_mode(True, 100000)
                 s3 = max(args.steps, 2000)
                 env3.step_synthetic(8000, 1)                                # 40 ms: clocks up
                 env3.sync()
@@ -392,7 +399,7 @@ def main():
                 env3.close()
             except Exception as exc:
                 shard_leg = {"error": str(exc)}
-        env.set_step_mode(resident)
+        env.set_step_mode(resident, 100000)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
         frac = lambda ms: round(Bx * n * args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
@@ -457,7 +464,7 @@ def main():
                             + (" + fp32 depth" if render and args.depth else "")
                             + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
                             + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
-                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "prewarm_s": PREWARM_S,
+                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "prewarm_s": 0.0 if args.profile_mode else PREWARM_S,
                 "timing": ("host wall clock from the post of the first timed step to the completion flag of the last (worker resident across the warm-up -> timed boundary); "
                            "roofline.achieved from a second pass of the same steps bracketed by HIP events = one whole worker launch") if resident else "host wall clock around the timed steps; HIP events on the env's stream for roofline.achieved", "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
             },

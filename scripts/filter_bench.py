@@ -6,6 +6,7 @@ sys.path.insert(0, ".")
 from triton_racer_sim_amd.env import BatchedEnv
 
 N, STEPS = 1024, 600
+RESIDENT = len(sys.argv) > 1 and sys.argv[1] == "resident"      # steps posted to the resident worker instead of one launch per step
 STATIC = {"preprocessing_color_filter_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2}
 DYN = dict(STATIC, preprocessing_dynamic_brightness_enabled=True)
 
@@ -17,6 +18,9 @@ def timed(env, fn):
 
 
 env = BatchedEnv(n_envs=N, auto_reset=True)
+if RESIDENT:
+    env.set_step_mode(True)
+env.step_synthetic(6000, 1)                                     # GPU clocks up
 rows = []
 rows.append(("raw frames (no filter)", timed(env, lambda k: env.step_synthetic(k, 1))))
 env.set_frame_filter(STATIC)
@@ -34,5 +38,6 @@ def separate(k):
 
 
 rows.append(("raw frames + separate trs_preprocess kernel (same filter)", timed(env, separate)))
+print("step mode:", "resident worker (every step posted on its own)" if RESIDENT else "one launch per step")
 for name, us in rows:
     print(f"{name:62s} {us:8.2f} us / step   {N / us:7.2f} M env-steps/s")

@@ -43,7 +43,7 @@ def test_tables_bit_exact(make_env, track):
 
 @pytest.mark.parametrize("track", ["generated", "mountain"])
 def test_locate_matches_reference_golden(make_env, track):
-    """G1: integer indices produced by the reference's LocationTracker itself (6,994 / 2,872 queries incl.
+    """G1: integer indices produced by the reference's LocationTracker itself (6,994 / 2,597 queries incl.
     duplicates, far points -> 0, near ties, points around L1 = 100)."""
     g1 = load_golden(f"locate_{track}.json")
     env = make_env("hip", n_envs=1, track=track_points(track), render=False)
