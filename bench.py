@@ -15,6 +15,14 @@ Workload at N = 1: BASELINE.json configs[2] (1024 envs, physics + 120x160 RGB pi
 Workload at N > 1: BASELINE.json configs[3] (4096 envs in total, sharded over the N GPUs = 512 per GPU at N = 8,
 one RCCL all-gather of the episode returns closing the job).  --envs-per-gpu / --total-envs override either.
 Rank 0 prints ONE JSON line.
+
+Timing (round 3).  The metric is a steady-state rate.  An idle MI355X needs ~25-40 ms of work to raise its clocks, so untimed steps
+of the same workload run for PREWARM_S first, then the W warm-up steps.  In resident mode the worker stays on the GPU across the warm-up -> timed
+boundary: `value` is the host wall clock from the post of the first timed step to the completion flag of the last (env.sync() waits on the flags
+the worker writes once a step's frames are in memory); a device-wide synchronisation there would wait for the worker to leave, so torch's stream
+is synchronised instead.  `roofline.achieved` comes from a second pass of the same K steps bracketed by HIP events on the worker's own stream
+(= one whole worker launch: start-up, K steps, exit).  --profile-mode (scripts/profile.sh) drops the pre-warm and makes every worker dispatch of a
+trace serve exactly K steps.
 """
 import argparse
 import ctypes
