@@ -519,9 +519,9 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
         const int r = t[0], g = t[1], b = t[2];
         const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
         const int sdiv = f.hsv_tab[v], hdiv = f.hsv_tab[256 + diff];
-        const int sat = (diff * sdiv + (1 << 11)) >> 12;
+        const int sat = (__mul24(diff, sdiv) + (1 << 11)) >> 12;           // 24-bit multiplies: full rate (operands far below 2^23)
         int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-        h = (h * hdiv + (1 << 11)) >> 12;
+        h = (__mul24(h, hdiv) + (1 << 11)) >> 12;
         if (h < 0) h += 180;
         const int hh = min(h, 255), ss = min(sat, 255);
         for (int k = 0; k < f.n_filters; ++k) {

@@ -369,9 +369,9 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                     const int r = (int)ob[3 * px], gg = (int)ob[3 * px + 1], b = (int)ob[3 * px + 2];
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
                     const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
-                    const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
+                    const int sat = (__mul24(diff, s_tab[v]) + (1 << 11)) >> 12;       // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
                     int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
-                    h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
+                    h = (__mul24(h, s_tab[256 + diff]) + (1 << 11)) >> 12;
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
                     inr[px] = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
@@ -746,9 +746,9 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                     const int r = (int)ob[3 * q], gg = (int)ob[3 * q + 1], b = (int)ob[3 * q + 2];
                     const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
                     const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
-                    const int sat = (diff * s_tab[v] + (1 << 11)) >> 12;
+                    const int sat = (__mul24(diff, s_tab[v]) + (1 << 11)) >> 12;       // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
                     int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
-                    h = (h * s_tab[256 + diff] + (1 << 11)) >> 12;
+                    h = (__mul24(h, s_tab[256 + diff]) + (1 << 11)) >> 12;
                     if (h < 0) h += 180;
                     const int hh = min(h, 255), ss = min(sat, 255);
                     inr[q] = s_rng[hh] & s_rng[256 + ss] & s_rng[512 + v];

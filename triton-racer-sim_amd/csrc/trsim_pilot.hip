@@ -732,7 +732,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
 struct ChainLayer {
     const u4v* w; const float* bias;
     int IH, IW, OH, OW, COUT, cg, cgs;     // COUT == COUT_PAD (64 / 128); cg = input granules per pixel (8 / 16), cgs = log2
-    int nt;                                // 32-pixel tiles per wave item: 2 or 3, whichever leaves the busiest SIMD fewer MFMAs (3 also streams 1/3 less weights)
+    int nt, nb;                            // a wave item = nt x 32 pixels x nb x 32 channels (nt 2 / 3, nb 1 / 2): the choice that leaves the busiest SIMD the fewest MFMAs
 };
 struct ChainParams {
     const u4v* in;             // the first layer's input activation, fp16 NHWC
@@ -745,17 +745,29 @@ struct ChainParams {
 #ifndef TRS_CHAIN_ABLATE
 #define TRS_CHAIN_ABLATE 0   /* timing-only diagnostic builds of the chain's layers, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no MFMA */
 #endif
-template <int HALF, int R, int NT>
+#if defined(TRS_CHAIN_STAMPS) && TRS_CHAIN_STAMPS == 2   /* finer: workgroup 7, wave 0, inside each item: prologue | K loop | epilogue; the k-steps of the last layer */
+__device__ unsigned long long g_chain_dbg[64];
+__device__ int g_chain_dbg_n;
+#define CHAIN_ITEM_STAMP() do { if (blockIdx.x == 7 && wave == 0 && lane == 0 && g_chain_dbg_n < 64) g_chain_dbg[g_chain_dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+__shared__ unsigned long long g_chain_k[80];          // (in LDS: a global store per stamp would join the weight loads' in-order queue)
+#define CHAIN_K_STAMP(k) do { if (HALF == 8 && blockIdx.x == 7 && wave == 0 && lane == 0) g_chain_k[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHAIN_ITEM_STAMP() do { } while (0)
+#define CHAIN_K_STAMP(k) do { } while (0)
+#endif
+// One layer of the chain.  A wave item = NT x 32 pixels x NB x 32 output channels; the weight ring is R k-steps deep (R x NB granules per
+// lane: NB = 1 takes twice the depth for the same registers and the same lead time in MFMA clocks).
+template <int HALF, int R, int NT, int NB>
 __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
                                             unsigned short* gout, int wave, int nwaves, int lane)
 {
-    constexpr int NB = 2;
     const int r = lane & 31, h = lane >> 5;
     const int uout = L.OH * L.OW, m_wg = nu * uout;
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = L.COUT / (NB * 32);
     const float4* lbias = reinterpret_cast<const float4*>(lbias_f);
     constexpr int ksteps = 9 * HALF;
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
+        CHAIN_ITEM_STAMP();
         const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
         const int cbase = cgrp * NB * 32;
         int lbase[NT], mo[NT];
@@ -780,6 +792,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        [[maybe_unused]] h16x8 xkeep[NT];
         auto pixels = [&](int k, h16x8 (&x)[NT]) {
             const int tap = k / HALF, g = 2 * (k % HALF) + h;
             const int tap_off = (tap / 3) * L.IW + tap % 3;
@@ -794,12 +807,13 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #endif
             }
         };
-        [[maybe_unused]] h16x8 xkeep[NT];
+        CHAIN_ITEM_STAMP();
         h16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
         for (int k = 0; k < ksteps; ++k) {
             const int d = k % R;
+            CHAIN_K_STAMP(k);
             h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
             h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
             if (k + 1 < ksteps) pixels(k + 1, xn);
@@ -820,6 +834,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        CHAIN_ITEM_STAMP();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -849,12 +864,25 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 }
             }
         }
+        CHAIN_ITEM_STAMP();
     }
 }
-
 #ifndef TRS_CHAIN_R
-#define TRS_CHAIN_R 4   /* weight ring depth of the chain's layers, in k-steps */
+#define TRS_CHAIN_R 4   /* weight ring depth of the chain's layers in k-steps at NB = 2 (twice that at NB = 1) */
 #endif
+// (tile height, channel blocks) of a layer -> its instantiation
+template <int HALF>
+__device__ __forceinline__ void chain_layer_any(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
+                                                unsigned short* gout, int wave, int nwaves, int lane)
+{
+    if (L.nb == 1) {
+        if (L.nt == 3) chain_layer<HALF, 2 * TRS_CHAIN_R, 3, 1>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
+        else chain_layer<HALF, 2 * TRS_CHAIN_R, 2, 1>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
+    } else {
+        if (L.nt == 3) chain_layer<HALF, TRS_CHAIN_R, 3, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
+        else chain_layer<HALF, TRS_CHAIN_R, 2, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
+    }
+}
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams p)
 {
@@ -879,6 +907,12 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
             }
         }
     };
+#ifdef TRS_CHAIN_STAMPS   /* diagnostic build: shader clocks of workgroup 7's waves 0 and 7 per stage of the chain */
+    unsigned long long cst[12] = {0}, cprev = __builtin_amdgcn_s_memtime(); int cn = 0;
+#define CHAIN_STAMP() do { if (blockIdx.x == 7 && (tid == 0 || tid == 448)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); cst[cn++] = tn - cprev; cprev = tn; } } while (0)
+#else
+#define CHAIN_STAMP() do { } while (0)
+#endif
     int li = 0;
     const u4v* cur = A;
     if (p.split_first) {
@@ -889,11 +923,13 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
             if (cnt > 0) stage(L0, u0 + per * pass, cnt, lds0 + p.offB);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            CHAIN_STAMP();
             if (cnt > 0) {
-                if (L0.nt == 3) chain_layer<4, TRS_CHAIN_R, 3>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
-                else chain_layer<4, TRS_CHAIN_R, 2>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
+                chain_layer_any<4>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
             }
+            CHAIN_STAMP();
             __syncthreads();
+            CHAIN_STAMP();
         }
         li = 1;
     } else {
@@ -904,16 +940,37 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     for (; li < p.nl - 1; ++li) {
         const ChainLayer& L = p.L[li];
         u4v* const nxt = cur == A ? B : A;
-        if (L.nt == 3) chain_layer<4, TRS_CHAIN_R, 3>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
-        else chain_layer<4, TRS_CHAIN_R, 2>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        chain_layer_any<4>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
+        CHAIN_STAMP();
         __syncthreads();
+        CHAIN_STAMP();
         cur = nxt;
     }
     {
         const ChainLayer& L = p.L[p.nl - 1];
-        if (L.nt == 3) chain_layer<8, TRS_CHAIN_R, 3>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
-        else chain_layer<8, TRS_CHAIN_R, 2>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
+        chain_layer_any<8>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
     }
+#ifdef TRS_CHAIN_STAMPS
+    __syncthreads();   // the printf below is a host call: from a wave that is done early it would run beside the last layer of the others (and did, in
+                       // the first stamped builds: their weight loads then took ~3,000 clocks each - an artefact of the instrument, not of the kernel)
+#endif
+    CHAIN_STAMP();
+#if defined(TRS_CHAIN_STAMPS) && TRS_CHAIN_STAMPS == 2
+    if (blockIdx.x == 7 && tid == 0) {
+        for (int i = 0; i + 3 < g_chain_dbg_n; i += 4)
+            printf("chain item %d of wave 0: prologue %llu | K loop %llu | epilogue %llu | since previous item's end %llu\n", i / 4, g_chain_dbg[i + 1] - g_chain_dbg[i],
+                   g_chain_dbg[i + 2] - g_chain_dbg[i + 1], g_chain_dbg[i + 3] - g_chain_dbg[i + 2], i ? g_chain_dbg[i] - g_chain_dbg[i - 1] : 0ull);
+        g_chain_dbg_n = 0;
+        printf("chain conv7 k-steps of wave 0 [clocks each]:");
+        for (int k = 1; k < 72; ++k) printf(" %llu", g_chain_k[k] - g_chain_k[k - 1]);
+        printf("\n");
+    }
+#endif
+#ifdef TRS_CHAIN_STAMPS
+    if (blockIdx.x == 7 && (tid == 0 || tid == 448))
+        printf("chain, workgroup 7, wave %d [clocks]: stage A %llu | conv4 A work %llu wait %llu | stage B %llu | conv4 B work %llu wait %llu | conv5 work %llu wait %llu | conv6 work %llu wait %llu | conv7 %llu\n",
+               wave, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], cst[7], cst[8], cst[9], cst[10]);
+#endif
 }
 
 // ---- conv3 with its input frames in LDS (round 2) -----------------------------------------------------------------------------
@@ -2276,7 +2333,7 @@ TRS_EXPORT void trs_default_pilot_tuning(trs_pilot_tuning* t)
     std::memset(t, 0, sizeof *t);
     t->struct_size = (uint32_t)sizeof *t;
     t->fuse_band_r2 = 6; t->fuse_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
-    t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
+    t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->chain_nb = 2; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
 }
 
 TRS_EXPORT int trs_pilot_set_tuning(trs_env* e, const trs_pilot_tuning* t)
@@ -2576,12 +2633,30 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 q.F = f; q.nl = nl; q.split_first = split ? 1 : 0; q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
                 for (int j = 0; j < nl; ++j) {
                     const ConvLayer& l = c->L[first + j];
-                    // tile height per layer: items = ceil(pixels / (32 nt)) x (COUT / 64) over 8 waves = 4 SIMDs; the busiest SIMD's MFMA count decides
-                    const int px = (split && j == 0 ? f / 2 : f) * l.OH * l.OW, cgrps = l.COUT / 64;
-                    auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
-                    int nt = busiest(3) <= busiest(2) ? 3 : 2;
-                    if (T.chain_nt == 2 || T.chain_nt == 3) nt = T.chain_nt;
-                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt};
+                    // item shape per layer: items = ceil(pixels / (32 nt)) x (COUT / (32 nb)), dealt round-robin to 8 waves; waves w and w + 4 share
+                    // a SIMD (one workgroup per CU): the shape that leaves the busiest SIMD the fewest MFMAs per k-step, and among equals the one
+                    // that gives that SIMD two waves (a lone wave per SIMD exposes every LDS and L2 round trip: stamps, profiles/r03_pilot_chain.txt)
+                    const int px = (split && j == 0 ? f / 2 : f) * l.OH * l.OW;
+                    auto busiest = [&](int nt, int nb, int& waves_on_it) {
+                        const int items = ((px + 32 * nt - 1) / (32 * nt)) * (l.COUT / (32 * nb));
+                        int worst = 0; waves_on_it = 0;
+                        for (int sd = 0; sd < 4; ++sd) {
+                            int n_items = 0, n_waves = 0;
+                            for (int w = sd; w < 8; w += 4) { const int mine = items > w ? (items - w + 7) / 8 : 0; n_items += mine; n_waves += mine > 0; }
+                            if (n_items * nt * nb > worst) { worst = n_items * nt * nb; waves_on_it = n_waves; }
+                        }
+                        return worst;
+                    };
+                    int nt = 2, nb = 2, best = 1 << 30, best_waves = 0;
+                    for (int cnb = 2; cnb >= 1; --cnb)
+                        for (int cnt = 3; cnt >= 2; --cnt) {
+                            if (T.chain_nt == 2 || T.chain_nt == 3) { if (cnt != T.chain_nt) continue; }
+                            if (T.chain_nb == 1 || T.chain_nb == 2) { if (cnb != T.chain_nb) continue; }
+                            int wv = 0;
+                            const int m = busiest(cnt, cnb, wv);
+                            if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt = cnt; nb = cnb; }
+                        }
+                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, nb};
                 }
                 c->chain_first = first; c->chain_lds = (int)total;
             }
