@@ -330,15 +330,17 @@ typedef struct trs_pilot_tuning {
     int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel */
     int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel when whole input frames fit LDS; 0: span kernel; 2: also in row bands */
     int32_t frame5_bands;        /* 0: automatic; else at least this many row bands */
-    int32_t frame5_f;            /* 0: automatic; else at most this many frames per workgroup */
+    int32_t frame5_f;            /* 0: automatic (one frame per 4-wave workgroup, two workgroups per CU, where 2-3 frames fit a CU); else this many frames per workgroup (as far as they fit) */
     int32_t frame_layers_mask;   /* 0x78: bit i = conv(i+1) (3x3 layers) on trs_conv_frame_kernel where its input fits LDS */
     int32_t frame_bands[4];      /* conv4..conv7: 0 automatic, else at least this many row bands */
+    int32_t frame_ohb[4];        /* conv4..conv7: 0 automatic, else output rows per band (the last band takes what is left) */
     int32_t frame_f;             /* 0: automatic; else frames (units) per workgroup */
     int32_t frame_deep;          /* 0; 1: the deep-ring instantiation (measured slower, kept for A/B) */
     int32_t frame_nt;            /* 0: automatic (2 or 3 tiles of 32 pixels per wave item); 2 or 3 forces it */
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
     int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it (32-pixel tiles per wave item) */
     int32_t chain_nb;            /* 2: 32-channel blocks per wave item; 1; 0: per layer, whichever leaves the busiest SIMD fewer MFMAs (measured: no faster) */
+    int32_t chain_f;             /* 0: automatic (4 frames per workgroup of 8 waves while the grid fills the chip, else 2); 2: two frames per workgroup of 4 waves, two workgroups per CU */
     int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel; 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
     int32_t ksplit;              /* 0: automatic; else K slices of dense1 */
     int32_t min_waves;           /* 7: conv layers on the quad-load kernel keep 64-channel slices while this many waves fit */

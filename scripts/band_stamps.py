@@ -14,6 +14,7 @@ if tune:
     env.pilot_tuning(**{k: int(v) for k, v in tune.items()})
 env.pilot_load(make_weights(H, W, seed=1))
 env.step_synthetic(4, 1)
-for _ in range(3):
+import os
+for _ in range(int(os.environ.get("STAMP_STEPS", "3"))):   # STAMP_STEPS=400: the clocks of a loaded chip (read the last lines)
     env.step_pilot(1)
     env.sync()

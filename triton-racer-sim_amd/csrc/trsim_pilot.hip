@@ -617,7 +617,11 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
     }
     const u4v* lin = reinterpret_cast<const u4v*>(psmem);
     const float4* lbias = reinterpret_cast<const float4*>(psmem + (((size_t)(p.F * upix) << p.cgs) * 16));   // staged behind the activations
-    const int m_wg = nu * uout;                                             // output pixel slots of this workgroup
+    int m_wg = nu * uout;                                                   // output pixel slots of this workgroup
+    if (p.F == 1 && p.bands > 1) {                                          // one unit: a short last band has no tiles for the rows below the frame
+        const int band = u0 % p.bands;
+        m_wg = min(p.ohb, p.OH - band * p.ohb) * p.OW;
+    }
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = p.COUT_PAD / (NB * 32);
     constexpr int ksteps = 9 * HALF;                                        // k-steps (16 input channels of one tap each) of a 3x3 kernel
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
@@ -884,7 +888,7 @@ __device__ __forceinline__ void chain_layer_any(const ChainLayer& L, const u4v* 
     }
 }
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams p)
+__global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainParams p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int nwaves = BLOCK / 64;
@@ -909,6 +913,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     };
 #ifdef TRS_CHAIN_STAMPS   /* diagnostic build: shader clocks of workgroup 7's waves 0 and 7 per stage of the chain */
     unsigned long long cst[12] = {0}, cprev = __builtin_amdgcn_s_memtime(); int cn = 0;
+    const unsigned long long c_t0 = cprev, c_r0 = __builtin_amdgcn_s_memrealtime();   // shader clocks against the 100 MHz counter: the clock the kernel ran at
 #define CHAIN_STAMP() do { if (blockIdx.x == 7 && (tid == 0 || tid == 448)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); cst[cn++] = tn - cprev; cprev = tn; } } while (0)
 #else
 #define CHAIN_STAMP() do { } while (0)
@@ -967,6 +972,10 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_chain_kernel(const ChainParams
     }
 #endif
 #ifdef TRS_CHAIN_STAMPS
+    if (blockIdx.x == 7 && tid == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - c_t0, dr = __builtin_amdgcn_s_memrealtime() - c_r0;
+        printf("chain, workgroup 7: %llu shader clocks in %llu ticks of 10 ns = %.2f GHz\n", dt, dr, dr ? (double)dt / (10.0 * (double)dr) : 0.0);
+    }
     if (blockIdx.x == 7 && (tid == 0 || tid == 448))
         printf("chain, workgroup 7, wave %d [clocks]: stage A %llu | conv4 A work %llu wait %llu | stage B %llu | conv4 B work %llu wait %llu | conv5 work %llu wait %llu | conv6 work %llu wait %llu | conv7 %llu\n",
                wave, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], cst[7], cst[8], cst[9], cst[10]);
@@ -1465,6 +1474,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
 #ifdef TRS_BAND_STAMPS   /* diagnostic build: shader clocks of workgroup 7's wave 0 (a conv2 wave) and wave 8 (a loader), summed over its items */
     unsigned long long bst[6] = {0, 0, 0, 0, 0, 0}, bprev = 0; int bitems = 0;
+    const unsigned long long b_t0 = __builtin_amdgcn_s_memtime(), b_r0 = __builtin_amdgcn_s_memrealtime();
 #define BAND_STAMP(k) do { if (blockIdx.x == 7 && (tid == 0 || tid == 512)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) bst[k] += tn - bprev; bprev = tn; } } while (0)
 #else
 #define BAND_STAMP(k) do { } while (0)
@@ -1565,6 +1575,10 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         wt = nxt;
     }
 #ifdef TRS_BAND_STAMPS
+    if (blockIdx.x == 7 && tid == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - b_t0, dr = __builtin_amdgcn_s_memrealtime() - b_r0;
+        printf("band head, workgroup 7: %llu shader clocks in %llu ticks of 10 ns = %.2f GHz\n", dt, dr, dr ? (double)dt / (10.0 * (double)dr) : 0.0);
+    }
     if (blockIdx.x == 7 && (tid == 0 || tid == 512))
         printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %llu | wait at barrier %llu | phase 2 work %llu | wait at barrier %llu\n", wave, bitems, bst[1], bst[2], bst[3], bst[4]);
 #endif
@@ -1998,7 +2012,7 @@ struct PilotCtx {
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
     bool dense_new = false;               // dense1 (and dense4) on trs_pilot_dense_kernel
-    int chain_first = -1, chain_lds = 0; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
+    int chain_first = -1, chain_lds = 0, chain_block = 512; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
     bool chain_mid_valid = true;          // act[chain_first .. 5] hold the last pass (the chain never writes them; the debug getter runs the single layers on demand)
     u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
     trs_pilot_tuning tun{};               // the kernel choices this context was loaded with (trs_pilot_set_tuning, else the defaults)
@@ -2207,8 +2221,13 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         if (i == c->chain_first) {                                          // conv(i + 1) .. conv7 in one launch, activations in LDS
             ChainParams q = c->chain;
             q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
-            hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
+            if (c->chain_block == 256) {                                     // two workgroups of four waves per CU (their LDS images fit side by side)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
+                hipLaunchKernelGGL(trs_conv_chain_kernel<256>, dim3((n + q.F - 1) / q.F), dim3(256), c->chain_lds, v.stream, q);
+            } else {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
+                hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
+            }
             HIPCHK(hipGetLastError());
             in = c->act[6];
             in_bytes = (size_t)n * c->act_elems[6] * 2;
@@ -2435,7 +2454,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 int bands = 1;
                 while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
                 if (T.frame_bands[i - 3] > 0) bands = std::max(bands, std::min((int)T.frame_bands[i - 3], l.OH));   // tuning (0 = automatic)
-                const int ohb = (l.OH + bands - 1) / bands, ihb = ohb + l.KH - 1;
+                int ohb = (l.OH + bands - 1) / bands;
+                if (T.frame_ohb[i - 3] > 0) { ohb = std::min((int)T.frame_ohb[i - 3], l.OH); bands = (l.OH + ohb - 1) / ohb; }   // tuning: rows per band (the last band takes what is left)
+                const int ihb = ohb + l.KH - 1;
                 const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
                 // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
                 int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
@@ -2458,8 +2479,13 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             const size_t unit = (size_t)ihb * l.IW * 64;
             int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
             if (bands > 1) f = std::min(f, 1);
-            while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
+            // two or three frames per CU: one frame per workgroup of four waves, two workgroups side by side - one stages its frame while the
+            // other computes (round 3: closed loop 192.7 -> 189.3 us on one box, 193.5 -> 193.3 on another; never slower)
             if (T.frame5_f > 0) f = std::max(1, std::min(f, (int)T.frame5_f));
+            else {
+                if (f >= 2 && f <= 3) f = 1;
+                while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
+            }
             // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; TRS_PILOT_FRAME5 = 2 forces bands)
             if (on && (bands == 1 || on >= 2) && shape_ok && f >= 1 && f * unit + 256 <= 158 * 1024) {
                 l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
@@ -2621,6 +2647,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             auto in_bytes_of = [&](int i) { return (size_t)c->L[i].IH * c->L[i].IW * c->L[i].CIN * 2; };
             for (int f = 4; f >= 2 && c->chain_first < 0; f -= 2) {
                 if (f > 2 && (c->n_cap + f - 1) / f < c->cu_count) continue;          // keep a workgroup per CU
+                if (T.chain_f == 2 && f > 2) continue;
                 const bool split = nl == 4;
                 size_t a, b;
                 if (split) { a = std::max(f * out_bytes(3), f * out_bytes(5)); b = std::max((size_t)(f / 2) * in_bytes_of(3), f * out_bytes(4)); }
@@ -2630,6 +2657,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 if (total > 158 * 1024) continue;
                 ChainParams& q = c->chain;
                 q = ChainParams{};
+                // waves per workgroup: 8 (one workgroup per CU), or 4 when two workgroups' LDS images fit a CU side by side (trs_pilot_tuning.chain_f = 2)
+                const int nw = (T.chain_f == 2 && f == 2 && 2 * total <= 158 * 1024) ? 4 : 8;
                 q.F = f; q.nl = nl; q.split_first = split ? 1 : 0; q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
                 for (int j = 0; j < nl; ++j) {
                     const ConvLayer& l = c->L[first + j];
@@ -2642,7 +2671,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         int worst = 0; waves_on_it = 0;
                         for (int sd = 0; sd < 4; ++sd) {
                             int n_items = 0, n_waves = 0;
-                            for (int w = sd; w < 8; w += 4) { const int mine = items > w ? (items - w + 7) / 8 : 0; n_items += mine; n_waves += mine > 0; }
+                            for (int w = sd; w < nw; w += 4) { const int mine = items > w ? (items - w + nw - 1) / nw : 0; n_items += mine; n_waves += mine > 0; }
                             if (n_items * nt * nb > worst) { worst = n_items * nt * nb; waves_on_it = n_waves; }
                         }
                         return worst;
@@ -2658,7 +2687,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         }
                     q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, nb};
                 }
-                c->chain_first = first; c->chain_lds = (int)total;
+                c->chain_first = first; c->chain_lds = (int)total; c->chain_block = nw * 64;
             }
         }
     }

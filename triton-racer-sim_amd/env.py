@@ -404,7 +404,7 @@ class BatchedEnv:
 
     def pilot_tuning(self, **choices):
         """Override kernel choices of the NEXT ``pilot_load`` (``trs_pilot_tuning``, include/trsim.h) — tests that compare a kernel
-        with the one it replaced, and measurements.  No arguments: back to the defaults.  ``frame_bands`` takes 4 ints."""
+        with the one it replaced, and measurements.  No arguments: back to the defaults.  ``frame_bands`` and ``frame_ohb`` take 4 ints."""
         if not choices:
             self.api.check(self.api.pilot_set_tuning(self._h, None), "pilot_set_tuning")
             return
@@ -414,9 +414,9 @@ class BatchedEnv:
         for k, v in choices.items():
             if k not in names:
                 raise ValueError(f"trs_pilot_tuning has no field {k!r}")
-            if k == "frame_bands":
+            if k in ("frame_bands", "frame_ohb"):
                 for i, b in enumerate(v):
-                    t.frame_bands[i] = int(b)
+                    getattr(t, k)[i] = int(b)
             else:
                 setattr(t, k, int(v))
         self.api.check(self.api.pilot_set_tuning(self._h, C.byref(t)), "pilot_set_tuning")
