@@ -336,6 +336,7 @@ typedef struct trs_pilot_tuning {
     int32_t frame_ohb[4];        /* conv4..conv7: 0 automatic, else output rows per band (the last band takes what is left) */
     int32_t frame_f;             /* 0: automatic; else frames (units) per workgroup */
     int32_t frame_deep;          /* 0; 1: the deep-ring instantiation (measured slower, kept for A/B) */
+    int32_t frame_block;         /* 0: 512 threads per workgroup; 256: four waves per workgroup, two workgroups per CU where their LDS images fit side by side */
     int32_t frame_nt;            /* 0: automatic (2 or 3 tiles of 32 pixels per wave item); 2 or 3 forces it */
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
     int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it (32-pixel tiles per wave item) */

@@ -1987,7 +1987,7 @@ struct ConvLayer {
     bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
     bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
-    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
+    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0, frame_block = 512;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
     bool frame5 = false; int frame5_f = 1, frame5_lds = 0, frame5_bands = 1, frame5_ohb = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, input frames in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
@@ -2109,7 +2109,10 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         int nt = busiest(3) <= busiest(2) ? 3 : 2;
         if (T.frame_nt == 2 || T.frame_nt == 3) nt = T.frame_nt;
         if (l.frame_deep) nt = 2;
-        if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(2, 4, 12, 512); else if (nt == 3) LAUNCH_FRAME(3, 4, 4, 512); else LAUNCH_FRAME(2, 4, 4, 512); }
+        if (l.frame_block == 256 && !l.frame_deep) {                       // four waves per workgroup, two workgroups per CU (trs_pilot_tuning.frame_block)
+            if (q.cg == 8) { if (nt == 3) LAUNCH_FRAME(3, 4, 4, 256); else LAUNCH_FRAME(2, 4, 4, 256); }
+            else { if (nt == 3) LAUNCH_FRAME(3, 8, 4, 256); else LAUNCH_FRAME(2, 8, 4, 256); }
+        } else if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(2, 4, 12, 512); else if (nt == 3) LAUNCH_FRAME(3, 4, 4, 512); else LAUNCH_FRAME(2, 4, 4, 512); }
         else { if (l.frame_deep) LAUNCH_FRAME(2, 8, 8, 512); else if (nt == 3) LAUNCH_FRAME(3, 8, 4, 512); else LAUNCH_FRAME(2, 8, 4, 512); }
 #undef LAUNCH_FRAME
         HIPCHK(hipGetLastError());
@@ -2462,6 +2465,11 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
                 if (T.frame_f > 0) f = T.frame_f;
                 while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
+                l.frame_block = 512;
+                if (T.frame_block == 256 && 2 * (unit_bytes + l.COUT_PAD * 4) <= 158 * 1024) {   // two 4-wave workgroups per CU, as many units each as fit side by side
+                    l.frame_block = 256;
+                    f = (int)std::max<size_t>(1, std::min<size_t>(f, (78 * 1024) / unit_bytes));
+                }
                 l.frame_deep = T.frame_deep != 0;
                 l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
                 l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
