@@ -340,7 +340,7 @@ typedef struct trs_pilot_tuning {
     int32_t frame_nt;            /* 0: automatic (2 or 3 tiles of 32 pixels per wave item); 2 or 3 forces it */
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
     int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it (32-pixel tiles per wave item) */
-    int32_t chain_nb;            /* 2: 32-channel blocks per wave item; 1; 0: per layer, whichever leaves the busiest SIMD fewer MFMAs (measured: no faster) */
+    int32_t chain_nb;            /* 2: 64 output channels per wave item (default); 1: 32; 0: 32 only where 64 would leave half of the waves without an item (measured: no faster) */
     int32_t chain_f;             /* 0: automatic (4 frames per workgroup of 8 waves while the grid fills the chip, else 2); 2: two frames per workgroup of 4 waves, two workgroups per CU */
     int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel; 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
     int32_t ksplit;              /* 0: automatic; else K slices of dense1 */

@@ -2684,15 +2684,24 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         }
                         return worst;
                     };
-                    int nt = 2, nb = 2, best = 1 << 30, best_waves = 0;
-                    for (int cnb = 2; cnb >= 1; --cnb)
+                    auto pick = [&](int cnb, int& nt_out, int& items_out) {          // the better tile height for cnb channel blocks
+                        int best = 1 << 30, best_waves = 0;
                         for (int cnt = 3; cnt >= 2; --cnt) {
                             if (T.chain_nt == 2 || T.chain_nt == 3) { if (cnt != T.chain_nt) continue; }
-                            if (T.chain_nb == 1 || T.chain_nb == 2) { if (cnb != T.chain_nb) continue; }
                             int wv = 0;
                             const int m = busiest(cnt, cnb, wv);
-                            if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt = cnt; nb = cnb; }
+                            if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt_out = cnt; }
                         }
+                        items_out = ((px + 32 * nt_out - 1) / (32 * nt_out)) * (l.COUT / (32 * cnb));
+                        return best;
+                    };
+                    int nt = 2, nb = 2, items2 = 0;
+                    const int m2 = pick(2, nt, items2);
+                    if (T.chain_nb == 1) { int it1; pick(1, nt, it1); nb = 1; }
+                    else if (T.chain_nb == 0 && 2 * items2 <= nw) {                  // automatic: 32-channel items where 64-channel items leave half the waves idle
+                        int nt1 = 2, it1 = 0;
+                        if (pick(1, nt1, it1) <= m2) { nt = nt1; nb = 1; }
+                    }
                     q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, nb};
                 }
                 c->chain_first = first; c->chain_lds = (int)total; c->chain_block = nw * 64;
