@@ -336,6 +336,11 @@ def main():
             env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
             env.sync()
         wall_lock = time.perf_counter() - t3
+        env.step_device_wait(one_steer.data_ptr(), one_thr.data_ptr())
+        t3 = time.perf_counter()
+        for _ in range(lock_steps):                                       # ... the same tick through trs_step_wait: one FFI crossing
+            env.step_device_wait(one_steer.data_ptr(), one_thr.data_ptr())
+        wall_lock1 = time.perf_counter() - t3
         # ... and SURVEY 8(f-1): cnn_2d_speed_control inference on the device frame every step, actions fed back (closed loop, launch mode: the
         # pilot's kernels need the CUs' LDS, so the resident worker is asked to leave first)
         pilot_leg = None
@@ -422,8 +427,8 @@ def main():
                                      "note": "trs_step(device controls, n_steps = 1) called once per step: the consumer-paced path (one launch per call, raster waits for that step's physics); device time by HIP events"},
                 "resident_single_step_call": {"env_steps_per_s": rate(ms_res), "frac_of_hbm_peak": frac(ms_res), "us_per_call": round(ms_res * 1e3 / args.steps, 3),
                                               "host_wall_us_per_call": round(wall_res * 1e6 / args.steps, 3),
-                                              "lock_step_us_per_call": round(wall_lock * 1e6 / lock_steps, 3),
-                                              "note": "trs_set_step_mode(TRS_STEP_RESIDENT): the same calls only POST to the resident worker kernel (no launch, no kernel boundary, tables staged once); device time = the worker launch that served all the calls, by HIP events; lock_step = post, wait for the frame, post (host wall clock)"},
+                                              "lock_step_us_per_call": round(wall_lock1 * 1e6 / lock_steps, 3), "lock_step_two_calls_us": round(wall_lock * 1e6 / lock_steps, 3),
+                                              "note": "trs_set_step_mode(TRS_STEP_RESIDENT): the same calls only POST to the resident worker kernel (no launch, no kernel boundary, tables staged once); device time = the worker launch that served all the calls, by HIP events; lock_step = one trs_step_wait per tick: post, wait for the frame (host wall clock; lock_step_two_calls_us: trs_step + trs_sync)"},
                 "sequence_steps_per_launch_8": {"env_steps_per_s": rate(ms_seq), "frac_of_hbm_peak": frac(ms_seq),
                                                 "note": "trs_step_sequence: a different device-resident control set per step (open-loop action sequences), 8 steps per launch"},
                 "steps_per_launch_8": {"env_steps_per_s": rate(ms8), "frac_of_hbm_peak": frac(ms8),

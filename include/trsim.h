@@ -169,6 +169,9 @@ int trs_set_step_mode(trs_env* env, int mode, int idle_us);
  * the CUs the worker occupies (one workgroup slot and most of the LDS on every CU): a collective, a large kernel.  The step mode
  * stays TRS_STEP_RESIDENT. */
 int trs_quiesce(trs_env* env);
+/* trs_step followed by trs_sync in ONE call: the lock-step consumer of core/car.py:45-53 (post the controls, wait for the frame) crosses
+ * the FFI once per tick instead of twice.  Same arguments and errors as trs_step. */
+int trs_step_wait(trs_env* env, const float* d_steering, const float* d_throttle, const float* d_brake_or_null, const uint8_t* d_reset_or_null, int n_steps);
 /* Test hook: a resident worker leaves by itself after life_us microseconds (default 500,000; <= 0 restores it) and the next post
  * starts a new one — tests use a short lifetime to run many worker generations under load.  Needs trs_set_step_mode first. */
 int trs_resident_debug_lifetime(trs_env* env, int life_us);

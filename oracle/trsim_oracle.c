@@ -622,6 +622,7 @@ EXPORT int trso_counters(trs_env* e, uint64_t out[4]) { if (!e || !out) return T
 EXPORT int trso_stream_wait_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }
 EXPORT int trso_stream_signal_external(trs_env* e, void* s) { (void)s; return e ? TRS_OK : TRS_ERR_ARG; }
 /* how steps reach the GPU (include/trsim.h: trs_set_step_mode) changes no result: accepted and ignored here */
+EXPORT int trso_step_wait(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n) { return trso_step(e, st, th, br, rs, n); }   /* synchronous anyway */
 EXPORT int trso_quiesce(trs_env* e) { return e ? TRS_OK : TRS_ERR_ARG; }   /* nothing is ever resident here */
 EXPORT int trso_set_step_mode(trs_env* e, int mode, int idle_us) { (void)idle_us; if (!e) return TRS_ERR_ARG; return (mode == 0 || mode == 1) ? TRS_OK : TRS_ERR_ARG; }
 EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return TRS_OK; }

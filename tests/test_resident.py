@@ -249,3 +249,26 @@ def test_quiesce_keeps_the_mode_and_the_results(make_env):
         g.quiesce()
     assert_state_equal(g, o, "after quiesce calls")
     assert_frames_equal(g, o, "after quiesce calls")
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_step_wait_is_step_then_sync(make_env, resident):
+    """``trs_step_wait`` (the lock-step tick in one FFI crossing): when it returns, the frame and the telemetry of that tick are
+    complete in memory for a consumer on ANOTHER stream — in both step modes, same values as the oracle."""
+    torch = pytest.importorskip("torch")
+    n = 256
+    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g.set_step_mode(resident)
+    rng = np.random.default_rng(5)
+    d_st, d_th, d_br = (torch.zeros(n, device="cuda") for _ in range(3))
+    for k in range(12):
+        st, th, br = controls(rng, n)
+        d_st.copy_(torch.from_numpy(st)); d_th.copy_(torch.from_numpy(th)); d_br.copy_(torch.from_numpy(br))
+        torch.cuda.synchronize()
+        g.step_device_wait(d_st.data_ptr(), d_th.data_ptr(), d_br.data_ptr())
+        o.step(st, th, br)
+        frames = torch.as_tensor(g.device_array("img", sync=False), device="cuda")   # read by torch's stream right away: no trs_sync in between
+        assert np.array_equal(frames.cpu().numpy(), o.fetch("img")), f"tick {k}"
+    assert_state_equal(g, o, "step_wait ticks")
+    with pytest.raises(RuntimeError):
+        g.step_device_wait(0, 0)                                 # trs_step's errors come through

@@ -1945,6 +1945,12 @@ TRS_EXPORT int trs_sync(trs_env* e)
     return sync_all(e);
 }
 
+TRS_EXPORT int trs_step_wait(trs_env* e, const float* d_st, const float* d_th, const float* d_br, const uint8_t* d_rs, int n_steps)
+{
+    const int rc = trs_step(e, d_st, d_th, d_br, d_rs, n_steps);
+    return rc ? rc : trs_sync(e);
+}
+
 TRS_EXPORT int trs_quiesce(trs_env* e)
 {
     if (!e) return fail(TRS_ERR_ARG, "null handle");

@@ -171,6 +171,12 @@ class BatchedEnv:
         self.api.check(self.api.step(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
                                      int(n_steps)), "step")
 
+    def step_device_wait(self, d_steering, d_throttle, d_brake=0, d_reset=0, n_steps=1):
+        """``step_device`` and ``sync`` in one call (``trs_step_wait``): the lock-step tick — post the controls, return when the
+        frame and the telemetry are complete — with one FFI crossing."""
+        self.api.check(self.api.step_wait(self._h, int(d_steering), int(d_throttle), int(d_brake) or None, int(d_reset) or None,
+                                          int(n_steps)), "step_wait")
+
     def step_sequence(self, steering, throttle, brake=None, reset=None, steps_per_launch=8):
         """Open-loop action sequences: ``steering`` / ``throttle`` / ``brake`` are ``[n_steps, n_envs]`` host arrays, one
         control set per step (``trs_step_sequence_host``); the call runs ``steps_per_launch`` steps per kernel launch."""
