@@ -17,6 +17,7 @@ CFGS = {
     "trim + dynamic + masks + Canny": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True, "preprocessing_color_filter_enabled": True,
                                        "preprocessing_edge_detection_enabled": True},
     "trim + dynamic + HSV masks": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True, "preprocessing_color_filter_enabled": True},
+    "trim + HSV masks (no dynamic)": {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_color_filter_enabled": True},
 }
 frame = env.H * env.W * 3
 for name, cfg in CFGS.items():

@@ -315,9 +315,25 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
     }
     int fsel0 = -1, fsel1 = -1, fsel2 = -1;
     for (int f = 0; f < p.n_filters; ++f) { const int dc = p.dst_ch[f]; if (dc == 0) fsel0 = f; else if (dc == 1) fsel1 = f; else if (dc == 2) fsel2 = f; }
+    auto trim_table = [&](float deltaf) {                                   // this frame's trim of every byte value, in numpy's operation order (:92-99)
+        if (tid < 256) {
+            float x = (float)tid;
+            if (p.dynamic) x = x + deltaf;
+            x = x - p.offset;
+            x = x * p.contrast;
+            x = x + p.offset;
+            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+            s_trim[tid] = (unsigned)(int)x;
+        }
+    };
+    // Without dynamic brightness (the reference's default, config.py) nothing depends on the frame's own mean: the table is made once and
+    // the frames stream through one pass, no channel sums and no barrier per frame (round 3).
+    if (!p.dynamic) trim_table(0.0f);
+    __syncthreads();
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        if (p.dynamic) {
         // ---- pass 1: channel sums over the brightness rows ----
         unsigned sr = 0, sg = 0, sb = 0;
         for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += nthreads) {
@@ -343,17 +359,9 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
             s_delta = (float)((p.baseline - cur) / 3);
         }
         __syncthreads();
-        const float deltaf = s_delta, off = p.offset, con = p.contrast;
-        if (tid < 256) {                                                    // this frame's trim of every byte value, in numpy's operation order (:92-99)
-            float x = (float)tid;
-            if (p.dynamic) x = x + deltaf;
-            x = x - off;
-            x = x * con;
-            x = x + off;
-            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
-            s_trim[tid] = (unsigned)(int)x;
-        }
+        trim_table(s_delta);
         __syncthreads();
+        }
         // ---- pass 2: trim, masks, merge ----
         // (p.color is tested once per 4-pixel group, not per pixel: the four pixels' chains of dependent table lookups — trim, OpenCV's
         // reciprocal tables, the range bits — then interleave instead of running one behind the other)
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                              ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
-        __syncthreads();   // s_part / s_delta are reused by the next frame of this workgroup
+        if (p.dynamic) __syncthreads();   // s_part / s_delta / s_trim are rewritten for the next frame of this workgroup
     }
 }
 
