@@ -330,6 +330,7 @@ typedef struct trs_pilot_tuning {
     int32_t fuse_band_r2;        /* 6: conv2 rows per band of the band-form head (trs_conv12_band_kernel); 0: direct form (trs_conv12_kernel) */
     int32_t fuse_r2;             /* 6: conv2 rows per band of the direct form */
     int32_t fuse_wsplit_max;     /* 4: a band may be cut into up to this many parts in width (240x320 needs 2); 1: never */
+    int32_t fuse_roll;           /* 1: with a (frame, part) per CU or more, a workgroup walks a frame's bands top to bottom and computes the 3 conv1 rows two bands share once; 0: never */
     int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel */
     int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel when whole input frames fit LDS; 0: span kernel; 2: also in row bands */
     int32_t frame5_bands;        /* 0: automatic; else at least this many row bands */

@@ -318,6 +318,29 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
         assert np.max(np.abs(fused_out - plain_out)) <= 2e-3
 
 
+@pytest.mark.parametrize("size,n", [((120, 160), 300), ((240, 320), 150), ((130, 300), 131)])
+def test_fused_head_rolling_bands_are_bit_identical_to_one_band_per_item(make_env, size, n):
+    """Round 3: with a (frame, part) stream per CU or more, a workgroup of the band-form head walks a frame's bands top to bottom and keeps
+    the three conv1 rows two neighbouring bands share in a ring (trs_pilot_tuning.fuse_roll, the default) instead of computing them
+    twice.  Same values into the same MFMAs: conv2's activation and the model's outputs must equal the one-band-per-item order bit for
+    bit — whole streams per workgroup and a ragged last round (n not a multiple of the CU count), the width-split form, a narrow last part."""
+    h, w = size
+    ws = make_weights(h, w, seed=5)
+    rng = np.random.default_rng(12)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    oh2, ow2 = ((h - 5) // 2 + 1 - 5) // 2 + 1, ((w - 5) // 2 + 1 - 5) // 2 + 1
+    res = {}
+    for roll in (1, 0):
+        env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_tuning(fuse_roll=roll)
+        env.pilot_load(ws)
+        out = env.pilot_forward_host(frames)
+        res[roll] = (out, env.pilot_layer(1, (n, oh2, ow2, 32)))
+        del env
+    assert np.array_equal(res[1][1], res[0][1])
+    assert np.array_equal(res[1][0], res[0][0])
+
+
 @pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5), ((120, 160), 1)])
 def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution

@@ -1244,6 +1244,7 @@ struct Fuse12Params {
     int tile_bytes;
     int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as fp16 [rows][IW * 3]
     int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
+    int roll;                                               // band kernel: a workgroup walks the bands of a (frame, part) top to bottom and keeps the 3 shared conv1 rows (see the kernel)
     unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
 };
 
@@ -1393,36 +1394,59 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
         if (rm < 0) { --qt; rm += d; } else if (rm >= d) { ++qt; rm -= d; }
     };
-    // item wt = (frame n, band of R2 conv2 rows from y2_0[, part of w2 conv2 columns from x2_0]); w1 = the part's conv1 columns
-    auto geometry = [&](int wt, int& n, int& y2_0, int& r2, int& r1, int& x2_0, int& w2, int& w1) {
-        if constexpr (SPLIT) {
-            const int per = q.bands * q.wsplit;
-            n = wt / per;
-            const int rem = wt - n * per, b = rem / q.wsplit, part = rem - b * q.wsplit;
-            y2_0 = b * q.R2; x2_0 = part * q.w2p; w2 = min(q.w2p, q.OW2 - x2_0); w1 = 2 * w2 + 3;
+    // The workgroup's item `it` = (frame n, band of R2 conv2 rows from y2_0[, part of w2 conv2 columns from x2_0]); w1 = the part's conv1 columns.
+    // Two orders (q.roll, chosen by the host):
+    //   flat     item blockIdx.x + it * gridDim.x of all (frame, band, part) triples - neighbouring bands go to different workgroups, every band
+    //            computes all 2 r2 + 3 conv1 rows under it (3 of them a second time);
+    //   rolling  (round 3) the workgroup takes whole (frame, part) streams and walks their bands top to bottom: the conv1 tile is a ring of
+    //            NR = 2 R2 + 3 rows (conv1 row y lives in slot y mod NR), the last 3 rows of the previous band are still in it, so a band after
+    //            the first computes only its 2 r2 NEW rows (`skip` = 3) from a band image that starts 6 frame rows lower: a fifth less conv1
+    //            arithmetic, unpacking and LDS traffic, and 30 instead of 37 conv1 tiles per band at 120x160 (two rounds of the 16 waves, not
+    //            three).  Same values into the same MFMAs: bit-identical to the flat order.
+    const int NR = 2 * q.R2 + 3;
+    auto geometry = [&](int it, int& n, int& y2_0, int& r2, int& r1, int& x2_0, int& w2, int& w1, int& skip) {
+        int b, part = 0;
+        if (q.roll) {
+            const int sidx = it / q.bands;
+            b = it - sidx * q.bands;
+            const int stream = (int)blockIdx.x + sidx * (int)gridDim.x;
+            if constexpr (SPLIT) { n = stream / q.wsplit; part = stream - n * q.wsplit; } else n = stream;
+            skip = b > 0 ? 3 : 0;
         } else {
-            n = wt / q.bands;
-            const int b = wt - n * q.bands;
-            y2_0 = b * q.R2; x2_0 = 0; w2 = q.OW2; w1 = q.OW1;
+            const int wt = (int)blockIdx.x + it * (int)gridDim.x;
+            if constexpr (SPLIT) {
+                const int per = q.bands * q.wsplit;
+                n = wt / per;
+                const int rem = wt - n * per;
+                b = rem / q.wsplit; part = rem - b * q.wsplit;
+            } else {
+                n = wt / q.bands;
+                b = wt - n * q.bands;
+            }
+            skip = 0;
         }
+        y2_0 = b * q.R2;
+        if constexpr (SPLIT) { x2_0 = part * q.w2p; w2 = min(q.w2p, q.OW2 - x2_0); w1 = 2 * w2 + 3; }
+        else { x2_0 = 0; w2 = q.OW2; w1 = q.OW1; }
         r2 = min(q.R2, q.OH2 - y2_0); r1 = 2 * (r2 - 1) + 5;
     };
     // the band of item wt: frame rows 4 y2_0 .. + 2 r1 + 2 — whole rows are contiguous in the frame; a part takes 16 cpr bytes of each
     // row from column 4 x2_0 on (what it reads past its own 2 w1 + 3 pixels is never used)
     // A loader thread moves HALF chunks (8 frame bytes -> 16 bytes of the image): consecutive lanes then write consecutive 16-byte
     // slots (whole chunks per lane put the two ds_write_b128 of a lane 32 bytes apart: a 2-way bank conflict on every write)
-    auto request = [&](int wt, uint2 (&raw)[2 * kBandPf]) {
-        int n, y2_0, r2, r1, x2_0, w2, w1;
-        geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
+    auto request = [&](int it, uint2 (&raw)[2 * kBandPf]) {
+        int n, y2_0, r2, r1, x2_0, w2, w1, skip;
+        geometry(it, n, y2_0, r2, r1, x2_0, w2, w1, skip);
+        const int row0 = 4 * y2_0 + 2 * skip, rows = 2 * (r1 - skip) + 3;   // the frame rows under the conv1 rows this item computes
         if constexpr (SPLIT) {
-            const int start = ((n * q.IH + 4 * y2_0) * q.IW + 4 * x2_0) * 3, nchunk = (2 * r1 + 3) * q.cpr;
+            const int start = ((n * q.IH + row0) * q.IW + 4 * x2_0) * 3, nchunk = rows * q.cpr;
 #pragma unroll
             for (int j = 0; j < 2 * kBandPf; ++j) {
                 const int hc = (tid - 512) + j * 512, c = hc >> 1, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
                 raw[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rin, c < nchunk ? start + row * row_in + 16 * kk + 8 * (hc & 1) : q.frames_bytes, 0, 0));   // past the end: zeros
             }
         } else {
-            const int start = (n * q.IH + 4 * y2_0) * row_in, nchunk = ((2 * r1 + 3) * row_in) >> 4;
+            const int start = (n * q.IH + row0) * row_in, nchunk = (rows * row_in) >> 4;
 #pragma unroll
             for (int j = 0; j < 2 * kBandPf; ++j) {
                 const int hc = (tid - 512) + j * 512;
@@ -1445,17 +1469,19 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 
     // Waves 8..15 are the loaders: they have no conv2 tiles (and so no stores in their memory queue to wait behind), request a
     // band a whole item ahead and unpack it while waves 0..7 run conv2.
-    const int total = q.N * q.bands * (SPLIT ? q.wsplit : 1);
+    const int n_streams = q.N * (SPLIT ? q.wsplit : 1), n_flat = n_streams * q.bands;
+    const int mine = q.roll ? n_streams : n_flat;                           // what the workgroups share out: streams of bands, or single items
+    const int total = ((int)blockIdx.x < mine ? (mine - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0) * (q.roll ? q.bands : 1);   // this workgroup's items
     const bool loader = wave >= 8;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);                // tile indices in scalar registers
     const unsigned magic1 = (unsigned)((0x100000000ull + (unsigned)q.OW1 - 1u) / (unsigned)q.OW1);   // floor(p / OW1) = umulhi(p, magic1) for p < 65536
-    int wt = blockIdx.x;
+    int wt = 0;                                                             // this workgroup's item counter
     uint2 raw[2 * kBandPf];
     if (loader && wt < total) request(wt, raw);
     __syncthreads();                                                        // weights staged, tile and band zeroed
     if (loader && wt < total) {
         unpack(raw);
-        if (wt + (int)gridDim.x < total) request(wt + gridDim.x, raw);      // the second item's band is on its way
+        if (wt + 1 < total) request(wt + 1, raw);                           // the second item's band is on its way
     }
     __syncthreads();
     // conv1's weights are the same for every tile of every band: this lane's five granules stay in registers (they were 6 of the
@@ -1475,18 +1501,19 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 #ifdef TRS_BAND_STAMPS   /* diagnostic build: shader clocks of workgroup 7's wave 0 (a conv2 wave) and wave 8 (a loader), summed over its items */
     unsigned long long bst[6] = {0, 0, 0, 0, 0, 0}, bprev = 0; int bitems = 0;
     const unsigned long long b_t0 = __builtin_amdgcn_s_memtime(), b_r0 = __builtin_amdgcn_s_memrealtime();
-#define BAND_STAMP(k) do { if (blockIdx.x == 7 && (tid == 0 || tid == 512)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) bst[k] += tn - bprev; bprev = tn; } } while (0)
+#define BAND_STAMP(k) do { if (blockIdx.x == 7 && lane == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) bst[k] += tn - bprev; bprev = tn; } } while (0)
 #else
 #define BAND_STAMP(k) do { } while (0)
 #endif
     while (wt < total) {
         BAND_STAMP(0);
-        const int nxt = wt + gridDim.x;                                     // uniform per workgroup
-        int n, y2_0, r2, r1, x2_0, w2, w1;
-        geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1);
+        const int nxt = wt + 1;                                             // uniform per workgroup
+        int n, y2_0, r2, r1, x2_0, w2, w1, skip;
+        geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1, skip);
         const unsigned magic = SPLIT ? (w2 == q.w2p ? q.magic_full : q.magic_last) : magic1;
-        // ---- phase 1: conv1 rows of the band, from the fp16 image ----
-        const int npx1 = r1 * w1, ntile1 = (npx1 + 31) >> 5;
+        const int s0 = q.roll ? (2 * y2_0) % NR : 0;                        // ring slot of the band's first conv1 row
+        // ---- phase 1: the band's conv1 rows that are not in the tile yet (all of them, or all but the first 3), from the fp16 image ----
+        const int rows1 = r1 - skip, npx1 = rows1 * w1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1
         for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
             // the tile's first pixel splits into (row, column) on the scalar unit; a lane adds its r (OW1 >= 32: one wrap at most);
@@ -1494,7 +1521,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             const int p0 = t1 * 32, yl0 = (int)__umulhi((unsigned)p0, magic), x0 = p0 - yl0 * w1;
             int x = x0 + r, yl = yl0;
             if (x >= w1) { x -= w1; ++yl; }
-            if (p0 + r >= npx1) { yl = r1 - 1; x = w1 - 1; }
+            if (p0 + r >= npx1) { yl = rows1 - 1; x = w1 - 1; }
             const unsigned char* wbase = band + ((size_t)(2 * yl) * bpitch + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
             f32x16 acc;
 #pragma unroll
@@ -1513,7 +1540,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
                 // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
                 // its selects cost more than the conflict; the same swap instead of ds_bpermute_b32 in the frame kernels' epilogues: no change)
-                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)yl * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
+                int slot1 = s0 + skip + yl;                                  // (yl counts the rows computed here; < 2 NR)
+                slot1 = slot1 >= NR ? slot1 - NR : slot1;
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)slot1 * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = bb1[qd];
@@ -1529,7 +1558,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         if (loader) {
             if (nxt < total) {
                 unpack(raw);                                                // the next item's band (requested an item ago)
-                if (nxt + (int)gridDim.x < total) request(nxt + gridDim.x, raw);
+                if (nxt + 1 < total) request(nxt + 1, raw);
             }
         } else {
             // ---- phase 2: conv2 rows from the tile (waves 0..7: at most a handful of tiles per band) ----
@@ -1545,12 +1574,15 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 const int mm = min(t2 * 32 + r, npx2 - 1);
                 int yl2, x2;
                 divmod(mm, w2, inv_w2, yl2, x2);
-                const unsigned char* abase = tile1 + (size_t)(2 * yl2) * tile_pitch + (size_t)x2 * 48;   // even plane, conv1 row 2 yl2, pixel x2
+                const unsigned char* abase = tile1 + (size_t)x2 * 48;        // even plane, pixel x2; the row: ring slot of conv1 row 2 yl2 + kh
+                const int trow = s0 + 2 * yl2;
                 f32x16 acc2[1];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
                 for (int kh = 0; kh < 5; ++kh) {
-                    const unsigned char* arow = abase + (size_t)kh * tile_pitch;
+                    int tr = trow + kh;
+                    tr = tr >= NR ? tr - NR : tr;
+                    const unsigned char* arow = abase + (size_t)tr * tile_pitch;
 #pragma unroll
                     for (int t = 0; t < 16; t += 2) {
                         // slot t + h of the window: 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero weights: the odd run's next 16 bytes)
@@ -1579,7 +1611,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - b_t0, dr = __builtin_amdgcn_s_memrealtime() - b_r0;
         printf("band head, workgroup 7: %llu shader clocks in %llu ticks of 10 ns = %.2f GHz\n", dt, dr, dr ? (double)dt / (10.0 * (double)dr) : 0.0);
     }
-    if (blockIdx.x == 7 && (tid == 0 || tid == 512))
+    if (blockIdx.x == 7 && lane == 0)
         printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %llu | wait at barrier %llu | phase 2 work %llu | wait at barrier %llu\n", wave, bitems, bst[1], bst[2], bst[3], bst[4]);
 #endif
 }
@@ -2201,7 +2233,10 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         q.frames = d_frames; q.frames_bytes = (int)in_bytes; q.N = n;
         q.c2.out = c->act[1]; q.c2.M = n * c->L[1].OH * c->L[1].OW;
         q.c2.nt_out = 0;
-        const int grid = std::max(1, std::min(n * q.bands * std::max(1, q.wsplit), c->cu_count));
+        int grid = std::max(1, std::min(n * q.bands * std::max(1, q.wsplit), c->cu_count));
+        // rolling bands when there are enough (frame, part) streams for every CU (a small batch keeps one band per workgroup: more parallelism)
+        q.roll = (c->fuse_band && c->tun.fuse_roll && n * std::max(1, q.wsplit) >= c->cu_count && q.bands > 1) ? 1 : 0;
+        if (q.roll) grid = std::min(n * std::max(1, q.wsplit), c->cu_count);
         if (c->fuse_band) {
             if (q.wsplit > 1) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
@@ -2355,7 +2390,7 @@ TRS_EXPORT void trs_default_pilot_tuning(trs_pilot_tuning* t)
     std::memset(t, 0, sizeof *t);
     t->struct_size = (uint32_t)sizeof *t;
     t->fuse_band_r2 = 6; t->fuse_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
-    t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->chain_nb = 2; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
+    t->fuse_roll = 1; t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->chain_nb = 2; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
 }
 
 TRS_EXPORT int trs_pilot_set_tuning(trs_env* e, const trs_pilot_tuning* t)
