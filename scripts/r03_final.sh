@@ -27,7 +27,7 @@ PL_TAG=r03fb bash scripts/pilot_layers.sh --envs-per-gpu 512 --img-h 240 --img-w
 } > $O/r03f_pilot_layers.txt 2>&1
 { PL_TAG=r03fa bash scripts/pilot_pmc.sh; PL_TAG=r03fb PL_ENVS=512 bash scripts/pilot_pmc.sh --img-h 240 --img-w 320 --depth; } > $O/r03f_pilot_pmc.txt 2>&1
 python scripts/pilot_precision.py > $O/r03f_pilot_precision.txt 2>&1
-{ TRS_HIP_LIB=$PWD/scripts/ab_bin/libtrsim_bstamps.so python scripts/band_stamps.py 1024 120 160; TRS_HIP_LIB=$PWD/scripts/ab_bin/libtrsim_bstamps.so python scripts/band_stamps.py 512 240 320; } > $O/r03f_band_stamps.txt 2>&1
+{ STAMP_STEPS=40 TRS_HIP_LIB=$PWD/scripts/ab_bin/libtrsim_bstamps.so python scripts/band_stamps.py 1024 120 160 | tail -17; STAMP_STEPS=40 TRS_HIP_LIB=$PWD/scripts/ab_bin/libtrsim_bstamps.so python scripts/band_stamps.py 512 240 320 | tail -17; STAMP_STEPS=40 TRS_HIP_LIB=$PWD/scripts/ab_bin/libtrsim_cstamps.so python scripts/band_stamps.py 1024 120 160 | tail -10; } > $O/r03f_band_stamps.txt 2>&1
 echo "[image path]"; date
 {
 python scripts/preprocess_bench.py 1024 120 160
