@@ -1522,14 +1522,16 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             int x = x0 + r, yl = yl0;
             if (x >= w1) { x -= w1; ++yl; }
             if (p0 + r >= npx1) { yl = rows1 - 1; x = w1 - 1; }
-            const unsigned char* wbase = band + ((size_t)(2 * yl) * bpitch + (size_t)x * 6 + 8 * h) * 2;   // kernel row 0 of this lane's window, half h
+            // (24-bit multiplies: full rate - every factor here is far below 2^23; the 32-bit v_mul_lo_u32 the plain products compile to is quarter rate,
+            // and this phase is bound by its ~70 vector instructions per tile, not by its 5 MFMAs)
+            const unsigned char* wbase = band + (unsigned)(__mul24(2 * yl, bpitch) + __mul24(x, 6) + 8 * h) * 2u;   // kernel row 0 of this lane's window, half h
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
             u4v xv[5];                                                      // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
 #pragma unroll
             for (int s6 = 0; s6 < 5; ++s6) {
-                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (size_t)s6 * bpitch * 2);
+                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (unsigned)(s6 * bpitch * 2));
                 xv[s6] = u4v{src[0], src[1], src[2], src[3]};
             }
             __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
@@ -1542,7 +1544,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 // its selects cost more than the conflict; the same swap instead of ds_bpermute_b32 in the frame kernels' epilogues: no change)
                 int slot1 = s0 + skip + yl;                                  // (yl counts the rows computed here; < 2 NR)
                 slot1 = slot1 >= NR ? slot1 - NR : slot1;
-                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)slot1 * tile_pitch + (size_t)(x & 1) * plane_bytes + (size_t)(x >> 1) * 48);
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + (unsigned)(__mul24(slot1, tile_pitch) + ((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)));
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const float4 bb = bb1[qd];
