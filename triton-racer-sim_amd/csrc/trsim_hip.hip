@@ -527,6 +527,26 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
 #define EDGE_STAMP(k) do { } while (0)
 #endif
     u3v R[kEdgeGpt];                                                          // this thread's groups of the frame (see below)
+    const int chunk_groups0 = kEdgeBlock * kEdgeGpt;
+    auto chunk_sums = [&](const u3v (&R)[kEdgeGpt], int c, unsigned& sr, unsigned& sg, unsigned& sb) {   // this thread's groups of chunk c inside the brightness rows
+        const int t = fresh(tid);
+#pragma unroll
+        for (int k = 0; k < kEdgeGpt; ++k) {
+            const int g = c * chunk_groups0 + k * kEdgeBlock + t;
+            if (g >= p.r0 * p.gpr && g < p.r1 * p.gpr) {
+                const u3v w = R[k];
+                sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
+                sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
+                sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+            }
+        }
+    };
+    auto publish_sums = [&](unsigned sr, unsigned sg, unsigned sb) {           // wave totals -> s_part (read by the delta phase behind a barrier)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
+        if (lane == 0) { s_part[wave * 3] = sr; s_part[wave * 3 + 1] = sg; s_part[wave * 3 + 2] = sb; }
+    };
+    bool sums_ready = false;                                                  // uniform: s_part already holds this frame's sums
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         EDGE_STAMP(0);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
@@ -553,24 +573,17 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         };
         if (!(one_chunk && img != (int)blockIdx.x)) fetch(rs, 0, R);        // (one-chunk frames after the first: prefetched during the previous frame)
         // ---- channel sums over the brightness rows -> delta (as trs_preprocess_kernel) ----
-        unsigned sr = 0, sg = 0, sb = 0;
-        for (int c = 0, t = fresh(tid); c < nchunks; ++c) {
-            if (c > 0) fetch(rs, c, R);
-#pragma unroll
-            for (int k = 0; k < kEdgeGpt; ++k) {
-                const int g = c * chunk_groups + k * kEdgeBlock + t;
-                if (g >= p.r0 * p.gpr && g < p.r1 * p.gpr) {
-                    const u3v w = R[k];
-                    sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
-                    sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
-                    sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
-                }
+        // (one-chunk frames after the first: the sums were taken from the prefetched registers in the middle of the previous frame, see below -
+        // this phase and its barrier were 12 % of the kernel, most of it waves waiting for each other right after the previous frame's last phase)
+        if (!sums_ready) {
+            unsigned sr = 0, sg = 0, sb = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                if (c > 0) fetch(rs, c, R);
+                chunk_sums(R, c, sr, sg, sb);
             }
+            publish_sums(sr, sg, sb);
+            __syncthreads();
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-        if (lane == 0) { s_part[wave * 3] = sr; s_part[wave * 3 + 1] = sg; s_part[wave * 3 + 2] = sb; }
-        __syncthreads();
         EDGE_STAMP(1);
         // every wave of the table's 256 threads adds the 16 partial sums itself (lanes 0..15 one wave's three sums each, 4 shuffle steps:
         // exact integers, any order) and evaluates the same binary64 expression: no serial pass by one thread, no barrier for the delta
@@ -654,6 +667,15 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         }
         __syncthreads();
         EDGE_STAMP(4);
+        // the NEXT frame's channel sums, from the registers its groups were prefetched into in front of the Sobel phase (they have arrived;
+        // s_part is not read again in this frame): the next frame starts with its delta, no sums phase and no barrier for it
+        sums_ready = false;
+        if (one_chunk && img + (int)gridDim.x < p.n_img) {
+            unsigned sr = 0, sg = 0, sb = 0;
+            chunk_sums(R, 0, sr, sg, sb);
+            publish_sums(sr, sg, sb);
+            sums_ready = true;
+        }
         // ---- non-maximum suppression + double threshold: map <- 0 = weak / 1 = no / 2 = edge ----
         // Branch-free, two pixels per instruction (hipcc turned the per-pixel choice of neighbours into divergent branches with LDS reads
         // inside them: 133 instructions per pixel).  A comparison a < b of two magnitudes (0 .. 2040) is the sign bit of the 16-bit
