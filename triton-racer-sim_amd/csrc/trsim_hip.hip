@@ -289,6 +289,44 @@ struct PreParams {
     size_t scratch_stride;
 };
 
+// The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).
+// P = the TRIMMED pixel, bytes (r, g, b, x).  rngb[c * 256 + x] (built per launch by range_byte_table) has byte ch = 0xFF when value x of
+// component c (h, s, v) lies inside the range of the filter whose mask goes to channel ch, so the AND of three lookups is the pixel's masks in
+// place; sel has 0xFF in the channels that carry a mask (a later filter on the same channel replaces an earlier one, :57-63), the others keep the
+// trimmed value.  (Round 3: one table lookup chain and one v_bfi per pixel instead of a bit test, a compare and a select per channel.)
+__device__ __forceinline__ unsigned mask_pixel(unsigned P, const int* tab, const unsigned* rngb, unsigned sel)
+{
+    const int r = (int)(P & 255u), g = (int)((P >> 8) & 255u), b = (int)((P >> 16) & 255u);
+    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+    const int sat = (__mul24(diff, tab[v]) + (1 << 11)) >> 12;             // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
+    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    h = (__mul24(h, tab[256 + diff]) + (1 << 11)) >> 12;
+    h = h < 0 ? h + 180 : h;
+    const unsigned m = rngb[min(h, 255)] & rngb[256 + min(sat, 255)] & rngb[512 + v];
+    return (m & sel) | (P & ~sel);
+}
+// entry i = c * 256 + x of the table above; *sel_out = the channels that carry a mask
+__device__ __forceinline__ unsigned range_byte_entry(const unsigned (&lo)[4], const unsigned (&hi)[4], const int (&dst_ch)[4], int n_filters, int i, unsigned* sel_out)
+{
+    const int c = i >> 8, x = i & 255;
+    int fsel[3] = {-1, -1, -1};
+    for (int f = 0; f < n_filters; ++f) { const int dc = dst_ch[f]; if (dc >= 0 && dc <= 2) fsel[dc] = f; }
+    unsigned word = 0, sel = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        if (fsel[ch] < 0) continue;
+        const int l = (int)((lo[fsel[ch]] >> (8 * c)) & 255u), u = (int)((hi[fsel[ch]] >> (8 * c)) & 255u);
+        sel |= 0xFFu << (8 * ch);
+        if (x >= l && x <= u) word |= 0xFFu << (8 * ch);
+    }
+    if (sel_out) *sel_out = sel;
+    return word;
+}
+// four pixels (r, g, b, x) -> the 12 bytes of their group (the rasteriser's byte shuffles)
+__device__ __forceinline__ u3v pack_rgb4(unsigned P0, unsigned P1, unsigned P2, unsigned P3)
+{
+    return u3v{__builtin_amdgcn_perm(P1, P0, 0x04020100u), __builtin_amdgcn_perm(P2, P1, 0x05040201u), __builtin_amdgcn_perm(P3, P2, 0x06050402u)};
+}
+
 __device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
 
 __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)   // 256 threads per frame at 120x160, 1024 for frames of 8,192+ pixel groups
@@ -298,23 +336,15 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
     __shared__ float s_delta;
     // per-value tables replace per-pixel arithmetic (the masks variant was VALU bound at ~80 integer ops per pixel):
     // s_trim[x] = the trim of byte value x for this frame's delta; s_rng[c][x] = bit f set when value x of component c
-    // (h, s, v) lies inside filter f's range -> one AND of three lookups answers all (<= 4) in-range tests of a pixel
+    // (h, s, v) lies inside the range of the filter that owns channel f's mask, as a BYTE mask -> the AND of three lookups is a pixel's masks (mask_pixel)
     __shared__ unsigned s_trim[256];
     __shared__ unsigned s_rng[3][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const size_t frame_bytes = (size_t)p.gpe * 12;
     for (int i = tid; i < 512; i += nthreads) s_tab[i] = p.hsv_tab[i];
-    for (int i = tid; i < 768; i += nthreads) {
-        const int c = i >> 8, x = i & 255;
-        unsigned bits = 0;
-        for (int f = 0; f < p.n_filters; ++f) {
-            const int lo = (p.lo[f] >> (8 * c)) & 255, hi = (p.hi[f] >> (8 * c)) & 255;
-            bits |= (x >= lo && x <= hi) ? 1u << f : 0u;
-        }
-        s_rng[c][x] = bits;
-    }
-    int fsel0 = -1, fsel1 = -1, fsel2 = -1;
-    for (int f = 0; f < p.n_filters; ++f) { const int dc = p.dst_ch[f]; if (dc == 0) fsel0 = f; else if (dc == 1) fsel1 = f; else if (dc == 2) fsel2 = f; }
+    unsigned sel = 0;                                                       // the channels that carry a mask
+    for (int i = tid; i < 768; i += nthreads) (&s_rng[0][0])[i] = range_byte_entry(p.lo, p.hi, p.dst_ch, p.n_filters, i, nullptr);
+    (void)range_byte_entry(p.lo, p.hi, p.dst_ch, p.n_filters, 0, &sel);
     auto trim_table = [&](float deltaf) {                                   // this frame's trim of every byte value, in numpy's operation order (:92-99)
         if (tid < 256) {
             float x = (float)tid;
@@ -367,33 +397,17 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         // reciprocal tables, the range bits — then interleave instead of running one behind the other)
         for (int g = tid; g < p.gpe; g += nthreads) {
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
-            unsigned ob[12];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { ob[k] = s_trim[(w.x >> (8 * k)) & 255u]; ob[4 + k] = s_trim[(w.y >> (8 * k)) & 255u]; ob[8 + k] = s_trim[(w.z >> (8 * k)) & 255u]; }
+            // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3 -> four trimmed pixels (r, g, b, 0)
+            auto tr = [&](unsigned word, int k) -> unsigned { return s_trim[(word >> (8 * k)) & 255u]; };
+            unsigned P0 = tr(w.x, 0) | (tr(w.x, 1) << 8) | (tr(w.x, 2) << 16);
+            unsigned P1 = tr(w.x, 3) | (tr(w.y, 0) << 8) | (tr(w.y, 1) << 16);
+            unsigned P2 = tr(w.y, 2) | (tr(w.y, 3) << 8) | (tr(w.z, 0) << 16);
+            unsigned P3 = tr(w.z, 1) | (tr(w.z, 2) << 8) | (tr(w.z, 3) << 16);
             if (p.color) {
-                unsigned inr[4];
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    const int r = (int)ob[3 * px], gg = (int)ob[3 * px + 1], b = (int)ob[3 * px + 2];
-                    const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
-                    const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
-                    const int sat = (__mul24(diff, s_tab[v]) + (1 << 11)) >> 12;       // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
-                    int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
-                    h = (__mul24(h, s_tab[256 + diff]) + (1 << 11)) >> 12;
-                    if (h < 0) h += 180;
-                    const int hh = min(h, 255), ss = min(sat, 255);
-                    inr[px] = s_rng[0][hh] & s_rng[1][ss] & s_rng[2][v];
-                }
-                // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it (fsel, -1 = none)
-#pragma unroll
-                for (int px = 0; px < 4; ++px) {
-                    if (fsel0 >= 0) ob[3 * px] = (inr[px] >> fsel0) & 1u ? 255u : 0u;
-                    if (fsel1 >= 0) ob[3 * px + 1] = (inr[px] >> fsel1) & 1u ? 255u : 0u;
-                    if (fsel2 >= 0) ob[3 * px + 2] = (inr[px] >> fsel2) & 1u ? 255u : 0u;
-                }
+                P0 = mask_pixel(P0, s_tab, &s_rng[0][0], sel); P1 = mask_pixel(P1, s_tab, &s_rng[0][0], sel);
+                P2 = mask_pixel(P2, s_tab, &s_rng[0][0], sel); P3 = mask_pixel(P3, s_tab, &s_rng[0][0], sel);
             }
-            const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
-                             ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
+            const u3v out = pack_rgb4(P0, P1, P2, P3);
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
         if (p.dynamic) __syncthreads();   // s_part / s_delta / s_trim are rewritten for the next frame of this workgroup
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [kEdgeBlock / 64][3]
     float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
     unsigned* const s_trim = reinterpret_cast<unsigned*>(s_delta + 4);        // [256] this frame's trim of every byte value
-    unsigned* const s_rng = s_trim + 256;                                    // [3][256] bit f: value x of component c (h, s, v) lies inside filter f's range
+    unsigned* const s_rng = s_trim + 256;                                    // [3][256] byte ch = 0xFF: value x of component c (h, s, v) lies inside the range of the filter that owns channel ch's mask (mask_pixel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Every phase takes its thread index through `fresh`: an empty asm the compiler cannot see through, so that what a phase derives from
     // the index (row / column splits, addresses) is computed where it is used.  Left alone, hipcc hoisted those values of ALL phases in
@@ -507,17 +521,9 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     const int H = p.H, W = p.W, MP = W + 8, npx = H * W;
     const size_t frame_bytes = (size_t)p.gpe * 12;
     for (int i = tid; i < 512; i += kEdgeBlock) s_tab[i] = p.hsv_tab[i];
-    for (int i = tid; i < 768; i += kEdgeBlock) {
-        const int c = i >> 8, x = i & 255;
-        unsigned bits = 0;
-        for (int f = 0; f < p.n_filters; ++f) {
-            const int lo = (p.lo[f] >> (8 * c)) & 255, hi = (p.hi[f] >> (8 * c)) & 255;
-            bits |= (x >= lo && x <= hi) ? 1u << f : 0u;
-        }
-        s_rng[i] = bits;
-    }
-    int fsel0 = -1, fsel1 = -1, fsel2 = -1;                                  // later filters overwrite earlier ones (:57-63): a channel shows the LAST filter that targets it
-    for (int f = 0; f < p.n_filters; ++f) { const int dc = p.dst_ch[f]; if (dc == 0) fsel0 = f; else if (dc == 1) fsel1 = f; else if (dc == 2) fsel2 = f; }
+    unsigned sel = 0;                                                        // the channels that carry a mask (a later filter on a channel replaces an earlier one, :57-63)
+    for (int i = tid; i < 768; i += kEdgeBlock) s_rng[i] = range_byte_entry(p.lo, p.hi, p.dst_ch, p.n_filters, i, nullptr);
+    (void)range_byte_entry(p.lo, p.hi, p.dst_ch, p.n_filters, 0, &sel);
     // Sobel work items: (4-pixel column group, chunk of rows); the whole block works at once when the frame has <= 1024 / gpr chunks
     const int nchunk = max(1, kEdgeBlock / p.gpr), rows_per = (H + nchunk - 1) / nchunk;
 #ifdef TRS_EDGE_STAMPS   /* diagnostic build: shader clocks per phase of workgroup 7, summed over its frames, printed at the end */
@@ -763,42 +769,23 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         // interleave instead of running one after the other)
         for (int g = fresh(tid); g < (TRS_EDGE_ABLATE == 4 ? 0 : p.gpe); g += kEdgeBlock) {
             const unsigned* sw = reinterpret_cast<const unsigned*>(simg + (size_t)g * 12);
-            const unsigned w3[3] = {sw[0], sw[1], sw[2]};
+            const unsigned w0 = sw[0], w1 = sw[1], w2 = sw[2];              // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3, trimmed
             const unsigned e4 = *reinterpret_cast<const unsigned*>(map + (size_t)g * 4);
-            auto byte_of = [&](int bi) -> unsigned { return (w3[bi >> 2] >> (8 * (bi & 3))) & 255u; };
-            unsigned ob[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) ob[k] = byte_of(k);
+            unsigned P[4] = {w0, __builtin_amdgcn_alignbyte(w1, w0, 3), __builtin_amdgcn_alignbyte(w2, w1, 2), w2 >> 8};   // pixels as (r, g, b, x)
             if (p.color) {
-                unsigned inr[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) P[q] = mask_pixel(P[q], s_tab, s_rng, sel);
+            }
+            if (p.edge_ch >= 0 && p.edge_ch <= 2) {                          // the edge layer last (:43-53): 255 where the map says edge (2), else 0
+                const unsigned e1 = (e4 >> 1) & 0x01010101u, evb = (e1 << 8) - e1;   // per pixel byte: 0xFF / 0x00
+                const unsigned em = 0xFFu << (8 * p.edge_ch);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int r = (int)ob[3 * q], gg = (int)ob[3 * q + 1], b = (int)ob[3 * q + 2];
-                    const int v = max(r, max(gg, b)), vmin = min(r, min(gg, b)), diff = v - vmin;
-                    const int vr = (v == r) ? -1 : 0, vg = (v == gg) ? -1 : 0;
-                    const int sat = (__mul24(diff, s_tab[v]) + (1 << 11)) >> 12;       // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
-                    int h = (vr & (gg - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - gg + 4 * diff))));
-                    h = (__mul24(h, s_tab[256 + diff]) + (1 << 11)) >> 12;
-                    if (h < 0) h += 180;
-                    const int hh = min(h, 255), ss = min(sat, 255);
-                    inr[q] = s_rng[hh] & s_rng[256 + ss] & s_rng[512 + v];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (fsel0 >= 0) ob[3 * q] = (inr[q] >> fsel0) & 1u ? 255u : 0u;
-                    if (fsel1 >= 0) ob[3 * q + 1] = (inr[q] >> fsel1) & 1u ? 255u : 0u;
-                    if (fsel2 >= 0) ob[3 * q + 2] = (inr[q] >> fsel2) & 1u ? 255u : 0u;
+                    const unsigned ev = (unsigned)__builtin_amdgcn_sbfe((int)evb, 8 * q, 8);   // all ones / zero
+                    P[q] = (ev & em) | (P[q] & ~em);
                 }
             }
-            if (p.edge_ch >= 0 && p.edge_ch <= 2) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned ev = ((e4 >> (8 * q)) & 255u) == 2u ? 255u : 0u;
-                    ob[3 * q] = p.edge_ch == 0 ? ev : ob[3 * q]; ob[3 * q + 1] = p.edge_ch == 1 ? ev : ob[3 * q + 1]; ob[3 * q + 2] = p.edge_ch == 2 ? ev : ob[3 * q + 2];
-                }
-            }
-            const u3v out = {ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24), ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24),
-                             ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24)};
+            const u3v out = pack_rgb4(P[0], P[1], P[2], P[3]);
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
         __syncthreads();   // LDS is reused by the next frame of this workgroup
