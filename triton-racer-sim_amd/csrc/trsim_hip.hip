@@ -333,7 +333,6 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
 {
     __shared__ int s_tab[512];
     __shared__ unsigned s_part[16][3];
-    __shared__ float s_delta;
     // per-value tables replace per-pixel arithmetic (the masks variant was VALU bound at ~80 integer ops per pixel):
     // s_trim[x] = the trim of byte value x for this frame's delta; s_rng[c][x] = bit f set when value x of component c
     // (h, s, v) lies inside the range of the filter that owns channel f's mask, as a BYTE mask -> the AND of three lookups is a pixel's masks (mask_pixel)
@@ -377,8 +376,8 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
         if (lane == 0) { s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb; }
         __syncthreads();
-        if (tid == 0) {
-            const double cnt = (double)(p.r1 - p.r0) * (double)p.W;
+        if (tid < 256) {                                                    // every thread of the table evaluates the same binary64 expression itself (exact integer
+            const double cnt = (double)(p.r1 - p.r0) * (double)p.W;         // totals, any order): no serial pass by one thread, no barrier for the delta (round 3)
             double cur = 0.0;
             for (int ch = 0; ch < 3; ++ch) {
                 unsigned long long tot = 0;
@@ -386,10 +385,8 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                 cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
             }
             cur = cur + 0.0;
-            s_delta = (float)((p.baseline - cur) / 3);
+            trim_table((float)((p.baseline - cur) / 3));
         }
-        __syncthreads();
-        trim_table(s_delta);
         __syncthreads();
         }
         // ---- pass 2: trim, masks, merge ----
@@ -410,7 +407,7 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
             const u3v out = pack_rgb4(P0, P1, P2, P3);
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
-        if (p.dynamic) __syncthreads();   // s_part / s_delta / s_trim are rewritten for the next frame of this workgroup
+        if (p.dynamic) __syncthreads();   // s_part / s_trim are rewritten for the next frame of this workgroup
     }
 }
 
