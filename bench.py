@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes ITSELF (launch_ranks: plain child
+processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, created before this process imports torch or
+touches a GPU), relays rank 0's JSON line and exits with the children's code.  Under torch.distributed.run the same file is the rank.
+
 A "step" = one pass of the hot path over every env of every shard: bicycle-model integration, binary64
 nearest-point index, cte/done/return, and one 120x160 RGB frame per env written to HBM (inputs and
 outputs device-resident; controls from the counter-based generator of include/trsim_spec.h).
@@ -133,6 +137,161 @@ def pilot_weights(h, w):
     return ws, macs
 
 
+def config1_car_loop(device, ticks=1500):
+    """BASELINE configs[0] on the GPU box: 1 env through `Car.tick` (the reference's drive loop, core/car.py:45-53) with a constant-control part
+    and HipGymInterface (frame uint8[120,160,3] + 5 Python floats copied to the host every tick, one synchronisation).  ticks/s with the sleep
+    disabled, one launch per tick and with the resident worker."""
+    from triton_racer_sim_amd.components import HipGymInterface
+    from triton_racer_sim_amd.core import Car, Component
+
+    class Const(Component):
+        def __init__(self):
+            super().__init__(outputs=["mux/steering", "mux/throttle", "mux/breaking", "usr/reset"])
+
+        def step(self, *a):
+            return 0.05, 0.5, None, False
+
+    out = {}
+    for label, res in (("launch", False), ("resident", True)):
+        car = Car(loop_hz=1e9, verbose=False)
+        gym = HipGymInterface(gym_config={"scene_name": "generated_track", "hip_device": device, "hip_resident": res, "hip_resident_idle_us": 100000})
+        car.addComponent(Const())
+        car.addComponent(gym)
+        for _ in range(200):
+            car.tick()
+        t0 = time.perf_counter()
+        for _ in range(ticks):
+            car.tick()
+        dt = time.perf_counter() - t0
+        img, x = car.pool.get_value("cam/img"), car.pool.get_value("gym/x")
+        assert img.shape == (120, 160, 3) and img.dtype.name == "uint8" and type(x) is float
+        out[label] = ticks / dt
+        car.stop()
+    return {"ticks_per_s_launch": round(out["launch"], 1), "ticks_per_s_resident": round(out["resident"], 1), "ticks": ticks,
+            "us_per_tick_launch": round(1e6 / out["launch"], 2), "us_per_tick_resident": round(1e6 / out["resident"], 2),
+            "pcie_inclusive_MBps_resident": round(out["resident"] * 57600 / 1e6, 1),
+            "note": "BASELINE configs[0]: 1 env through Car.tick (core/car.py:45-53) = constant-control part + HipGymInterface.step (trs_step_host + trs_fetch_outputs: the frame "
+                    "and 5 Python floats on the host every tick), sleep disabled; host wall clock; latency-bound (FFI + launch or post + one synchronisation), never part of `value`; "
+                    "the reference paces this loop at 20 ticks/s (car_templates/manage.py:38)"}
+
+
+def physics_256(device, steps=4000):
+    """BASELINE configs[1]: 256 envs, physics only (trs_physics_kernel, 88 algorithmic bytes per env-step: latency-bound, the HBM roofline means nothing
+    here — reported as us per step).  One step per launch, 16 steps per launch, and the consumer-paced tick (trs_step once per tick with device controls)
+    in launch mode and posted to the resident physics worker."""
+    import torch
+    from triton_racer_sim_amd.env import BatchedEnv
+    n = 256
+    env = BatchedEnv(n_envs=n, render=False, auto_reset=True, device=device)
+    B = algorithmic_bytes(0, 0, False)
+    out = {"envs": n, "steps": steps, "bytes_per_env_step": B}
+    env.step_synthetic(4000, 16)
+    env.sync()
+    for label, spl in (("1", 1), ("16", 16)):
+        env.event_record(0)
+        env.step_synthetic(steps, spl)
+        env.event_record(1)
+        ms = env.event_elapsed_ms(0, 1)
+        out[f"us_per_step_spl{label}"] = round(ms * 1e3 / steps, 3)
+        out[f"us_per_launch_spl{label}"] = round(ms * 1e3 / (steps / spl), 3)
+        out[f"env_steps_per_s_spl{label}"] = round(n * steps / (ms * 1e-3), 1)
+        out[f"GBps_spl{label}"] = round(B * n * steps / (ms * 1e-3) / 1e9, 2)
+    st = (torch.rand(n, device="cuda") * 2 - 1) * 0.3
+    th = torch.rand(n, device="cuda") * 0.6 + 0.2
+    torch.cuda.synchronize()
+    for label, res in (("launch", False), ("resident", True)):
+        try:
+            env.set_step_mode(res, 100000)
+        except Exception as exc:
+            out[f"tick_{label}_error"] = str(exc)
+            continue
+        for _ in range(200):
+            env.step_device(st.data_ptr(), th.data_ptr())
+        env.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step_device(st.data_ptr(), th.data_ptr())
+        env.sync()
+        dt = time.perf_counter() - t0
+        out[f"tick_{label}_us"] = round(dt * 1e6 / steps, 3)
+        out[f"tick_{label}_env_steps_per_s"] = round(n * steps / dt, 1)
+        lock = 500
+        t0 = time.perf_counter()
+        for _ in range(lock):
+            env.step_device_wait(st.data_ptr(), th.data_ptr())
+        out[f"tick_{label}_lock_step_us"] = round((time.perf_counter() - t0) * 1e6 / lock, 3)
+    env.close()
+    out["note"] = ("BASELINE configs[1]: 256 envs, bicycle physics + binary64 nearest point, no camera; spl = steps per launch of trs_physics_kernel with the in-kernel control "
+                   "generator (device time by HIP events); tick_* = trs_step once per tick with device-resident controls (core/car.py:45-53), host wall clock: one launch per tick, "
+                   "or posted to the resident physics worker (trs_set_step_mode); lock_step = trs_step_wait (post, wait for the telemetry)")
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks, argv):
+    """Parent of a self-launched run: one child process per rank (= per GPU), each running THIS file with the environment
+    torch.distributed.run would give it.  The parent imports neither torch nor the HIP library and never touches a GPU (a process that
+    has initialised the GPU must not spawn / exec its replacement on this pool); it relays the children's stdout lines that are
+    JSON objects (rank 0's line) to its own stdout, everything else to stderr, and returns the first non-zero exit code (the other ranks
+    are then terminated by PID) or 0.  TRS_BENCH_CHILD (tests: a stub) replaces the script the ranks run."""
+    import signal
+    import subprocess
+    import threading
+    child = os.environ.get("TRS_BENCH_CHILD", os.path.abspath(__file__))
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TRS_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
+        procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def relay(proc):
+        for line in proc.stdout:
+            out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+            out.write(line)
+            out.flush()
+
+    threads = [threading.Thread(target=relay, args=(p_,), daemon=True) for p_ in procs]
+    for t in threads:
+        t.start()
+    rc = 0
+    try:
+        alive = set(range(n_ranks))
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+                    sys.stderr.write(f"bench.py: rank {r} exited with code {code}; stopping the other ranks\n")
+                    for o in alive:
+                        procs[o].terminate()
+            time.sleep(0.02)
+    except KeyboardInterrupt:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.send_signal(signal.SIGINT)
+        rc = 130
+    for p_ in procs:
+        try:
+            p_.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p_.kill()
+    for t in threads:
+        t.join(timeout=5)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,28 +315,47 @@ def main():
     ap.add_argument("--profile-mode", action="store_true", help="for rocprofv3 runs (scripts/profile.sh): no clock pre-warm, and a resident worker is asked to leave after the "
                                                                   "warm-up, so that every trs_worker_kernel dispatch of the trace serves exactly --steps (or --warmup) steps")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
+    ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (launch_ranks) even at --gpus 1: the rank runs as a child process of a parent that never touches the GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL of the N > 1 code path on a box with fewer GPUs than ranks: every rank uses GPU 0 and the process group is gloo "
+                                                             "(RCCL refuses two ranks on one device); the line says so and its value means nothing")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # self-launch: this process becomes the parent of the rank processes; it has imported neither torch nor the HIP library
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    launcher = os.environ.get("TRS_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else ("self" if "WORLD_SIZE" not in os.environ else "external"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
     import torch
-    from triton_racer_sim_amd.shard import ShardedEnvs
+    from triton_racer_sim_amd.shard import ShardedEnvs, max_over_ranks, timed_steps
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
+    if args.share_gpu:
+        local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but this node shows {torch.cuda.device_count()} GPU(s); --gpus N needs N GPUs (--share-gpu rehearses the code path on fewer)")
     torch.cuda.set_device(local_rank)
     dist = None
+    host_group = None
     if world > 1 or args.force_dist:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            host_group = dist.group.WORLD
+        else:
+            # device collectives (the one all-gather): nccl = RCCL over xGMI.  Barriers and the MAX over ranks: a gloo group, i.e. host
+            # sockets — a barrier must not need CU resources while every CU holds a resident worker
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
+            host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
 
     if args.envs_per_gpu is not None and args.total_envs is not None:
         sys.exit("give --envs-per-gpu or --total-envs, not both")
@@ -213,30 +391,26 @@ def main():
     if resident:
         # idle_us: the worker leaves by itself after this long without a post.  The library's default (2 ms) suits an interactive loop; a
         # benchmark whose host thread can be descheduled for milliseconds (a tracer attached, the GIL) would see its worker leave and be
-        # relaunched mid-run — every explicit boundary below asks it to leave (quiesce) instead.
-        env.set_step_mode(True, 100000)
+        # relaunched mid-run — every explicit boundary below asks it to leave (quiesce) instead.  (Rehearsal with several ranks on ONE GPU:
+        # their workers cannot be resident together, so each must leave quickly for the next one to start.)
+        env.set_step_mode(True, 2000 if args.share_gpu else 100000)
 
-    def barrier():
-        # every step handed to the env so far is complete in memory (resident mode: completion flags; launch mode: the stream has drained),
-        # torch's own work is done, and every rank is here.  While a resident worker is on the GPU a DEVICE-wide synchronisation would
-        # wait for that kernel to end (it leaves 2 ms after the last post): resident mode synchronises torch's stream instead — the
-        # worker's steps are covered by env.sync() — so that the worker stays across the warm-up -> timed boundary (steady state:
-        # what a consumer that keeps posting sees)
-        env.sync()
+    # The timed region is triton_racer_sim_amd.shard.timed_steps: [env.sync + stream synchronisation + barrier] t0 - K steps - env.sync t1
+    # [stream synchronisation + barrier], MAX of (t1 - t0) over ranks.  env.sync() = every step handed to the env so far is complete in memory
+    # (resident mode: the completion flags the worker writes; launch mode: the env's stream has drained).  While a resident worker is on the GPU
+    # a DEVICE-wide synchronisation would wait for that kernel to end (it leaves idle_us after the last post), so resident mode synchronises
+    # torch's stream instead, and the barrier between ranks is a HOST barrier (gloo): the worker stays across the warm-up -> timed boundary on
+    # every rank (steady state: what a consumer that keeps posting sees).
+    def host_barrier():
         if dist is not None:
-            if resident:
-                env.quiesce()                       # the collective's kernel needs CU resources the worker holds: N > 1 restarts the worker inside the timed region
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        elif resident:
-            torch.cuda.current_stream().synchronize()
-        else:
-            torch.cuda.synchronize()
+            dist.barrier(group=host_group)
 
-    if dist is not None:   # warm the communicator outside the timed region
+    stream_sync = (lambda: torch.cuda.current_stream().synchronize()) if resident else torch.cuda.synchronize
+
+    if dist is not None and not args.share_gpu:   # warm the communicator (RCCL: connection set-up over xGMI) before any worker is resident
         warm = torch.zeros(n * world, device="cuda")
         dist.all_gather_into_tensor(warm, torch.zeros(n, device="cuda"))
+        torch.cuda.synchronize()
     # An idle MI355X takes ~25-40 ms of work to raise its clocks: the first 2,000 steps of a fresh process run 12-14 % slower than the
     # steady state (profiles/r03_steady_state.txt: 10.85 us per step, then 9.46-9.58).  The metric is a steady-state rate, and
     # the driver's --warmup 5 is 50 us, so the clocks are brought up first — with untimed steps of the same workload, for PREWARM_S
@@ -249,18 +423,23 @@ def main():
     if args.profile_mode and resident:
         env.quiesce()
 
-    barrier()
-    t0 = time.perf_counter()
-    if not resident:
-        env.event_record(0)
-    run(args.steps)
-    if not resident:
-        env.event_record(1)
-    gathered = None
+    def timed_run(k_):
+        if not resident:
+            env.event_record(0)
+        run(k_)
+        if not resident:
+            env.event_record(1)
+
+    wall = timed_steps(env, timed_run, args.steps, host_barrier, stream_sync)
+    # the job's ONE exchange: an all-gather of the episode returns (4 B per env) per reporting interval — configs[3]: one per 1000 steps —
+    # so it closes the job here, timed on its own, not inside the K timed steps (a resident worker is asked to leave first, outside the timing)
+    gathered, allgather_s = None, None
     if dist is not None:
-        gathered = shard.allgather("ep_return")                        # the single RCCL all-gather over xGMI (4 B per env; asks a resident worker to leave first)
-    barrier()
-    wall = time.perf_counter() - t0
+        gathered, allgather_s = shard.allgather_timed("ep_return", host_barrier, torch.cuda.synchronize)
+        allgather_s = max_over_ranks(allgather_s, host_group)
+        mine = torch.as_tensor(env.fetch("ep_return"))
+        if not torch.equal(gathered.cpu()[shard.base:shard.base + n], mine):
+            sys.exit(f"rank {rank}: the gathered returns do not hold this shard's values at [{shard.base}, {shard.base + n})")
     if resident:
         # the dominant kernel's launch duration by HIP events on its own stream: an event on that stream makes the worker leave, so this
         # is a SECOND pass over the same K steps, bracketed by events = exactly one trs_worker_kernel launch (start-up, K steps, exit)
@@ -415,6 +594,19 @@ def main():
                 env3.close()
             except Exception as exc:
                 shard_leg = {"error": str(exc)}
+        # ... BASELINE configs[0]: ONE env through the Component / DataPool / Car loop (core/car.py:45-53), frame + 5 Python floats to the host every
+        # tick (HipGymInterface.step = trs_step_host + trs_fetch_outputs) — the reference's own shape, sleep disabled; fixed length
+        car_leg = None
+        try:
+            car_leg = config1_car_loop(local_rank)
+        except Exception as exc:
+            car_leg = {"error": str(exc)}
+        # ... BASELINE configs[1]: 256 envs, bicycle physics only (no camera), one GPU; fixed lengths (a consumer-paced tick and multi-step launches)
+        phys_leg = None
+        try:
+            phys_leg = physics_256(local_rank)
+        except Exception as exc:
+            phys_leg = {"error": str(exc)}
         env.set_step_mode(resident, 100000)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -439,10 +631,12 @@ def main():
             also["pilot_closed_loop_512x240x320_depth"] = pilot5_leg
         if shard_leg:
             also["shard_512_of_4096"] = shard_leg
+        if car_leg:
+            also["config1_car_loop"] = car_leg
+        if phys_leg:
+            also["physics_256"] = phys_leg
     if dist is not None:
-        tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+        wall = max_over_ranks(wall, host_group)
 
     if rank == 0:
         total_env_steps = n * world * args.steps
@@ -481,8 +675,9 @@ def main():
                             + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
                             + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
                 "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "prewarm_s": 0.0 if args.profile_mode else PREWARM_S,
-                "timing": ("host wall clock from the post of the first timed step to the completion flag of the last (worker resident across the warm-up -> timed boundary); "
-                           "roofline.achieved from a second pass of the same steps bracketed by HIP events = one whole worker launch") if resident else "host wall clock around the timed steps; HIP events on the env's stream for roofline.achieved", "sharding": f"{world} shard(s), one all-gather of ep_return" if world > 1 else "1 shard",
+                "timing": ("host wall clock from the post of the first timed step to the completion flag of the last (worker resident across the warm-up -> timed boundary)"
+                           + ("; per rank between two host (gloo) barriers, MAX over ranks" if world > 1 else "") + "; "
+                           "roofline.achieved from a second pass of the same steps bracketed by HIP events = one whole worker launch") if resident else "host wall clock around the timed steps; HIP events on the env's stream for roofline.achieved", "sharding": f"{world} shard(s), no data-path collective; one all-gather of ep_return closes the job, timed separately (`allgather`)" if world > 1 else "1 shard",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -504,9 +699,21 @@ def main():
             line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
                                 "traffic": None, "kernel": "per step: trs_step_kernel + trs_conv12_band_kernel (conv1 + conv2 fused) + trs_conv_frame5_kernel (conv3) + trs_conv_chain_kernel (conv4..7 in one launch) + trs_pilot_dense_kernel (dense1) + trs_pilot_tail_kernel at 120x160; frames too large for LDS: trs_conv_span_kernel (conv3) and one trs_conv_frame_kernel launch per 3x3 layer",
                                 "flops_per_frame": pilot_flops, "avg_step_us": round(kernel_ms * 1e3 / args.steps, 3),
-                                "note": "whole closed-loop step by HIP events; per-layer times in profiles/r02_pilot_final.txt"}
+                                "note": "whole closed-loop step by HIP events; per-layer times in profiles/r04_pilot_layers.txt"}
+        line["config"]["launcher"] = launcher          # "self": python bench.py --gpus N started the ranks (launch_ranks); "torch.distributed.run"; "external"
+        if resident:
+            # the same K steps with the worker's start-up and exit inside the clock (round 2's definition of `value`): one whole
+            # trs_worker_kernel launch by HIP events — what a consumer that posts K steps and then stops sees.  `value` is the steady-state rate.
+            line["value_incl_worker_launch"] = round(n * world * args.steps / avg_launch_s, 1)
+            line["roofline"]["covers"] = "one whole worker launch (start-up + K steps + exit) by HIP events; `value` and frac_by_wall_clock cover the K steps alone, worker resident"
         if gathered is not None:
-            line["config"]["allgather_returns_mean"] = round(float(gathered.mean().item()), 4)
+            line["allgather"] = {"us": round(allgather_s * 1e6, 1), "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "floats_per_rank": n, "returns_mean": round(float(gathered.float().mean().item()), 4),
+                                 "note": "ONE all-gather of ep_return closes the job (configs[3]: one per 1000 steps), timed on its own after the K steps: "
+                                         "[worker asked to leave, host barrier] t0 - all_gather_into_tensor - device synchronisation t1, MAX over ranks; never inside `value`"}
+            line["config"]["allgather_returns_mean"] = line["allgather"]["returns_mean"]
+        if args.share_gpu:
+            line["config"]["rehearsal"] = f"{world} ranks SHARING GPU 0 over gloo: a rehearsal of the N > 1 code path, not a measurement (the ranks' workers take turns on the one GPU)"
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(min(n, 1024), args.img_h, args.img_w) if render else None
             if cb:

@@ -88,7 +88,7 @@ enum {
     TRS_F_PALETTE,   /* uint32[img_h][4] 0x00BBGGRR       */
     TRS_F_TANGENT,   /* float[n_points][2] (tx, tz)       */
     TRS_F_STEER_FILT,/* float[n_envs] synthetic low-pass state */
-    TRS_F_STATS,     /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [8..] diagnostics */
+    TRS_F_STATS,     /* uint64[64]: [0] off-track events, [1] resets since load_track, [2] layout faults, [3] fp16 saturations counted by trs_pilot_range_check, [8..] diagnostics */
     TRS_F_DEPTH,     /* float[n_envs][img_h][img_w] */
     TRS_F_ROWDEPTH,  /* float[img_h] */
     TRS_F_CTL_STEER, /* float[n_envs]: the handle's own control arrays — what trs_step_host uploaded or the pilot of  */
@@ -158,8 +158,9 @@ int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h
  *     on a side stream, and every OTHER call that needs the stream (reset, set_pose, load_track, image path, control glue,
  *     pilot, events) first asks the worker to leave.  Frames and telemetry of a completed step are in HBM (written through);
  *     a consumer that reads them on its own stream does so after trs_sync.  Device-resident controls must be complete
- *     (their producer synchronised) when trs_step is called, and stay untouched until that step is done.  Needs a camera
- *     (cfg.render).  Every frame filter of trs_set_frame_filter is rendered by the worker (the dynamic-brightness one by its own
+ *     (their producer synchronised) when trs_step is called, and stay untouched until that step is done.  Physics-only
+ *     handles (cfg.render == 0, BASELINE configs[1]) get their own worker since round 4 (trs_physics_worker_kernel: one env per wave,
+ *     the same mailbox and completion flags; a tick costs a post instead of a launch).  Every frame filter of trs_set_frame_filter is rendered by the worker (the dynamic-brightness one by its own
  *     instantiation since round 3).
  *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident. */
 enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
@@ -172,9 +173,13 @@ int trs_quiesce(trs_env* env);
 /* trs_step followed by trs_sync in ONE call: the lock-step consumer of core/car.py:45-53 (post the controls, wait for the frame) crosses
  * the FFI once per tick instead of twice.  Same arguments and errors as trs_step. */
 int trs_step_wait(trs_env* env, const float* d_steering, const float* d_throttle, const float* d_brake_or_null, const uint8_t* d_reset_or_null, int n_steps);
-/* Test hook: a resident worker leaves by itself after life_us microseconds (default 500,000; <= 0 restores it) and the next post
- * starts a new one — tests use a short lifetime to run many worker generations under load.  Needs trs_set_step_mode first. */
+/* ---- test hooks of the resident worker: UNSTABLE, not part of the drop-in surface (no reference interface stands behind them; they exist so
+ * that tests/test_resident.py can force the worker's rare paths).  trs_resident_debug_lifetime: a worker leaves by itself after life_us
+ * microseconds (default 500,000; <= 0 restores it) and the next post starts a new one — many worker generations under load.  Needs
+ * trs_set_step_mode first.  trs_resident_debug_abort: sets the running worker's abort bit from outside, as a wave does whose bounded wait gave up:
+ * every wave must leave within its next poll and the next call must fail with TRS_ERR_DEVICE ("resident worker gave up") instead of hanging. */
 int trs_resident_debug_lifetime(trs_env* env, int life_us);
+int trs_resident_debug_abort(trs_env* env);
 
 /* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
 int trs_get_state(trs_env* env, trs_state_view* out);
@@ -382,6 +387,15 @@ int trs_pilot_forward_host_ex(trs_env* env, const uint8_t* h_frames, const float
 /* Activations of one layer of the last forward pass as float32 (tests): layer 0..6 = conv1..conv7 output
  * [n][OH][OW][C], 7 = dense1 [n][100]. */
 int trs_pilot_debug_layer(trs_env* env, int layer, float* h_dst, size_t n_floats);
+
+/* The reference runs the network in fp32 (components/keras_pilot.py:49-59: float32 frames into a Keras model); this library stores activations as
+ * binary16 and SATURATES them at 65504 in every convolution epilogue (an overflow cannot become an infinity downstream) — silently, because a
+ * per-step counter would cost every epilogue instructions.  trs_pilot_range_check is how a model's range is validated: after a forward pass
+ * on representative frames (trs_pilot_forward / _host / trs_pilot_act / trs_step_pilot) it counts the saturated elements (stored value 65504) of
+ * every convolution's activation of THAT pass — the ones the fused kernels keep in LDS are recomputed by the single-layer kernels — into
+ * h_out[0..6] (conv1..conv7) and their sum into h_out[7]; the sum is also added to TRS_F_STATS[3].  0 everywhere = the pass stayed inside
+ * binary16's range and differs from fp32 by rounding only (about 1e-3 relative per output at the top of the range, tests/test_pilot.py). */
+int trs_pilot_range_check(trs_env* env, uint64_t h_out[8]);
 
 /* KerasPilot.step (keras_pilot.py:45-95,139-153) for n cars on DEVICE arrays — the part of a device-resident pilot -> mux -> sim
  * graph (car_templates/manage.py:46-75): model(d_frames), then the model type's post-processing, written to d_steering /

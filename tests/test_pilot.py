@@ -420,3 +420,53 @@ def test_conv3_with_frames_in_lds_is_bit_identical_to_the_span_kernel(make_env, 
     assert np.array_equal(res["0"][1], res["1"][1])
     assert np.array_equal(res["0"][0], res["1"][0])
     assert np.abs(res["1"][1]).max() > 0
+
+
+def _range_weights(h, w, seed, conv2_peak):
+    """Glorot weights rescaled so that conv2's activations peak at ``conv2_peak`` (fp32 reference on noise + flat frames) and the following two
+    layers scale the signal back down by the same factor — the network's outputs stay O(1) while one activation tensor sits at the top of
+    (or beyond) binary16's range."""
+    ws = make_weights(h, w, seed=seed)
+    rng = np.random.default_rng(seed)
+    frames = np.concatenate([rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8), np.full((1, h, w, 3), 255, np.uint8)])
+    a1 = torch_layer(0, frames, ws, mirror=False)
+    a2 = torch_layer(1, a1, ws, mirror=False)
+    s = float(conv2_peak) / float(a2.max())
+    r = math.sqrt(s)
+    ws[2] = ws[2] * np.float32(s); ws[3] = ws[3] * np.float32(s)       # conv2: kernel and bias
+    ws[4] = ws[4] / np.float32(r); ws[6] = ws[6] / np.float32(r)       # conv3, conv4: kernels only (their inputs are s / r and 1 x too large)
+    return ws, frames
+
+
+def test_fp16_range_top_of_the_range_and_saturation_count(make_env):
+    """the reference runs the network in fp32 (components/keras_pilot.py:49-59); this library stores activations as fp16 and
+    saturates at 65504.  (a) Activations up to ~3e4 (conv2) — inside the range: no saturation is counted (trs_pilot_range_check, TRS_F_STATS[3])
+    and the outputs agree with fp32 PyTorch to 2e-3 of the output scale (fp16's 2^-11 relative rounding per stored activation; measured value
+    printed).  (b) The same network pushed to a conv2 peak of ~2.6e5 — beyond the range: the check reports saturated elements in conv2 and
+    nothing downstream of the clamp is an infinity or a NaN."""
+    h, w = 120, 160
+    env = make_env("hip", n_envs=4, img_h=h, img_w=w)
+    ws, frames = _range_weights(h, w, seed=23, conv2_peak=3.0e4)
+    env.pilot_load(ws)
+    out = env.pilot_forward_host(frames)
+    a2 = env.pilot_layer(1, (4,) + tuple(torch_layer(1, torch_layer(0, frames, ws), ws).shape[1:]))
+    assert 1.0e4 <= a2.max() < 65504.0, float(a2.max())
+    sat = env.pilot_range_check()
+    assert sat.sum() == 0, sat
+    assert int(env.fetch("stats")[3]) == 0
+    pure = torch_pure(frames, ws)
+    scale = max(1.0, float(np.abs(pure).max()))
+    rel = float(np.max(np.abs(out - pure))) / scale
+    print(f"conv2 peak {a2.max():.0f}: max |HIP - fp32| / scale = {rel:.2e} (outputs {out[0]}, fp32 {pure[0]})")
+    assert rel <= 2e-3, rel
+    # (b) beyond the range
+    ws_hi, _ = _range_weights(h, w, seed=23, conv2_peak=2.6e5)
+    env.pilot_load(ws_hi)
+    out_hi = env.pilot_forward_host(frames)
+    sat_hi = env.pilot_range_check()
+    print(f"conv2 peak 2.6e5: saturated elements per layer {sat_hi[:7]}, outputs {out_hi[0]}")
+    assert sat_hi[1] > 0 and sat_hi[7] == sat_hi[:7].sum()
+    assert int(env.fetch("stats")[3]) == int(sat_hi[7])
+    assert np.isfinite(out_hi).all()
+    a2_hi = env.pilot_layer(1, a2.shape)
+    assert a2_hi.max() == 65504.0 and np.isfinite(a2_hi).all()

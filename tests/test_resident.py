@@ -153,10 +153,7 @@ def test_resident_sequence_and_mode_errors(make_env, hip_api):
         env.step_sequence(st, th, steps_per_launch=4)
     assert_state_equal(g, o, "sequence through the worker")
     assert_frames_equal(g, o, "sequence through the worker")
-    p = make_env("hip", n_envs=4, render=False)
-    with pytest.raises(RuntimeError):
-        p.set_step_mode(True)                                    # no camera: refused
-    assert hip_api.set_step_mode(g._h, 7, 0) != 0
+    assert hip_api.set_step_mode(g._h, 7, 0) != 0                # an unknown mode is refused (physics-only handles have their own worker since round 4)
 
 
 def test_resident_worker_generations_under_load(make_env):
@@ -272,3 +269,106 @@ def test_step_wait_is_step_then_sync(make_env, resident):
     assert_state_equal(g, o, "step_wait ticks")
     with pytest.raises(RuntimeError):
         g.step_device_wait(0, 0)                                 # trs_step's errors come through
+
+
+# ---- physics-only envs (cfg.render == 0, BASELINE configs[1]): trs_physics_worker_kernel, round 4 ----
+
+def test_resident_physics_only_equals_the_oracle(make_env):
+    """The test at the top of this file with ``render=False``: synthetic controls, then host controls with more posts than ring slots,
+    a user reset in the middle; every state field against the oracle (indices and flags exact, pose within 1e-5)."""
+    n = 64
+    g, o = make_env("hip", n_envs=n, render=False, auto_reset=True), make_env("oracle", n_envs=n, render=False, auto_reset=True)
+    g.set_step_mode(True)
+    rng = np.random.default_rng(11)
+    for env in (g, o):
+        env.step_synthetic(11, 1)
+    assert_state_equal(g, o, "physics only, after 11 synthetic steps")
+    for k in range(19):
+        st, th, br = controls(rng, n)
+        rs = (rng.uniform(0, 1, n) < 0.05) if k == 4 else None
+        for env in (g, o):
+            env.step(st, th, br, reset=rs)
+    assert_state_equal(g, o, "physics only, after host-controlled steps")
+    assert np.array_equal(g.fetch("last_return"), o.fetch("last_return"))
+    assert g.fetch("stats")[2] == 0
+
+
+def test_resident_physics_256_envs_configs1_many_steps(make_env):
+    """BASELINE configs[1]: 256 envs, physics only; 1000 posted steps (queued 8 deep), a ragged last workgroup (n % 4 != 0) on the way,
+    then lock step with device controls rewritten in place."""
+    torch = pytest.importorskip("torch")
+    for n, steps in ((256, 1000), (101, 60)):
+        g, o = make_env("hip", n_envs=n, render=False, auto_reset=True), make_env("oracle", n_envs=n, render=False, auto_reset=True)
+        g.set_step_mode(True)
+        for env in (g, o):
+            env.step_synthetic(steps, 1)
+        assert_state_equal(g, o, f"physics only, {n} envs x {steps}")
+        rng = np.random.default_rng(12)
+        d_st, d_th = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        for k in range(30):
+            st, th, _ = controls(rng, n)
+            d_st.copy_(torch.from_numpy(st)); d_th.copy_(torch.from_numpy(th))
+            torch.cuda.synchronize()
+            g.step_device_wait(d_st.data_ptr(), d_th.data_ptr())      # post, wait for the telemetry: the arrays may be rewritten afterwards
+            o.step(st, th)
+        assert_state_equal(g, o, f"physics only, {n} envs, lock step")
+
+
+def test_resident_physics_worker_generations_idle_exit_and_launch_mix(make_env):
+    """Workers that leave (idle, a short lifetime under load) and are restarted by the next post; launches and resets in between."""
+    n = 96
+    g, o = make_env("hip", n_envs=n, render=False, auto_reset=True), make_env("oracle", n_envs=n, render=False, auto_reset=True)
+    g.set_step_mode(True, idle_us=300)
+    for env in (g, o):
+        env.step_synthetic(5, 1)
+    time.sleep(0.05)                                             # the worker leaves by itself (idle) ...
+    for env in (g, o):
+        env.step_synthetic(7, 1)                                 # ... and the next post starts a new one
+    assert_state_equal(g, o, "physics only, after an idle exit")
+    mask = np.zeros(n, np.uint8); mask[::7] = 1
+    for env in (g, o):
+        env.reset(mask)                                          # asks the worker to leave (the reset needs the stream)
+        env.step_synthetic(3, 1)
+    g.set_step_mode(False)
+    for env in (g, o):
+        env.step_synthetic(16, 8)                                # launches
+    g.set_step_mode(True)
+    g.resident_lifetime(400)                                     # many worker generations under load
+    for env in (g, o):
+        env.step_synthetic(600, 1)
+    assert_state_equal(g, o, "physics only, generations under load")
+    assert g.fetch("stats")[2] == 0
+
+
+def test_resident_abort_makes_every_wave_leave_and_the_host_gets_an_error(make_env):
+    """every spin of the worker is bounded and the abort bit makes every wave leave — also the raster waves of the
+    dynamic-brightness instantiation inside their team barriers (raster_dyn_batch).  The abort is injected from outside while steps
+    keep coming (trs_resident_debug_abort); the host must get TRS_ERR_DEVICE within seconds instead of waiting for ever, the handle says
+    so on every later step, and loading the track again makes it usable."""
+    for kw in (dict(filter=True), dict(filter=False), dict(filter=False, render=False)):
+        n = 1024 if kw.get("render", True) else 256
+        g = make_env("hip", n_envs=n, auto_reset=True, render=kw.get("render", True))
+        if kw["filter"]:
+            g.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2})
+        g.set_step_mode(True, idle_us=100000)
+        g.step_synthetic(40, 1)
+        g.sync()
+        g.step_synthetic(6, 1)                                    # steps in flight when the abort lands
+        g.resident_abort()
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="resident worker gave up|injected"):
+            for _ in range(50):
+                g.step_synthetic(8, 1)
+                g.sync()
+        assert time.perf_counter() - t0 < 8.0, "the worker did not leave promptly after the abort"
+        with pytest.raises(RuntimeError, match="gave up earlier"):
+            g.step_synthetic(1, 1)
+        g.load_track("generated_track")                           # every env on a defined state again
+        o = make_env("oracle", n_envs=n, auto_reset=True, render=kw.get("render", True))
+        if kw["filter"]:
+            o.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2})
+        for env in (g, o):
+            env.step_synthetic(9, 1)
+        assert_state_equal(g, o, f"after an injected abort and a track reload {kw}")
+        if kw.get("render", True):
+            assert_frames_equal(g, o, f"after an injected abort and a track reload {kw}")

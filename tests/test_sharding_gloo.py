@@ -29,9 +29,17 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     api = _ffi.Api(ctypes.CDLL(os.path.join(ROOT, "oracle", "libtrsim_oracle.so")), "trso_")
     sh = ShardedEnvs(N_TOTAL, rank, world, device=0, _api=api, render=False, auto_reset=True)
-    sh.step_synthetic(STEPS, 1)
-    full = sh.allgather("ep_return")
+    # the protocol bench.py's ranks run at N > 1: K steps between two HOST barriers (timed per rank, MAX over ranks), then the one
+    # all-gather timed on its own
+    from triton_racer_sim_amd.shard import max_over_ranks, timed_steps
+    calls = []
+    barrier = lambda: (calls.append("barrier"), dist.barrier())
+    wall = timed_steps(sh.env, lambda k: (calls.append(f"run{k}"), sh.step_synthetic(k, 1)), STEPS, barrier, lambda: calls.append("sync"))
+    assert calls == ["sync", "barrier", f"run{STEPS}", "sync", "barrier"], calls
+    wall_max = max_over_ranks(wall + rank)                  # rank 1's value is larger by construction: both ranks must get it
+    full, gather_s = sh.allgather_timed("ep_return", dist.barrier, None)
     idx = sh.allgather("cte")
+    np.save(os.path.join(out_dir, f"wall_{rank}.npy"), np.array([wall, wall_max, gather_s]))
     np.save(os.path.join(out_dir, f"ret_{rank}.npy"), full.numpy())
     np.save(os.path.join(out_dir, f"cte_{rank}.npy"), idx.numpy())
     dist.barrier()
@@ -44,6 +52,9 @@ def test_two_rank_allgather_equals_single_process(tmp_path, make_env):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     ref = make_env("oracle", n_envs=N_TOTAL, render=False, auto_reset=True)
     ref.step_synthetic(STEPS, 1)
+    w0, w1 = np.load(tmp_path / "wall_0.npy"), np.load(tmp_path / "wall_1.npy")
+    assert w0[0] > 0 and w1[0] > 0 and w0[2] > 0 and w1[2] > 0
+    assert w0[1] == w1[1] == w1[0] + 1                     # MAX over ranks, the same on every rank
     for rank in (0, 1):                                    # every rank holds the whole vector, in global-id order
         assert np.array_equal(np.load(tmp_path / f"ret_{rank}.npy"), ref.fetch("ep_return"))
         assert np.array_equal(np.load(tmp_path / f"cte_{rank}.npy"), ref.fetch("cte"))

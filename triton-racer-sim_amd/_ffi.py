@@ -125,8 +125,8 @@ PILOT_ARRAYS_OF_TYPE = {"cnn_2d_speed_control": 22, "cnn_2d": 22, "cnn_2d_speed_
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
 PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_forward_ex", "pilot_forward_host_ex",
-                 "pilot_debug_layer", "pilot_act", "step_pilot", "default_pilot_tuning", "pilot_set_tuning",
-                 "resident_debug_lifetime"]      # (the last: a test hook of the resident worker, which the oracle does not have either)
+                 "pilot_debug_layer", "pilot_range_check", "pilot_act", "step_pilot", "default_pilot_tuning", "pilot_set_tuning",
+                 "resident_debug_lifetime", "resident_debug_abort"]      # (the last two: test hooks of the resident worker, which the oracle does not have either)
 
 
 class Api:
@@ -188,6 +188,7 @@ class Api:
             "pilot_forward": (i32, [vp, vp, i32, vp]),
             "pilot_forward_host": (i32, [vp, vp, i32, vp]),
             "pilot_debug_layer": (i32, [vp, i32, vp, C.c_size_t]),
+            "pilot_range_check": (i32, [vp, vp]),
             "pilot_forward_ex": (i32, [vp, vp, vp, vp, i32, vp]),
             "pilot_forward_host_ex": (i32, [vp, vp, vp, vp, i32, vp]),
             "pilot_act": (i32, [vp, C.POINTER(TrsPilotConfig), vp, vp, vp, vp, vp, vp, vp, i32]),
@@ -195,6 +196,7 @@ class Api:
             "default_pilot_tuning": (None, [C.POINTER(TrsPilotTuning)]),
             "pilot_set_tuning": (i32, [vp, C.POINTER(TrsPilotTuning)]),
             "resident_debug_lifetime": (i32, [vp, i32]),
+            "resident_debug_abort": (i32, [vp]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(cdll, prefix + name)

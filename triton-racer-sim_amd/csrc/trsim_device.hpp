@@ -548,9 +548,22 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
 constexpr int kDynBatch = 4;
 __host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128; }
 
-template <bool DEPTH>
-__device__ __forceinline__ void raster_dyn_batch(const RParams& p, const FParams& f, const RasterThread& rth, unsigned char* lds_base, const float4 (&cams)[kDynBatch],
-                                                 int nb, uint8_t* img, float* dep, int e, int it, int tid, int lane)
+// The team barrier of raster_dyn_batch: a BOUNDED spin.  Every 1024 polls (~30 us) it asks `bail(first)` whether to give up — the resident worker
+// answers from its abort bit and its safety deadline (a wave of the team that left at an aborted wait_posted never arrives here: ADVICE r03); a
+// launched kernel has no abort and passes a callable that says no.  false = gave up: the caller leaves the kernel.
+template <typename Bail>
+__device__ __forceinline__ bool team_barrier_wait(const int* dbar, int target, Bail& bail)
+{
+    for (unsigned spins = 0; __hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u && bail(spins == 1023u)) return false;
+    }
+    return true;
+}
+
+template <bool DEPTH, typename Bail>
+__device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams& f, const RasterThread& rth, unsigned char* lds_base, const float4 (&cams)[kDynBatch],
+                                                 int nb, uint8_t* img, float* dep, int e, int it, int tid, int lane, Bail&& bail)
 {
     uint32_t* const penv = reinterpret_cast<uint32_t*>(lds_base + f.lds_off);                          // [kDynBatch][H][4]
     int* const esum = reinterpret_cast<int*>(lds_base + f.lds_off + kDynBatch * p.H * 16);           // [2][kDynBatch][3]
@@ -620,7 +633,7 @@ __device__ __forceinline__ void raster_dyn_batch(const RParams& p, const FParams
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 1)) __builtin_amdgcn_s_sleep(1);
+    if (!team_barrier_wait(dbar, nrw * (2 * it + 1), bail)) return false;
     // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then the palette entries
     {
         const double cnt = (double)(f.w1 - f.w0) * (double)p.W;
@@ -647,7 +660,7 @@ __device__ __forceinline__ void raster_dyn_batch(const RParams& p, const FParams
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nrw * (2 * it + 2)) __builtin_amdgcn_s_sleep(1);
+    if (!team_barrier_wait(dbar, nrw * (2 * it + 2), bail)) return false;
     // (C)
 #pragma unroll
     for (int bi = 0; bi < kDynBatch; ++bi) {
@@ -684,6 +697,7 @@ __device__ __forceinline__ void raster_dyn_batch(const RParams& p, const FParams
             }
         }
     }
+    return true;
 }
 
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves 64 lanes x 16 B = 1 KB, lane-linear, no

@@ -75,6 +75,7 @@ int sync_handle(trs_env* e);                               // the handle's strea
 int quiesce_handle(trs_env* e);                            // a resident worker has left; queued work may still be running
 void comm_destroy(trs_env* e);
 bool resident_running(const trs_env* e);
+bool resident_fits_dynamic_filter(const trs_env* e);      // the worker's LDS need WITH the dynamic-brightness palettes still fits a CU
 void resident_clear_fault(trs_env* e);                     // trs_load_track puts every env on a defined state again
 int check_fault(trs_env* e);                               // TRS_ERR_DEVICE (sticky) once a kernel has reported a layout fault
 }  // namespace trsim

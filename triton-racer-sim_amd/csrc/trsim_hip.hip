@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                     }
                 }
             }
-            raster_dyn_batch<DEPTH>(p, sp.fp, rth, smem, cams, min(kDynBatch, e_end - e), img, dep, e, it, tid, lane);
+            (void)raster_dyn_batch<DEPTH>(p, sp.fp, rth, smem, cams, min(kDynBatch, e_end - e), img, dep, e, it, tid, lane, [](bool) { return false; });   // a launch has no abort: every raster wave arrives
             continue;
         }
         // rows with four equal class colours need no map lookup and no pose: they are written first, and in a single-step
@@ -933,9 +933,9 @@ int sync_all(trs_env* e)
 // anything about to be queued on the handle's stream must not end up behind a resident worker
 int quiesce(trs_env* e) { return e->res ? trsim::resident_quiesce(e) : TRS_OK; }
 
-// steps go to the resident worker: resident mode is on (it needs a camera); the dynamic-brightness frame filter has its own worker
+// steps go to the resident worker: resident mode is on (physics-only handles have their own worker kernel since round 4); the dynamic-brightness frame filter has its own worker
 // instantiation since round 3 (it used to fall back to launches)
-bool resident_steps(const trs_env* e) { return trsim::resident_on(e) && e->cfg.render; }
+bool resident_steps(const trs_env* e) { return trsim::resident_on(e); }
 
 // one launch of the fused step kernel: physics steps [step_base, step_base + n_phys) and the frames of launch-local
 // steps r_first..r_last (-1 = step_base - 1, whose camera parameters the previous launch left in the global ring)
@@ -1699,6 +1699,11 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
             const int rpp = kRasterThreads / (e->W / 4);
             if (rpp < 1 || (79 + rpp - 1) / rpp > 16) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 4 registers), use trs_preprocess");
             if (e->track_loaded && e->max_steps_dyn < 1) return fail(TRS_ERR_LIMIT, "no LDS left beside this track's tables for the in-kernel dynamic-brightness palette, use trs_preprocess");
+            // resident mode: the worker keeps its env state and hand-off ring in LDS as well — refuse HERE, with the reason, what every later
+            // trs_step would otherwise refuse as "too many envs per workgroup" 
+            if (e->track_loaded && trsim::resident_on(e) && !trsim::resident_fits_dynamic_filter(e))
+                return fail(TRS_ERR_LIMIT, "the resident worker's LDS (tables + env state + hand-off ring) leaves no room for the dynamic-brightness palettes of a batch: "
+                                           "select TRS_STEP_LAUNCH for this filter, or use trs_preprocess");
         }
         if (c->dynamic_brightness) { HIPCHK(hipSetDevice(e->device)); rc = ensure_hsv_table(e); if (rc) return rc; }
         e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
@@ -2038,6 +2043,7 @@ bool trs_internal_view(trs_env* e, TrsEnvView* v)
     v->speed = e->pp.speed; v->seg_idx = e->pp.seg_idx; v->n_points = e->pp.np;
     v->ctl_steer = e->ctl_steer; v->ctl_thr = e->ctl_thr; v->ctl_brk = e->ctl_brk;
     v->step_count = e->step_count;
+    v->stats = e->stats;
     return true;
 }
 void** trs_internal_pilot_slot(trs_env* e) { return e ? &e->pilot : nullptr; }

@@ -15,6 +15,7 @@ struct TrsEnvView {
     const int32_t* seg_idx; int n_points;   // LocationTracker index and track length ('loc/segment' = idx / n_points * 10)
     float *ctl_steer, *ctl_thr, *ctl_brk;   // the handle's own control staging arrays (device)
     uint64_t step_count;
+    unsigned long long* stats;        // TRS_F_STATS (device, uint64[64])
 };
 
 bool trs_internal_view(trs_env* e, TrsEnvView* out);

@@ -2001,6 +2001,18 @@ __global__ __launch_bounds__(256) void trs_pilot_tail_ex_kernel(const TailExPara
     p.steer[i] = steering; p.thr[i] = throttle; p.brk[i] = breaking;
 }
 
+// fp16 range check (trs_pilot_range_check): activations are stored as binary16 and SATURATE at 65504 (v_pk_min_i16 in every epilogue; the
+// reference computes in fp32, components/keras_pilot.py:49-59).  A stored value of exactly 0x7BFF is a saturated one (a sum that lands on
+// 65504 by itself is not a practical case): counted per layer into `per_layer` and into the handle's TRS_F_STATS slot.
+__global__ __launch_bounds__(256) void trs_pilot_count_sat_kernel(const unsigned short* act, size_t n, unsigned long long* per_layer, unsigned long long* total)
+{
+    unsigned cnt = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) cnt += act[i] == 0x7BFFu ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) { atomicAdd(per_layer, (unsigned long long)cnt); atomicAdd(total, (unsigned long long)cnt); }
+}
+
 __global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2885,6 +2897,50 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     std::vector<unsigned short> tmp(total);
     HIPCHK(hipMemcpy(tmp.data(), c->act[layer], total * 2, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < total; ++i) h_dst[i] = host_h2f(tmp[i]);
+    return TRS_OK;
+}
+
+// materialise what the fused kernels of the last forward pass kept in LDS (conv1 behind the fused head, the chain's interior layers)
+static int materialise_layers(PilotCtx* c, const TrsEnvView& v, int upto)
+{
+    if (!c->act0_valid) {
+        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count, c->tun);
+        if (rc) return rc;
+        c->act0_valid = true;
+    }
+    if (c->chain_first >= 0 && upto >= c->chain_first && !c->chain_mid_valid) {
+        for (int j = c->chain_first; j < 6; ++j) {
+            int rc = launch_conv(c->L[j], c->act[j - 1], (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count, c->tun);
+            if (rc) return rc;
+        }
+        c->chain_mid_valid = true;
+    }
+    return TRS_OK;
+}
+
+TRS_EXPORT int trs_pilot_range_check(trs_env* e, uint64_t h_out[8])
+{
+    TrsEnvView v;
+    if (!trs_internal_view(e, &v)) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    PilotCtx* c = static_cast<PilotCtx*>(*trs_internal_pilot_slot(e));
+    if (!c || !c->last_n) return trs_internal_fail(TRS_ERR_STATE, "no forward pass yet");
+    if (!h_out) return trs_internal_fail(TRS_ERR_ARG, "null output");
+    HIPCHK(hipSetDevice(v.device));
+    { int rc = materialise_layers(c, v, 6); if (rc) return rc; }
+    unsigned long long* const scratch = v.stats + 24;                       // stats[24..30]: this call's per-layer counts; stats[3]: running total
+    HIPCHK(hipMemsetAsync(scratch, 0, 8 * sizeof(unsigned long long), v.stream));
+    for (int i = 0; i < 7; ++i) {
+        const size_t n = (size_t)c->last_n * c->act_elems[i];
+        const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
+        hipLaunchKernelGGL(trs_pilot_count_sat_kernel, dim3(grid), dim3(256), 0, v.stream, static_cast<const unsigned short*>(c->act[i]), n, scratch + i, v.stats + 3);
+    }
+    HIPCHK(hipGetLastError());
+    unsigned long long host[8] = {};
+    HIPCHK(hipMemcpyAsync(host, scratch, sizeof host, hipMemcpyDeviceToHost, v.stream));
+    HIPCHK(hipStreamSynchronize(v.stream));
+    host[7] = 0;
+    for (int i = 0; i < 7; ++i) { h_out[i] = host[i]; host[7] += host[i]; }
+    h_out[7] = host[7];
     return TRS_OK;
 }
 

@@ -278,10 +278,10 @@ __device__ __forceinline__ void raster_arrive(const WLds& l, u64 s, int lane)
 // The forwarder (the workgroup's last physics wave: it never stores to global memory, so it has nothing to drain) watches the
 // LDS counters in its idle moments.  All eight raster waves in: it arrives for the workgroup on a device counter sharded by
 // blockIdx % 8; the last workgroup of a shard arrives on the top counter; the last shard tells the host.
-__device__ __forceinline__ void forward_arrivals(const WParams& wp, const WLds& l, u64& fwd, int lane)
+__device__ __forceinline__ void forward_arrivals(const WParams& wp, const WLds& l, u64& fwd, int lane, int want = kRasterThreads / 64)
 {
     const int slot = (int)(fwd & (kSlots - 1));
-    if (lds_load32(&l.arrive[slot]) != kRasterThreads / 64) return;
+    if (lds_load32(&l.arrive[slot]) != want) return;
     if (lane == 0) {
         lds_store32(&l.arrive[slot], 0);
         const int shard = (int)(blockIdx.x & 7u), nshards = min(8, wp.n_blocks);
@@ -303,14 +303,14 @@ __device__ __forceinline__ void forward_arrivals(const WParams& wp, const WLds& 
 
 // What a waiting physics wave does on the side: the leader keeps the workgroup's LDS word fresh (workgroup 0's also talks to
 // the host), the forwarder passes completed steps on.
-struct Duties { bool leader, forwarder; u64 fwd; };
+struct Duties { bool leader, forwarder; u64 fwd; int want = kRasterThreads / 64; };   // want: arrivals that complete a step in this workgroup
 
 // 1 = step s is posted (go), 0 = leave.
 __device__ __forceinline__ int wait_posted(const WParams& wp, const WLds& l, Duties& D, u64 s, int lane)
 {
     u64 t0 = 0;
     for (unsigned spins = 0;; ++spins) {
-        if (D.forwarder) forward_arrivals(wp, l, D.fwd, lane);
+        if (D.forwarder) forward_arrivals(wp, l, D.fwd, lane, D.want);
         const u64 w = lds_load64(l.word);
         if (w & kAbortBit) return 0;
         if ((w & kCountMask) > s) return 1;
@@ -334,7 +334,7 @@ __device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, Dut
     u64 t0 = 0;
     for (unsigned spins = 0;; ++spins) {
         if (lds_load32(ctr) >= want) return 1;
-        if (D && D->forwarder) forward_arrivals(wp, l, D->fwd, lane);
+        if (D && D->forwarder) forward_arrivals(wp, l, D->fwd, lane, D->want);
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 1023u) == 1023u) {
             if (lds_load64(l.word) & kAbortBit) return 0;
@@ -553,7 +553,16 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                         if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                raster_dyn_batch<DEPTH>(p, wp.fp, rth, smem, cams, min(kDynBatch, n_loc - b0), img, dep, e_begin + b0, r * nbatch + b0 / kDynBatch, tid, lane);
+                u64 t0_bar = 0;
+                // the team barriers inside are bounded like every other spin of the worker: abort bit of this workgroup, then the safety deadline
+                auto bail = [&](bool first) -> bool {
+                    if (lds_load64(l.word) & kAbortBit) return true;
+                    const u64 now = (u64)wall_clock64();
+                    if (first) { t0_bar = now; return false; }
+                    if (now - t0_bar > wp.safety_ticks) { worker_abort(wp, l, 5u); return true; }
+                    return false;
+                };
+                if (!raster_dyn_batch<DEPTH>(p, wp.fp, rth, smem, cams, min(kDynBatch, n_loc - b0), img, dep, e_begin + b0, r * nbatch + b0 / kDynBatch, tid, lane, bail)) return;
                 if (mine_j >= 0 && !(kDiag & 2)) {                    // the step's telemetry of this wave's env of the batch (a wave owns at most one of four)
                     const size_t e = (size_t)(e_begin + mine_j);
                     if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -595,6 +604,132 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     }
 }
 
+// ---- physics-only envs (cfg.render == 0, BASELINE configs[1]): the consumer-paced step without a launch per step -------------------
+// The same mailbox, device ring, arrival counters and exit protocol as trs_worker_kernel, on the geometry of trs_physics_kernel: one env
+// per wave, four envs per workgroup, the 38 KB track image staged once.  A workgroup has two more waves that own no env:
+//   wave 4, the service wave: leader (keeps the workgroup's LDS word fresh from the device word) and forwarder (passes whole-workgroup
+//           arrivals on: sharded device counter -> top counter -> done flag in the mailbox);
+//   wave 5, workgroup 0 only: the dispatcher (dispatcher_run, unchanged: PCIe polls must not sit in front of any env's integration).
+// A physics wave keeps its env in registers for the whole launch.  Per step: wait for the post, read the entry from the device ring — a
+// load, and vector-memory operations complete in order on this chip, so once it has returned every store of the previous step has been
+// acknowledged: the wave arrives for step s - 1 here, without a drain (the lagged arrival of the raster waves, with a lag of one) — then
+// the controls (system-scope loads), env_advance (the same inlined routine as every other step path: bit-identical results) and the
+// step's telemetry, written through (14 arrays, one lane each: two wave instructions).  With nothing queued behind the step (a
+// lock-step consumer is waiting for it) the wave drains and arrives at once.
+constexpr int kPwEnvs = 4;                          // envs (= physics waves) per workgroup
+constexpr int kPwBlock = 64 * (kPwEnvs + 2);
+
+__global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WParams wp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const PParams& P = wp.ph;
+    const WLds l = wlds_of(smem + wp.lds_off_ctl, kPwEnvs);
+    const int e_begin = blockIdx.x * kPwEnvs;
+    const int n_loc = min(e_begin + kPwEnvs, P.n_envs) - e_begin;
+    if ((unsigned)(uintptr_t)smem != 0u) {                   // the track image is addressed from LDS offset 0
+        if (tid == 0) {
+            atomicAdd(&P.stats[2], 1ull);
+            sys_store64(P.fault, 1ull);
+            sys_store64(&wp.mb->error, (9ull << 32) | (u64)blockIdx.x);
+            __hip_atomic_fetch_or(&wp.dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) { sys_store64(&wp.mb->consumed, wp.start); sys_store64(&wp.mb->exited, 1ull); }
+        }
+        return;
+    }
+    stage_lds_dma(P.blob, P.blob_bytes, 0u, wave, kPwBlock / 64, lane);
+    if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
+    if (tid < kSlots) l.arrive[tid] = 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    if (wave == kPwEnvs + 1) {                               // the dispatcher: workgroup 0 only
+        if (blockIdx.x == 0) dispatcher_run(wp, l, lane);
+        return;
+    }
+    if (wave == kPwEnvs) {                                   // the service wave: leader + forwarder, until the launch's last step has been passed on
+        Duties D{blockIdx.x != 0, true, wp.start, n_loc};
+        u64 s = wp.start;
+        while (wait_posted(wp, l, D, s, lane)) ++s;          // returns at once for a step that is posted: s runs up to the published count, then the wait does the duties
+        const u64 w = lds_load64(l.word);
+        if (w & kAbortBit) return;
+        const u64 last = w & kCountMask;                     // EXIT | final count: every physics wave finishes the steps below it
+        u64 t0 = 0;
+        for (unsigned spins = 0; D.fwd < last; ++spins) {
+            forward_arrivals(wp, l, D.fwd, lane, n_loc);
+            if (lds_load64(l.word) & kAbortBit) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins & 1023u) == 1023u) {
+                const u64 now = (u64)wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > wp.safety_ticks) { worker_abort(wp, l, 4u); break; }
+            }
+        }
+        return;
+    }
+    if (wave >= n_loc) return;                               // the last workgroup may own fewer than four envs
+
+    const int e = e_begin + wave;
+    EnvRegs st;
+    env_load(P, e, st);
+    float lr = coherent_load(&P.last_return[e]);
+    unsigned char* optr = nullptr;                           // this lane's telemetry array (lanes 0..11: 4-byte arrays, lanes 12, 13: done, pending)
+    {
+        unsigned char* const tab[14] = {(unsigned char*)P.x, (unsigned char*)P.y, (unsigned char*)P.z, (unsigned char*)P.yaw, (unsigned char*)P.v,
+                                        (unsigned char*)P.speed, (unsigned char*)P.cte, (unsigned char*)P.seg_idx, (unsigned char*)P.ep_return,
+                                        (unsigned char*)P.ep_len, (unsigned char*)P.steer_filt, (unsigned char*)P.last_return,
+                                        (unsigned char*)P.done, (unsigned char*)P.pending};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) optr = lane == k ? tab[k] : optr;
+    }
+    Duties none{false, false, 0};
+    u64 owed = wp.start;                                     // oldest step this wave has not arrived for
+    for (u64 s = wp.start;; ++s) {
+        if (owed < s && (lds_load64(l.word) & kCountMask) <= s) {   // nothing further posted: the consumer may be waiting for step s - 1
+            drain_vmem();
+            for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+        }
+        if (!wait_posted(wp, l, none, s, lane)) {
+            drain_vmem();
+            for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+            return;
+        }
+        const u64* en = reinterpret_cast<const u64*>(&wp.dc->ring[s & (kSlots - 1)]);
+        const u64 ev = lane < 6 ? agent_load64(en + lane) : 0ull;   // words 1..5 of the entry (WEntry): steer, thr, brk, reset, synth
+        const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 1));   // (the readlanes wait for the load: vmcnt(0))
+        const float* const c_th = reinterpret_cast<const float*>(lane_u64(ev, 2));
+        const float* const c_br = reinterpret_cast<const float*>(lane_u64(ev, 3));
+        const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(lane_u64(ev, 4));
+        const int synth = (int)(unsigned)lane_u64(ev, 5);
+        drain_vmem();                                        // (explicit: the entry is here, so every older store of this wave is in memory)
+        for (; owed < s; ++owed) raster_arrive(l, owed, lane);
+        float steer = 0.f, thr = 0.f, brk = 0.f;
+        uint8_t rin = 0;
+        if (!synth) {
+            steer = sys_load_val(&c_st[e]); thr = sys_load_val(&c_th[e]);
+            if (c_br) brk = sys_load_val(&c_br[e]);
+            if (c_rs) rin = sys_load_val(&c_rs[e]);
+        }
+        const float epr_before = st.epr;
+        StepOut o;
+        env_advance<true, false>(P, smem, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o);
+        if (o.do_reset) lr = epr_before;
+        if (lane == 0) {
+            if (o.is_done) atomicAdd(&P.stats[0], 1ull);
+            if (o.do_reset) atomicAdd(&P.stats[1], 1ull);
+        }
+        unsigned tel = 0;
+        {
+            const unsigned vals[13] = {__float_as_uint(st.x), __float_as_uint(st.y), __float_as_uint(st.z), __float_as_uint(st.yaw), __float_as_uint(st.v),
+                                       __float_as_uint(st.speed), __float_as_uint(st.cte), (unsigned)st.seg, __float_as_uint(st.epr), (unsigned)st.epl,
+                                       __float_as_uint(st.sf), __float_as_uint(lr), (unsigned)st.done};
+#pragma unroll
+            for (int k = 0; k < 13; ++k) tel = lane == k ? vals[k] : tel;
+        }
+        if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // zero the device control block and set its word before a launch (stream-ordered in front of the worker)
 __global__ void trs_worker_init_kernel(DevCtl* dc, u64 start)
 {
@@ -620,6 +755,12 @@ inline void host_store(uint64_t* p, uint64_t v) { __atomic_store_n(p, v, __ATOMI
 int worker_fits(trs_env* e)
 {
     Resident* R = e->res;
+    if (!e->cfg.render) {                                    // physics-only envs: the track image + the control block (trs_physics_worker_kernel)
+        R->lds_off_ctl = (e->lds_p + 15) & ~15;
+        R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(kPwEnvs) + 16);
+        if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "track image too large for the resident physics worker");
+        return TRS_OK;
+    }
     R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables
     R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
     if (e->has_frame_filter && e->filter_dynamic) { R->lds_off_dyn = (R->lds_bytes + 15) & ~15; R->lds_bytes = R->lds_off_dyn + dyn_lds_bytes(e->H); }
@@ -644,9 +785,15 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.life_ticks = (unsigned long long)R->life_us * 100ull;   // 0.5 s by default: then the dispatcher leaves and the host starts a new worker at its next post
     wp.safety_ticks = 200000000ull;                         // 2 s
     wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl;
-    const int grid = (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg;
+    const int grid = e->cfg.render ? (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg : (e->n + kPwEnvs - 1) / kPwEnvs;
     wp.n_blocks = grid;
     hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)start);
+    if (!e->cfg.render) {
+        hipLaunchKernelGGL(trs_physics_worker_kernel, dim3(grid), dim3(kPwBlock), R->lds_bytes, e->sP, wp);
+        RCHK(hipGetLastError());
+        R->running = true;
+        return TRS_OK;
+    }
     const bool dyn = e->has_frame_filter && e->filter_dynamic;
     if (dyn) {                                              // the fields trs_step_kernel's DYN instantiation gets (trsim_hip.hip, launch_step)
         const trs_pre_config& c = e->frame_filter;
@@ -675,7 +822,8 @@ int worker_error(trs_env* e)
     const uint64_t err = host_load(&e->res->mb->error);
     if (!err) return TRS_OK;
     e->res->broken = true;
-    static const char* const what[] = {"", "waiting for a post", "camera ring back-pressure", "waiting for the physics team", "", "", "", "", "",
+    static const char* const what[] = {"", "waiting for a post", "camera ring back-pressure", "waiting for the physics team", "forwarding the last arrivals",
+                                       "team barrier of the dynamic-brightness batch", "", "abort injected by trs_resident_debug_abort (test hook)", "",
                                        "dynamic LDS segment not at offset 0"};
     const unsigned code = (unsigned)(err >> 32);
     return trs_internal_fail(TRS_ERR_DEVICE, std::string("resident worker gave up (") + (code < 10 ? what[code] : "?") + ") in workgroup " +
@@ -727,7 +875,15 @@ int ensure_resident(trs_env* e)
     RCHK(hipHostMalloc((void**)&R->mb, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(R->mb, 0, sizeof(Mailbox));
     RCHK(hipMalloc((void**)&R->dc, sizeof(DevCtl)));
-    RCHK(hipStreamCreateWithFlags(&R->sC, hipStreamNonBlocking));
+    // The copy stream must not share a hardware queue with the handle's stream: a copy queued behind the worker kernel on the same queue would
+    // wait until the worker leaves (seen in round 4: 100 ms = idle_us per trs_fetch_outputs in a process that had created many streams, where
+    // the runtime's least-used-queue choice put both streams on one queue).  The runtime keeps a separate pool of hardware queues per stream
+    // priority, so the copy stream takes the HIGHEST priority and the handle's stream (default priority) can never alias it.
+    {
+        int least = 0, greatest = 0;
+        RCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        RCHK(hipStreamCreateWithPriority(&R->sC, hipStreamNonBlocking, greatest));
+    }
     R->hctl_slot = ((size_t)e->n * 13 + 63) & ~(size_t)63;
     RCHK(hipHostMalloc((void**)&R->hctl, R->hctl_slot * kSlots, hipHostMallocMapped | hipHostMallocCoherent));
     return TRS_OK;
@@ -740,6 +896,12 @@ namespace trsim {
 bool resident_on(const trs_env* e) { return e && e->res && e->res->enabled; }
 bool resident_running(const trs_env* e) { return e && e->res && e->res->running; }
 void resident_clear_fault(trs_env* e) { if (e && e->res) e->res->broken = false; }
+bool resident_fits_dynamic_filter(const trs_env* e)
+{
+    const int off_ctl = (e->lds_step + 15) & ~15;
+    const int base = (int)(off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
+    return ((base + 15) & ~15) + dyn_lds_bytes(e->H) <= 160 * 1024;
+}
 
 int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride)
 {
@@ -865,6 +1027,25 @@ TRS_EXPORT int trs_resident_debug_lifetime(trs_env* e, int life_us)
     return TRS_OK;
 }
 
+// test hook: what a wave does when one of its bounded waits gives up, done from outside — the abort bit in the device word and the
+// error word in the mailbox, by a one-thread kernel on the side stream (the worker owns the handle's stream)
+__global__ void trs_worker_debug_abort_kernel(Mailbox* mb, DevCtl* dc)
+{
+    sys_store64(&mb->error, (7ull << 32));
+    __hip_atomic_fetch_or(&dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+TRS_EXPORT int trs_resident_debug_abort(trs_env* e)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    if (!e->res || !e->res->running) return trs_internal_fail(TRS_ERR_STATE, "no resident worker is running on this handle");
+    RCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(trs_worker_debug_abort_kernel, dim3(1), dim3(1), 0, e->res->sC, e->res->mb, e->res->dc);
+    RCHK(hipGetLastError());
+    RCHK(hipStreamSynchronize(e->res->sC));
+    return TRS_OK;
+}
+
 TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
 {
     if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
@@ -876,7 +1057,6 @@ TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
         e->res->enabled = false;
         return rc;
     }
-    if (!e->cfg.render) return trs_internal_fail(TRS_ERR_STATE, "resident mode needs a camera (cfg.render == 1): the physics-only kernel already keeps K steps in one launch");
     if (!e->track_loaded) return trs_internal_fail(TRS_ERR_STATE, "no track loaded");
     if (!e->res) e->res = new (std::nothrow) Resident();
     if (!e->res) return trs_internal_fail(TRS_ERR_NOMEM, "out of memory");
@@ -888,6 +1068,7 @@ TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_worker_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (idle_us > 0) R->idle_us = (unsigned)std::min(idle_us, 1000000);
     if (!R->enabled) { R->base = R->seen_done = e->step_count; host_store(&R->mb->posted, e->step_count); }
     R->enabled = true;

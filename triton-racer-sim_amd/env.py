@@ -431,6 +431,10 @@ class BatchedEnv:
         """Test hook (``trs_resident_debug_lifetime``): resident workers leave by themselves after ``life_us``."""
         self.api.check(self.api.resident_debug_lifetime(self._h, int(life_us)), "resident_debug_lifetime")
 
+    def resident_abort(self):
+        """Test hook (``trs_resident_debug_abort``): the running worker's abort bit is set from outside."""
+        self.api.check(self.api.resident_debug_abort(self._h), "resident_debug_abort")
+
     def pilot_config(self, cfg=None):
         pc = _ffi.TrsPilotConfig()
         self.api.default_pilot_config(C.byref(pc))
@@ -465,6 +469,12 @@ class BatchedEnv:
     def pilot_layer(self, layer, shape):
         out = np.empty(shape, dtype=np.float32)
         self.api.check(self.api.pilot_debug_layer(self._h, int(layer), out.ctypes.data, out.size), "pilot_debug_layer")
+        return out
+
+    def pilot_range_check(self):
+        """fp16 saturations of the last forward pass per convolution (``trs_pilot_range_check``): ``uint64[8]``, [0..6] = conv1..conv7, [7] = sum."""
+        out = np.zeros(8, np.uint64)
+        self.api.check(self.api.pilot_range_check(self._h, out.ctypes.data), "pilot_range_check")
         return out
 
     def step_pilot(self, n_steps=1, cfg=None):

@@ -5,6 +5,8 @@ all-gather of the per-env episode returns (RCCL over xGMI with the ``nccl`` back
 bound, issued per reporting interval, never per step).  The reference has no distributed layer at all
 (SURVEY.md §5); this is the MI355X-native fan-out named by BASELINE.json's north_star.
 """
+import time
+
 import numpy as np
 
 from .env import BatchedEnv
@@ -15,6 +17,41 @@ def shard_range(n_total, rank, world):
         raise ValueError(f"n_total={n_total} is not divisible by world_size={world}")
     n_local = n_total // world
     return rank * n_local, n_local
+
+
+def timed_steps(env, run, steps, host_barrier, stream_sync=None):
+    """The timed region of a sharded run (bench.py, N >= 1): [barrier + stream synchronisation] t0 — ``run(steps)`` — ``env.sync()`` t1
+    [barrier].  Returns this rank's ``t1 - t0`` in seconds; the caller takes the MAX over ranks (``max_over_ranks``).
+
+    ``host_barrier`` must not need the GPU (a gloo barrier, or a no-op at world size 1): a resident worker holds a workgroup slot
+    and most of the LDS of every CU, so a device-side barrier (an RCCL kernel) would have to wait for the worker to leave and the
+    region would time the worker's restart instead of K steps.  ``env.sync()`` returns when every posted / launched step is complete
+    in memory (resident mode: the completion flags the worker writes; launch mode: the stream has drained) — the same condition a
+    device synchronisation gives, without ending the worker.  ``stream_sync``: the caller's own stream (torch's), synchronised on
+    both sides outside [t0, t1]."""
+    env.sync()
+    if stream_sync is not None:
+        stream_sync()
+    host_barrier()
+    t0 = time.perf_counter()
+    run(steps)
+    env.sync()
+    t1 = time.perf_counter()
+    if stream_sync is not None:
+        stream_sync()
+    host_barrier()
+    return t1 - t0
+
+
+def max_over_ranks(value, group=None):
+    """MAX of a host float over the ranks of ``group`` (a gloo group: no GPU work); the value itself without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
 
 
 class ShardedEnvs:
@@ -39,6 +76,21 @@ class ShardedEnvs:
             unique_id = exchange(self.env.comm_unique_id())
         self.env.comm_init(self.rank, self.world, unique_id)
         self._c_comm = True
+
+    def allgather_timed(self, name="ep_return", host_barrier=None, device_sync=None):
+        """The job's ONE exchange, timed on its own (BASELINE configs[3]: one all-gather per reporting interval, never per step):
+        the worker is asked to leave first (outside the timing), then ``[barrier] t0 — all-gather — device synchronisation t1``.
+        Returns ``(gathered, seconds)``."""
+        self.env.quiesce()
+        if device_sync is not None:
+            device_sync()
+        if host_barrier is not None:
+            host_barrier()
+        t0 = time.perf_counter()
+        out = self.allgather(name)
+        if device_sync is not None:
+            device_sync()
+        return out, time.perf_counter() - t0
 
     def allgather(self, name="ep_return"):
         """All ranks receive the full ``[n_total]`` vector of a per-env float32 field, ordered by global env id."""
