@@ -351,7 +351,7 @@ typedef struct trs_pilot_tuning {
     int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it (32-pixel tiles per wave item) */
     int32_t chain_nb;            /* 2: 64 output channels per wave item (default); 1: 32; 0: 32 only where 64 would leave half of the waves without an item (measured: no faster) */
     int32_t chain_f;             /* 0: automatic (4 frames per workgroup of 8 waves while the grid fills the chip, else 2); 2: two frames per workgroup of 4 waves, two workgroups per CU */
-    int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel; 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
+    int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel (64 frames per workgroup where K is long: 240x320); 2: the same with 32 frames per workgroup always (A/B); 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
     int32_t ksplit;              /* 0: automatic; else K slices of dense1 */
     int32_t min_waves;           /* 7: conv layers on the quad-load kernel keep 64-channel slices while this many waves fit */
     int32_t waves;               /* 0: automatic (about 16 per CU); else waves per CU for the quad-load / span kernels */

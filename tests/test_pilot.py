@@ -341,7 +341,7 @@ def test_fused_head_rolling_bands_are_bit_identical_to_one_band_per_item(make_en
     assert np.array_equal(res[1][0], res[0][0])
 
 
-@pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((100, 132), 5), ((120, 160), 1)])
+@pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((240, 320), 77), ((100, 132), 5), ((120, 160), 1)])
 def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution
     kernel (trs_pilot_tuning.dense = 0): the same fp16 products, K split differently — fp32 summation order only.  n is not a multiple
@@ -354,7 +354,7 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     oh, ow = h, w
     for k, s_, _, _ in SPEC:
         oh, ow = (oh - k) // s_ + 1, (ow - k) // s_ + 1
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):                                      # 2: always 32 frames per workgroup (1 takes 64 where K is long: 240x320 with n >= 64)
         env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
         env.pilot_tuning(dense=int(mode))
         env.pilot_load(ws)
@@ -366,7 +366,9 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     want = torch_layer(7, l6["1"], ws)                                # fp32 dense1 on the kernel's own conv7 activation
     assert np.max(np.abs(h1s["1"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
     assert np.max(np.abs(h1s["0"] - h1s["1"])) <= 1e-3 * max(1.0, float(np.abs(h1s["0"]).max()))
-    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-4
+    assert np.max(np.abs(h1s["2"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
+    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-4 and np.max(np.abs(outs["2"] - outs["1"])) <= 1e-4
+    assert np.array_equal(l6["2"], l6["1"])
     assert n == 1 or np.std(outs["1"][:, 0]) > 1e-5
 
 

@@ -59,9 +59,12 @@ struct FParams {                        // ImgPreprocessing with dynamic brightn
     int color, n_filters;
     int lo[4], hi[4], dst_ch[4];
     int w0, w1;                         // brightness window: image rows [w0, w1) = img[40:119] (img_preprocessing.py:88)
-    int lds_off;                        // LDS: uint32 penv[4][H][4] | int esum[2][4][3] | int dbar | float edelta[4]
-    const int* hsv_tab;                 // [512] OpenCV's sdiv | hdiv fixed-point reciprocals (global, 2 KB, cache resident)
+    int lds_off;                        // LDS: uint32 penv[4][H][4] | int esum[2][4][3] | int dbar | (128 B) | dyn tables (kDynTabWords)
+    const unsigned* tabs;               // global, kDynTabWords: int hsv[512] (OpenCV's sdiv | hdiv fixed-point reciprocals) | rngb[768] (byte masks of the
+                                        // in-range tests per component value, range_byte_entry) | sel — staged into LDS once per launch (round 4: the
+                                        // resident worker's raster waves then issue NO loads in their steady state)
 };
+constexpr int kDynTabWords = 512 + 768 + 4;
 
 }  // namespace trsim
 
@@ -83,6 +86,7 @@ constexpr int kPhysWaves = (kBlock - kRasterThreads) / 64;
 using trsim::PParams;
 using trsim::RParams;
 using trsim::FParams;
+using trsim::kDynTabWords;
 
 // ---------------------------------------------------------------------------------------------
 // device pieces of the spec
@@ -499,11 +503,44 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
     }
 }
 
+// The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).
+// P = the TRIMMED pixel, bytes (r, g, b, x).  rngb[c * 256 + x] (range_byte_entry) has byte ch = 0xFF when value x of component c (h, s, v) lies
+// inside the range of the filter whose mask goes to channel ch, so the AND of three lookups is the pixel's masks in place; sel has 0xFF in the
+// channels that carry a mask (a later filter on the same channel replaces an earlier one, :57-63), the others keep the trimmed value.
+// (Round 3: one table lookup chain and one v_bfi per pixel instead of a bit test, a compare and a select per channel.)
+__device__ __forceinline__ unsigned mask_pixel(unsigned P, const int* tab, const unsigned* rngb, unsigned sel)
+{
+    const int r = (int)(P & 255u), g = (int)((P >> 8) & 255u), b = (int)((P >> 16) & 255u);
+    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+    const int sat = (__mul24(diff, tab[v]) + (1 << 11)) >> 12;             // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
+    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    h = (__mul24(h, tab[256 + diff]) + (1 << 11)) >> 12;
+    h = h < 0 ? h + 180 : h;
+    const unsigned m = rngb[min(h, 255)] & rngb[256 + min(sat, 255)] & rngb[512 + v];
+    return (m & sel) | (P & ~sel);
+}
+// entry i = c * 256 + x of the table above; *sel_out = the channels that carry a mask
+__host__ __device__ inline unsigned range_byte_entry(const unsigned (&lo)[4], const unsigned (&hi)[4], const int (&dst_ch)[4], int n_filters, int i, unsigned* sel_out)
+{
+    const int c = i >> 8, x = i & 255;
+    int fsel[3] = {-1, -1, -1};
+    for (int f = 0; f < n_filters; ++f) { const int dc = dst_ch[f]; if (dc >= 0 && dc <= 2) fsel[dc] = f; }
+    unsigned word = 0, sel = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        if (fsel[ch] < 0) continue;
+        const int l = (int)((lo[fsel[ch]] >> (8 * c)) & 255u), u = (int)((hi[fsel[ch]] >> (8 * c)) & 255u);
+        sel |= 0xFFu << (8 * ch);
+        if (x >= l && x <= u) word |= 0xFFu << (8 * ch);
+    }
+    if (sel_out) *sel_out = sel;
+    return word;
+}
+
 // ImgPreprocessing.__process of ONE colour with this frame's brightness delta (img_preprocessing.py:37-74,92-99): the
 // per-pixel arithmetic of trs_preprocess_kernel (OpenCV's fixed-point reciprocal tables are read from global memory)
-__device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t bgr, float deltaf)
+__device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, const unsigned* ltabs, uint32_t bgr, float deltaf)
 {
-    int t[3];
+    unsigned P = 0u;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float x = (float)((bgr >> (8 * ch)) & 255u);
@@ -512,27 +549,11 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
         x = x * f.contrast;
         x = x + f.offset;
         x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
-        t[ch] = (int)x;
+        P |= (unsigned)(int)x << (8 * ch);
     }
-    int o0 = t[0], o1 = t[1], o2 = t[2];
-    if (f.color) {
-        const int r = t[0], g = t[1], b = t[2];
-        const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
-        const int sdiv = f.hsv_tab[v], hdiv = f.hsv_tab[256 + diff];
-        const int sat = (__mul24(diff, sdiv) + (1 << 11)) >> 12;           // 24-bit multiplies: full rate (operands far below 2^23)
-        int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-        h = (__mul24(h, hdiv) + (1 << 11)) >> 12;
-        if (h < 0) h += 180;
-        const int hh = min(h, 255), ss = min(sat, 255);
-        for (int k = 0; k < f.n_filters; ++k) {
-            const int lh = f.lo[k] & 255, ls = (f.lo[k] >> 8) & 255, lv = (f.lo[k] >> 16) & 255;
-            const int uh = f.hi[k] & 255, us = (f.hi[k] >> 8) & 255, uv = (f.hi[k] >> 16) & 255;
-            const int m = (hh >= lh && hh <= uh && ss >= ls && ss <= us && v >= lv && v <= uv) ? 255 : 0;
-            const int dc = f.dst_ch[k];
-            o0 = dc == 0 ? m : o0; o1 = dc == 1 ? m : o1; o2 = dc == 2 ? m : o2;
-        }
-    }
-    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+    // the masks through the LDS tables (the arithmetic of trs_preprocess_kernel's mask_pixel: OpenCV's reciprocals, then three byte-mask lookups)
+    if (f.color) P = mask_pixel(P, reinterpret_cast<const int*>(ltabs), ltabs + 512, ltabs[512 + 768]);
+    return P;
 }
 
 
@@ -545,8 +566,18 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, uint32_t
 // this launch has done before this one (the same in every raster wave): the barrier counter and the parity of the sum slots follow it.
 // LDS at f.lds_off: uint32 penv[kDynBatch][H][4] | int esum[2][kDynBatch][3] | int dbar — zeroed (esum, dbar) once per launch.
 // Shared by trs_step_kernel<., true> and trs_worker_kernel<., true>: the same instructions, bit-identical frames.
+#ifndef TRS_DYN_ABLATE
+#define TRS_DYN_ABLATE 0   /* timing-only diagnostic builds (scripts/r04_dyn_ablate.sh), never shipped: 1 no classification in phase A, 2 no filter arithmetic in phase B, 3 no stores in phase C */
+#endif
 constexpr int kDynBatch = 4;
-__host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128; }
+__host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128 + ((kDynTabWords * 4 + 15) & ~15); }
+// the tables behind the batch's palettes and sums (staged by dyn_stage_tables before the launch's first barrier)
+__device__ __forceinline__ unsigned* dyn_tabs_lds(unsigned char* lds_base, const FParams& f, int H) { return reinterpret_cast<unsigned*>(lds_base + f.lds_off + kDynBatch * H * 16 + 128); }
+__device__ __forceinline__ void dyn_stage_tables(unsigned char* lds_base, const FParams& f, int H, int tid, int nthreads)
+{
+    unsigned* const dst = dyn_tabs_lds(lds_base, f, H);
+    for (int i = tid; i < kDynTabWords; i += nthreads) dst[i] = f.tabs[i];
+}
 
 // The team barrier of raster_dyn_batch: a BOUNDED spin.  Every 1024 polls (~30 us) it asks `bail(first)` whether to give up — the resident worker
 // answers from its abort bit and its safety deadline (a wave of the team that left at an aborted wait_posted never arrives here: ADVICE r03); a
@@ -606,7 +637,11 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
             unsigned packs[kDynBatch];
 #pragma unroll
+#if TRS_DYN_ABLATE == 1   /* timing-only: phase A without its classification */
+            for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = 0u;
+#else
             for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = (v >= p.uni_rows && bi < nb) ? classify4(v, cams[bi]) : 0u;
+#endif
 #pragma unroll
             for (int bi = 0; bi < kDynBatch; ++bi) {
 #pragma unroll
@@ -650,11 +685,24 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         float dlt[kDynBatch];
 #pragma unroll
         for (int bi = 0; bi < kDynBatch; ++bi) dlt[bi] = __shfl(dl, bi, 64);
-        for (int t = tid; t < kDynBatch * per_env; t += kRasterThreads) {
-            const int bi = t / per_env, ent = t - bi * per_env;
+        // items: a uniform row (sky, beyond the far plane: its four classes share one colour) is filtered ONCE and written four times; a
+        // ground row's four entries are four items.  1,332 items instead of 1,920 entries per batch of four 120-row frames.
+        const unsigned* const ltabs = dyn_tabs_lds(lds_base, f, p.H);
+        const int items_env = p.uni_rows + 4 * (p.H - p.uni_rows);
+        for (int t = tid; t < kDynBatch * items_env; t += kRasterThreads) {
+            const int bi = t / items_env, it_e = t - bi * items_env;
             if (bi >= nb) break;
             const float deltaf = bi == 0 ? dlt[0] : (bi == 1 ? dlt[1] : (bi == 2 ? dlt[2] : dlt[3]));
-            penv[t] = filter_colour_dev(f, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)), deltaf);
+            const bool uni = it_e < p.uni_rows;
+            const int ent = uni ? 4 * it_e : it_e + 3 * p.uni_rows;          // palette entry (row * 4 + class) of this item
+#if TRS_DYN_ABLATE == 2   /* timing-only: phase B without the filter arithmetic */
+            const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)) + (unsigned)deltaf;
+#else
+            const uint32_t c = filter_colour_dev(f, ltabs, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)), deltaf);
+#endif
+            uint32_t* const dst = penv + bi * per_env + ent;
+            dst[0] = c;
+            if (uni) { dst[1] = c; dst[2] = c; dst[3] = c; }
         }
         if (tid < kDynBatch * 3) esum[(par ^ 1) * kDynBatch * 3 + tid] = 0;   // the next batch's sums start from zero (nobody reads that half now)
     }
@@ -689,12 +737,16 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
             const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
             const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
+#if TRS_DYN_ABLATE == 3   /* timing-only: phase C without its stores */
+            asm volatile("" :: "v"(px3.x), "v"(px3.y), "v"(px3.z)); (void)rsrc; (void)drs;
+#else
             __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, rth.col_off + v * rth.row_bytes, 0, TRS_STORE_AUX);
             if constexpr (DEPTH) {
                 const unsigned dz = __float_as_uint(rth.lrowdepth[v]);
                 const u4v d4 = {dz, dz, dz, dz};
                 __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (rth.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
             }
+#endif
         }
     }
     return true;

@@ -34,6 +34,7 @@ struct trs_env {
     int32_t* mux_state = nullptr; int mux_tick = 0;   // ControlMultiplexer state per car (trs_control_mux)
     uint8_t *tmp_in = nullptr, *tmp_out = nullptr; float* tmp_f = nullptr; size_t tmp_cap = 0;   // host-frame staging
     int* hsv_tab = nullptr;
+    unsigned* dyn_tab = nullptr;        // FParams::tabs of the dynamic-brightness frame filter that is set (hsv reciprocals | in-range byte masks | sel)
     unsigned char* edge_scratch = nullptr; size_t edge_scratch_bytes = 0;   // work arrays of the Canny layer for frames beyond LDS
     trsim::PParams pp{};
     trsim::RParams rp{};

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
-    if constexpr (DYN) { if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0; }   // esum[2][4][3], dbar
+    if constexpr (DYN) {
+        if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0;   // esum[2][4][3], dbar
+        dyn_stage_tables(smem, sp.fp, p.H, tid, kBlock);                   // OpenCV's reciprocals + the in-range byte masks (behind the prologue's barrier)
+    }
     // ---- prologue: everything is staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves
     // 64 lanes x 16 B = 1 KB, lane-linear, no registers and no ds_write pass), all requests are in flight together and
     // one workgroup barrier closes the stage.  Raster waves: the class map + row tables (one linear image at LDS offset
@@ -289,38 +292,6 @@ struct PreParams {
     size_t scratch_stride;
 };
 
-// The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).
-// P = the TRIMMED pixel, bytes (r, g, b, x).  rngb[c * 256 + x] (built per launch by range_byte_table) has byte ch = 0xFF when value x of
-// component c (h, s, v) lies inside the range of the filter whose mask goes to channel ch, so the AND of three lookups is the pixel's masks in
-// place; sel has 0xFF in the channels that carry a mask (a later filter on the same channel replaces an earlier one, :57-63), the others keep the
-// trimmed value.  (Round 3: one table lookup chain and one v_bfi per pixel instead of a bit test, a compare and a select per channel.)
-__device__ __forceinline__ unsigned mask_pixel(unsigned P, const int* tab, const unsigned* rngb, unsigned sel)
-{
-    const int r = (int)(P & 255u), g = (int)((P >> 8) & 255u), b = (int)((P >> 16) & 255u);
-    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
-    const int sat = (__mul24(diff, tab[v]) + (1 << 11)) >> 12;             // 24-bit multiplies: full rate (diff <= 255, the reciprocals < 2^21; 32-bit integer multiplies are quarter rate)
-    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-    h = (__mul24(h, tab[256 + diff]) + (1 << 11)) >> 12;
-    h = h < 0 ? h + 180 : h;
-    const unsigned m = rngb[min(h, 255)] & rngb[256 + min(sat, 255)] & rngb[512 + v];
-    return (m & sel) | (P & ~sel);
-}
-// entry i = c * 256 + x of the table above; *sel_out = the channels that carry a mask
-__device__ __forceinline__ unsigned range_byte_entry(const unsigned (&lo)[4], const unsigned (&hi)[4], const int (&dst_ch)[4], int n_filters, int i, unsigned* sel_out)
-{
-    const int c = i >> 8, x = i & 255;
-    int fsel[3] = {-1, -1, -1};
-    for (int f = 0; f < n_filters; ++f) { const int dc = dst_ch[f]; if (dc >= 0 && dc <= 2) fsel[dc] = f; }
-    unsigned word = 0, sel = 0;
-    for (int ch = 0; ch < 3; ++ch) {
-        if (fsel[ch] < 0) continue;
-        const int l = (int)((lo[fsel[ch]] >> (8 * c)) & 255u), u = (int)((hi[fsel[ch]] >> (8 * c)) & 255u);
-        sel |= 0xFFu << (8 * ch);
-        if (x >= l && x <= u) word |= 0xFFu << (8 * ch);
-    }
-    if (sel_out) *sel_out = sel;
-    return word;
-}
 // four pixels (r, g, b, x) -> the 12 bytes of their group (the rasteriser's byte shuffles)
 __device__ __forceinline__ u3v pack_rgb4(unsigned P0, unsigned P1, unsigned P2, unsigned P3)
 {
@@ -968,9 +939,9 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
             sp.fp.dst_ch[k] = c.dst_channel[k];
         }
         sp.fp.w0 = std::min(40, e->H); sp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
-        sp.fp.hsv_tab = e->hsv_tab;
+        sp.fp.tabs = e->dyn_tab;
         sp.fp.lds_off = (lds + 15) & ~15;
-        lds = sp.fp.lds_off + 4 * e->H * 16 + 128;                         // palettes of a batch of 4 envs + channel sums + barrier counter
+        lds = sp.fp.lds_off + dyn_lds_bytes(e->H);                         // palettes of a batch of 4 envs + channel sums + barrier counter + the mask tables
     }
     const dim3 grid(grid_of(e)), block(kBlock);
     if (dyn) {
@@ -1162,7 +1133,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     for (void* sc : e->scratch) (void)hipFree(sc);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->fault) (void)hipHostFree(e->fault);
-    (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab);
+    (void)hipFree(e->pre); (void)hipFree(e->tmp_in); (void)hipFree(e->tmp_out); (void)hipFree(e->tmp_f); (void)hipFree(e->hsv_tab); (void)hipFree(e->dyn_tab);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->sP) (void)hipStreamDestroy(e->sP);
     delete e;
@@ -1260,7 +1231,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         const int epw = k.envs_per_wg;
         const int free_b = 160 * 1024 - n_lds_step - epw * 4 - 16 - epw * 16;
         n_max_spl = std::max(1, std::min(16, free_b / (epw * 16)));
-        const int free_dyn = free_b - (4 * e->H * 16 + 160);
+        const int free_dyn = free_b - (dyn_lds_bytes(e->H) + 32);
         n_max_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
         if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
     }
@@ -1590,6 +1561,28 @@ int ensure_hsv_table(trs_env* e)
     return TRS_OK;
 }
 
+// the tables the DYN step kernels stage into LDS (FParams::tabs): OpenCV's reciprocals | the in-range byte masks of THIS filter | sel
+int upload_dyn_tables(trs_env* e, const trs_pre_config& c)
+{
+    int rc = ensure_hsv_table(e);
+    if (rc) return rc;
+    std::vector<unsigned> t(kDynTabWords, 0u);
+    HIPCHK(hipMemcpy(t.data(), e->hsv_tab, 512 * sizeof(int), hipMemcpyDeviceToHost));
+    unsigned lo[4], hi[4]; int dc[4];
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = c.hsv_lo[k][0] | (c.hsv_lo[k][1] << 8) | (c.hsv_lo[k][2] << 16);
+        hi[k] = c.hsv_hi[k][0] | (c.hsv_hi[k][1] << 8) | (c.hsv_hi[k][2] << 16);
+        dc[k] = c.dst_channel[k];
+    }
+    unsigned sel = 0;
+    for (int i = 0; i < 768; ++i) t[512 + i] = range_byte_entry(lo, hi, dc, c.n_filters, i, &sel);
+    t[512 + 768] = sel;
+    { int rq = quiesce(e); if (rq) return rq; HIPCHK(hipStreamSynchronize(e->sP)); }   // a running kernel may still be staging the old tables
+    if (!e->dyn_tab) HIPCHK(hipMalloc((void**)&e->dyn_tab, kDynTabWords * sizeof(unsigned)));
+    HIPCHK(hipMemcpy(e->dyn_tab, t.data(), kDynTabWords * sizeof(unsigned), hipMemcpyHostToDevice));
+    return TRS_OK;
+}
+
 // ImgPreprocessing.__process of ONE colour (img_preprocessing.py:37-74,92-99 without dynamic brightness and Canny):
 // the host twin of trs_preprocess_kernel's per-pixel arithmetic, used to filter the rasteriser's palette.
 uint32_t filter_colour(const trs_pre_config& c, uint32_t bgr)
@@ -1705,7 +1698,7 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
                 return fail(TRS_ERR_LIMIT, "the resident worker's LDS (tables + env state + hand-off ring) leaves no room for the dynamic-brightness palettes of a batch: "
                                            "select TRS_STEP_LAUNCH for this filter, or use trs_preprocess");
         }
-        if (c->dynamic_brightness) { HIPCHK(hipSetDevice(e->device)); rc = ensure_hsv_table(e); if (rc) return rc; }
+        if (c->dynamic_brightness) { HIPCHK(hipSetDevice(e->device)); rc = upload_dyn_tables(e, *c); if (rc) return rc; }
         e->frame_filter = *c; e->has_frame_filter = true; e->filter_dynamic = c->dynamic_brightness != 0;
     } else {
         e->has_frame_filter = false;

@@ -1753,42 +1753,54 @@ struct DenseParams {
     int n, G, gps, KS, groups;
 };
 
+#ifndef TRS_DENSE_ABLATE
+#define TRS_DENSE_ABLATE 0   /* timing-only diagnostic builds (scripts/r04_dense_ablate.sh), never shipped */
+#endif
 constexpr int kDenseChunk = 72;            // granules per LDS chunk = 36 k-steps
 constexpr int kDensePitch = 73;            // LDS row pitch in granules (odd: 16 lanes cover all 64 banks)
 constexpr int kDenseSteps = kDenseChunk / 2;
-constexpr int kDenseStage = 9;             // granules a thread stages per chunk (32 x 72 / 256)
-constexpr int kDenseLds = 2 * 32 * kDensePitch * 16;
+constexpr int kDenseStage = 9;             // granules a thread stages per chunk and per 32 frames (32 x 72 / 256)
+constexpr int kDenseLds = 2 * 32 * kDensePitch * 16;   // per 32 frames (NF = 2: twice that)
 
+// NF = frame blocks of 32 per workgroup.  NF = 2 (round 4, long K: 240x320): every weight fragment feeds TWO MFMAs (frames 0..31 and 32..63), so the
+// weight stream — per-lane 16-byte loads straight from L2, 1.18 MB per workgroup at 512 x 240x320, measured as 15 of the kernel's 37 us by a
+// timing-only build (profiles/r04_pilot_dense.txt) — is halved for the same arithmetic; 150 KB of LDS, one workgroup per CU.
+template <int NF>
 __global__ __launch_bounds__(256) void trs_pilot_dense_kernel(const DenseParams p)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int group = idx % p.groups, slice = xcd + 8 * (idx / p.groups);
     if (slice >= p.KS) return;                                              // the grid is padded to whole rounds of 8 slices
-    u4v* const st = reinterpret_cast<u4v*>(psmem);                          // [2][32][73] granules
+    u4v* const st = reinterpret_cast<u4v*>(psmem);                          // [2][32 NF][73] granules
     const int gs = slice * p.gps, ge = min(p.G, gs + p.gps);
-    const int f0 = group * 32;
+    const int f0 = group * 32 * NF;
+    constexpr int kStage = kDenseStage * NF, kBuf = 32 * NF * kDensePitch;
 
-    // staging: thread t moves granules e = t + 256 i (i < 9) of a chunk: frame e / 72, granule e % 72
-    int sbase[kDenseStage], sdst[kDenseStage];
+    // staging: thread t moves granules e = t + 256 i (i < 9 NF) of a chunk: frame e / 72, granule e % 72
+    int sbase[kStage], sdst[kStage];
 #pragma unroll
-    for (int i = 0; i < kDenseStage; ++i) {
+    for (int i = 0; i < kStage; ++i) {
         const int e = tid + 256 * i, f = e / kDenseChunk, gi = e - f * kDenseChunk;
         sbase[i] = min(f0 + f, p.n - 1) * p.G;
         sdst[i] = f * kDensePitch + gi;
     }
-    u4v pf[kDenseStage];
+    u4v pf[kStage];
     auto stage_load = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < kDenseStage; ++i) {
+        for (int i = 0; i < kStage; ++i) {
             const int e = tid + 256 * i, f = e / kDenseChunk, gi = e - f * kDenseChunk;
+#if TRS_DENSE_ABLATE == 2   /* timing-only: every chunk re-reads the slice's first chunk (cache hits instead of the HBM stream) */
+            pf[i] = p.act[sbase[i] + min(gs + gi, p.G - 1)]; (void)c0;
+#else
             pf[i] = p.act[sbase[i] + min(c0 + gi, p.G - 1)];
+#endif
         }
     };
     auto stage_write = [&](int buf) {
-        u4v* const sn = st + buf * (32 * kDensePitch);
+        u4v* const sn = st + buf * kBuf;
 #pragma unroll
-        for (int i = 0; i < kDenseStage; ++i) sn[sdst[i]] = pf[i];
+        for (int i = 0; i < kStage; ++i) sn[sdst[i]] = pf[i];
     };
     // weight ring: granule 2 j + h of the chunk for k-step j, this wave's 32 channels
     u4v wr[kDenseSteps];
@@ -1798,20 +1810,28 @@ __global__ __launch_bounds__(256) void trs_pilot_dense_kernel(const DenseParams 
 #pragma unroll
     for (int j = 0; j < kDenseSteps; ++j) ring_load(j, gs);
 
-    f32x16 acc;
+    f32x16 acc[NF];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = slice == 0 ? p.bias[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.0f;
+    for (int b = 0; b < NF; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = slice == 0 ? p.bias[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] : 0.0f;
     stage_write(0);
     __syncthreads();
 
     auto chunk = [&](int c0, int buf, auto prefetch) {
-        const u4v* const sb = st + buf * (32 * kDensePitch) + r * kDensePitch + h;
+        const u4v* const sb = st + buf * kBuf + r * kDensePitch + h;
 #pragma unroll
         for (int j = 0; j < kDenseSteps; ++j) {
-            u4v a = sb[2 * j];
-            if (c0 + 2 * j >= ge) a = u4v{0u, 0u, 0u, 0u};                  // ragged last chunk: a zero fragment instead of a branch
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, a), acc, 0, 0, 0);
+            const bool past = c0 + 2 * j >= ge;                             // ragged last chunk: a zero fragment instead of a branch
+#pragma unroll
+            for (int b = 0; b < NF; ++b) {
+                u4v a = sb[b * 32 * kDensePitch + 2 * j];
+                if (past) a = u4v{0u, 0u, 0u, 0u};
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wr[j]), __builtin_bit_cast(h16x8, a), acc[b], 0, 0, 0);
+            }
+#if TRS_DENSE_ABLATE != 1   /* 1: timing-only, the weights of the first chunk serve every chunk (no weight stream) */
             if constexpr (decltype(prefetch)::value) ring_load(j, c0 + kDenseChunk);
+#endif
         }
     };
     int c0 = gs, buf = 0;
@@ -1825,13 +1845,17 @@ __global__ __launch_bounds__(256) void trs_pilot_dense_kernel(const DenseParams 
 
     {   // D[cout][frame]: lane = frame r, registers 4 q4 .. + 3 = channels 32 wave + 8 q4 + 4 h .. + 3: one 16-byte store each
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slab, 0, (int)((size_t)p.KS * p.n * 400), 0x00020000);
-        const int row = ((slice * p.n + f0 + r) * 100) * 4;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int c = wave * 32 + 8 * q4 + 4 * h;
-            if (c < 100 && f0 + r < p.n) {
-                const u4v v = {__float_as_uint(acc[4 * q4]), __float_as_uint(acc[4 * q4 + 1]), __float_as_uint(acc[4 * q4 + 2]), __float_as_uint(acc[4 * q4 + 3])};
-                __builtin_amdgcn_raw_buffer_store_b128(v, rs, row + c * 4, 0, 0);
+        for (int b = 0; b < NF; ++b) {
+            const int fr = f0 + 32 * b + r;
+            const int row = ((slice * p.n + fr) * 100) * 4;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = wave * 32 + 8 * q4 + 4 * h;
+                if (c < 100 && fr < p.n) {
+                    const u4v v = {__float_as_uint(acc[b][4 * q4]), __float_as_uint(acc[b][4 * q4 + 1]), __float_as_uint(acc[b][4 * q4 + 2]), __float_as_uint(acc[b][4 * q4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, row + c * 4, 0, 0);
+                }
             }
         }
     }
@@ -2210,27 +2234,43 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     return TRS_OK;
 }
 
-// K slices of trs_pilot_dense_kernel: whole LDS chunks, as many slices as give every CU a workgroup (groups of 32 frames x slices)
-void dense_plan(const ConvLayer& l, int n, int cu_count, const trs_pilot_tuning& T, int* gps, int* ks)
+// K slices of trs_pilot_dense_kernel: whole LDS chunks, as many slices as give every CU a workgroup (groups of 32 NF frames x slices).
+// NF = 2 (64 frames per workgroup share every weight fragment) where the K dimension is long enough that every workgroup still gets two
+// chunks or more (240x320: 8,816 granules; at 120x160 a slice is one chunk and the kernel is launch-bound: NF = 1).
+void dense_plan(const ConvLayer& l, int n, int cu_count, const trs_pilot_tuning& T, int* gps, int* ks, int* nf_out = nullptr)
 {
-    const int groups = (n + 31) / 32, G = l.G;
+    const int G = l.G, chunks = (G + kDenseChunk - 1) / kDenseChunk;
+    int nf = 1;
+    {
+        const int groups2 = (n + 63) / 64, want2 = std::max(1, cu_count / groups2);
+        if (n >= 64 && (chunks + want2 - 1) / want2 >= 2) nf = 2;
+        if (T.dense == 2) nf = 1;                                           // tuning: dense = 2 keeps 32 frames per workgroup (A/B)
+    }
+    const int groups = (n + 32 * nf - 1) / (32 * nf);
     int want = std::max(1, cu_count / groups);
     if (T.ksplit > 0) want = T.ksplit;
-    const int chunks = (G + kDenseChunk - 1) / kDenseChunk;
     const int cps = std::max(1, (chunks + want - 1) / want);
     *gps = cps * kDenseChunk;
     *ks = (G + *gps - 1) / *gps;
+    if (nf_out) *nf_out = nf;
 }
 
 int launch_dense(PilotCtx* c, const ConvLayer& l, const void* in, int n, void* slab, hipStream_t s)
 {
     DenseParams q{};
     q.act = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.slab = static_cast<float*>(slab);
-    q.n = n; q.G = l.G; q.groups = (n + 31) / 32;
-    dense_plan(l, n, c->cu_count, c->tun, &q.gps, &q.KS);
+    int nf = 1;
+    q.n = n; q.G = l.G;
+    dense_plan(l, n, c->cu_count, c->tun, &q.gps, &q.KS, &nf);
+    q.groups = (n + 32 * nf - 1) / (32 * nf);
     const int grid = q.groups * ((q.KS + 7) / 8) * 8;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_pilot_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLds));
-    hipLaunchKernelGGL(trs_pilot_dense_kernel, dim3(grid), dim3(256), kDenseLds, s, q);
+    if (nf == 2) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_pilot_dense_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kDenseLds));
+        hipLaunchKernelGGL(trs_pilot_dense_kernel<2>, dim3(grid), dim3(256), 2 * kDenseLds, s, q);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_pilot_dense_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kDenseLds));
+        hipLaunchKernelGGL(trs_pilot_dense_kernel<1>, dim3(grid), dim3(256), kDenseLds, s, q);
+    }
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }

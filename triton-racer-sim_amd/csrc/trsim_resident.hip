@@ -373,7 +373,10 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
     if (tid < kSlots) l.arrive[tid] = 0;
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
-    if constexpr (DYN) { if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0; }   // channel sums, team-barrier counter
+    if constexpr (DYN) {
+        if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0;   // channel sums, team-barrier counter
+        dyn_stage_tables(smem, wp.fp, p.H, tid, kBlock);                   // the filter's tables, once per launch: the raster waves' steady state issues no loads
+    }
     if (!raster_team)
         for (int j = pw; j < n_loc; j += kPhysWaves) {
             EnvRegs st;
@@ -805,7 +808,7 @@ int worker_launch(trs_env* e, uint64_t start)
             wp.fp.dst_ch[k] = c.dst_channel[k];
         }
         wp.fp.w0 = std::min(40, e->H); wp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
-        wp.fp.hsv_tab = e->hsv_tab;
+        wp.fp.tabs = e->dyn_tab;
         wp.fp.lds_off = R->lds_off_dyn;
     }
     if (e->rp.depth) { if (dyn) hipLaunchKernelGGL((trs_worker_kernel<true, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
