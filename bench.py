@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--no-render", action="store_true", help="physics only (BASELINE configs[1] shape)")
     ap.add_argument("--pilot", action="store_true", help="closed loop with cnn_2d_speed_control inference on the device frame each step (BASELINE configs[4] shape)")
     ap.add_argument("--depth", action="store_true", help="also write the binary32 depth frame (BASELINE configs[4] frame format)")
-    ap.add_argument("--pilot-tuning", default="", help="with --pilot: kernel choices for measurements, e.g. frame5_f=1,frame_ohb=0:0:0:13 (fields of trs_pilot_tuning, include/trsim.h)")
+    ap.add_argument("--pilot-tuning", default="", help="with --pilot: kernel choices for measurements, e.g. dense=2,ksplit=32 (fields of trs_pilot_tuning, include/trsim.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the informational 8-steps-per-launch leg (profiling runs: only the timed kernel in the trace)")
     ap.add_argument("--profile-mode", action="store_true", help="for rocprofv3 runs (scripts/profile.sh): no clock pre-warm, and a resident worker is asked to leave after the "
@@ -380,7 +380,7 @@ def main():
     if args.pilot:
         ws, macs = pilot_weights(args.img_h, args.img_w)
         if args.pilot_tuning:
-            env.pilot_tuning(**{k: ([int(x) for x in v.split(":")] if ":" in v else int(v)) for k, v in (kv.split("=") for kv in args.pilot_tuning.split(","))})
+            env.pilot_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.pilot_tuning.split(","))})
         env.pilot_load(ws)
         pilot_flops = 2.0 * macs
         run = lambda k_: env.step_pilot(k_)

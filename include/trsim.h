@@ -331,32 +331,16 @@ void trs_default_pilot_config(trs_pilot_config* cfg);
  * trs_pilot_load (NULL = back to the defaults). */
 typedef struct trs_pilot_tuning {
     uint32_t struct_size;
-    int32_t no_fuse;             /* 0; 1: conv1 and conv2 as separate kernels (trs_conv_u8_kernel, trs_conv_span / _lt_kernel) */
-    int32_t fuse_band_r2;        /* 6: conv2 rows per band of the band-form head (trs_conv12_band_kernel); 0: direct form (trs_conv12_kernel) */
-    int32_t fuse_r2;             /* 6: conv2 rows per band of the direct form */
-    int32_t fuse_wsplit_max;     /* 4: a band may be cut into up to this many parts in width (240x320 needs 2); 1: never */
+    int32_t no_fuse;             /* 0; 1: conv1 and conv2 as separate kernels (trs_conv_u8_kernel, trs_conv_span_kernel) */
+    int32_t fuse_band_r2;        /* 6: conv2 rows per band of the fused head (trs_conv12_band_kernel); 0: never fuse */
+    int32_t fuse_wsplit_max;     /* 4: a band may be cut into up to this many parts in width (240x320 needs 2); 1: never (a frame whose whole-width band does not fit LDS then runs unfused) */
     int32_t fuse_roll;           /* 1: with a (frame, part) per CU or more, a workgroup walks a frame's bands top to bottom and computes the 3 conv1 rows two bands share once; 0: never */
-    int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel */
+    int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel (else trs_conv_lt_kernel) */
     int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel when whole input frames fit LDS; 0: span kernel; 2: also in row bands */
-    int32_t frame5_bands;        /* 0: automatic; else at least this many row bands */
-    int32_t frame5_f;            /* 0: automatic (one frame per 4-wave workgroup, two workgroups per CU, where 2-3 frames fit a CU); else this many frames per workgroup (as far as they fit) */
-    int32_t frame_layers_mask;   /* 0x78: bit i = conv(i+1) (3x3 layers) on trs_conv_frame_kernel where its input fits LDS */
-    int32_t frame_bands[4];      /* conv4..conv7: 0 automatic, else at least this many row bands */
-    int32_t frame_ohb[4];        /* conv4..conv7: 0 automatic, else output rows per band (the last band takes what is left) */
-    int32_t frame_f;             /* 0: automatic; else frames (units) per workgroup */
-    int32_t frame_deep;          /* 0; 1: the deep-ring instantiation (measured slower, kept for A/B) */
-    int32_t frame_block;         /* 0: 512 threads per workgroup; 256: four waves per workgroup, two workgroups per CU where their LDS images fit side by side */
-    int32_t frame_nt;            /* 0: automatic (2 or 3 tiles of 32 pixels per wave item); 2 or 3 forces it */
+    int32_t frame_layers_mask;   /* 0x78: bit i = conv(i+1) (3x3 layers) on trs_conv_frame_kernel where its input fits LDS (else trs_conv_lt_kernel) */
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
-    int32_t chain_nt;            /* 0: automatic per layer; 2 or 3 forces it (32-pixel tiles per wave item) */
-    int32_t chain_nb;            /* 2: 64 output channels per wave item (default); 1: 32; 0: 32 only where 64 would leave half of the waves without an item (measured: no faster) */
-    int32_t chain_f;             /* 0: automatic (4 frames per workgroup of 8 waves while the grid fills the chip, else 2); 2: two frames per workgroup of 4 waves, two workgroups per CU */
-    int32_t dense;               /* 1: dense1 / dense4 on trs_pilot_dense_kernel (64 frames per workgroup where K is long: 240x320); 2: the same with 32 frames per workgroup always (A/B); 0: the chunked 1x1-convolution kernel (trs_conv_mfma_kernel) */
+    int32_t dense;               /* 1: dense1 / dense4 with 64 frames per workgroup where K is long (240x320), else 32; 2: always 32 (A/B) */
     int32_t ksplit;              /* 0: automatic; else K slices of dense1 */
-    int32_t min_waves;           /* 7: conv layers on the quad-load kernel keep 64-channel slices while this many waves fit */
-    int32_t waves;               /* 0: automatic (about 16 per CU); else waves per CU for the quad-load / span kernels */
-    int32_t nt_mb;               /* 128: activations larger than this many MB leave with non-temporal stores */
-    int32_t nt_kind;             /* 1: nt; 2: sc0 sc1 */
 } trs_pilot_tuning;
 void trs_default_pilot_tuning(trs_pilot_tuning* t);
 int trs_pilot_set_tuning(trs_env* env, const trs_pilot_tuning* t_or_null);

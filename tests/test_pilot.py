@@ -282,12 +282,13 @@ def test_closed_loop_is_unaffected_by_another_stream(make_env):
 
 @pytest.mark.parametrize("size,wsplit", [((120, 160), None), ((240, 320), None), ((240, 320), 1), ((100, 132), None), ((130, 300), None)])
 def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
-    """conv1 -> conv2 fused (conv1's activation stays in LDS) against the two separate kernels.  The direct form (240x320 with
-    trs_pilot_tuning.fuse_wsplit_max = 1: bands may not be cut in width) feeds the same fp16 values into the same MFMA order: bit-identical.
+    """conv1 -> conv2 fused (conv1's activation stays in LDS; trs_conv12_band_kernel) against the two separate kernels (trs_pilot_tuning.no_fuse).
     The band form (120x160; 240x320 and 130x300 cut in two parts of conv2 columns, the last part narrower) keeps the conv1 tile
     split by column parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another
     summation order, so an output can land on the neighbouring fp16 value — at most one ulp (2^-10 relative), on a small fraction
-    of the elements."""
+    of the elements.  240x320 with fuse_wsplit_max = 1 (a band may not be cut in width, and a whole-width band does not fit LDS): the
+    library falls back to the two layers by itself (round 4 removed the direct form of the fused head) — bit-identical by construction,
+    and both activations are also checked against the PyTorch mirror."""
     h, w = size
     n = 21
     ws = make_weights(h, w, seed=3)
@@ -308,6 +309,9 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
     env.pilot_load(ws)                                                # the choice is read when the weights are loaded
     plain_out = env.pilot_forward_host(frames)
     plain_l1 = env.pilot_layer(1, (n, oh2, ow2, 32))
+    mirror_l1 = torch_layer(1, torch_layer(0, frames, ws), ws)         # conv2 of the PyTorch mirror on its own conv1 (fp16-rounded weights and activations)
+    dm = np.abs(plain_l1 - mirror_l1)
+    assert (dm <= 2.0 ** -9 * np.abs(mirror_l1) + 4e-4).all(), float(dm.max())   # two layers of summation-order roundings
     if wsplit == 1:
         assert np.array_equal(fused_l1, plain_l1)
         assert np.array_equal(fused_out, plain_out)
@@ -342,10 +346,12 @@ def test_fused_head_rolling_bands_are_bit_identical_to_one_band_per_item(make_en
 
 
 @pytest.mark.parametrize("size,n", [((120, 160), 77), ((240, 320), 40), ((240, 320), 77), ((100, 132), 5), ((120, 160), 1)])
-def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
-    """dense1 on trs_pilot_dense_kernel (32 frames x one K slice per workgroup, the default) against the chunked 1x1-convolution
-    kernel (trs_pilot_tuning.dense = 0): the same fp16 products, K split differently — fp32 summation order only.  n is not a multiple
-    of 32 (ragged last frame group) and spans several groups; 240x320 needs several LDS chunks per slice and a ragged last one."""
+def test_dense_kernel_against_torch_in_both_frame_groupings(make_env, size, n):
+    """dense1 on trs_pilot_dense_kernel against fp32 PyTorch on the kernel's own conv7 activation (the chunked 1x1-convolution kernel it
+    was compared with until round 3 is gone), in both of its forms: 64 frames per workgroup where K is long (the default at 240x320 with
+    n >= 64) and 32 frames per workgroup (trs_pilot_tuning.dense = 2) — the same fp16 products, K and frames split differently: fp32
+    summation order only.  n is not a multiple of 32 / 64 (ragged last frame group) and spans several groups; 240x320 needs several LDS
+    chunks per slice and a ragged last one."""
     h, w = size
     ws = make_weights(h, w, seed=5)
     rng = np.random.default_rng(11)
@@ -354,7 +360,7 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
     oh, ow = h, w
     for k, s_, _, _ in SPEC:
         oh, ow = (oh - k) // s_ + 1, (ow - k) // s_ + 1
-    for mode in ("0", "1", "2"):                                      # 2: always 32 frames per workgroup (1 takes 64 where K is long: 240x320 with n >= 64)
+    for mode in ("1", "2"):                                           # 2: always 32 frames per workgroup (1 takes 64 where K is long: 240x320 with n >= 64)
         env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
         env.pilot_tuning(dense=int(mode))
         env.pilot_load(ws)
@@ -362,12 +368,10 @@ def test_dense_kernel_against_the_chunked_kernel(make_env, size, n):
             outs[mode] = env.pilot_forward_host(frames)
         h1s[mode] = env.pilot_layer(7, (n, 100))
         l6[mode] = env.pilot_layer(6, (n, oh, ow, 128))
-    assert np.array_equal(l6["0"], l6["1"])
     want = torch_layer(7, l6["1"], ws)                                # fp32 dense1 on the kernel's own conv7 activation
     assert np.max(np.abs(h1s["1"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
-    assert np.max(np.abs(h1s["0"] - h1s["1"])) <= 1e-3 * max(1.0, float(np.abs(h1s["0"]).max()))
     assert np.max(np.abs(h1s["2"] - want)) <= 1e-3 * max(1.0, float(np.abs(want).max()))
-    assert np.max(np.abs(outs["0"] - outs["1"])) <= 1e-4 and np.max(np.abs(outs["2"] - outs["1"])) <= 1e-4
+    assert np.max(np.abs(outs["2"] - outs["1"])) <= 1e-4
     assert np.array_equal(l6["2"], l6["1"])
     assert n == 1 or np.std(outs["1"][:, 0]) > 1e-5
 

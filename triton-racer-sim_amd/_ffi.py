@@ -101,11 +101,8 @@ class TrsPilotConfig(C.Structure):
 class TrsPilotTuning(C.Structure):
     """``trs_pilot_tuning`` (include/trsim.h): kernel choices of ``trs_pilot_load``; tests and measurements only."""
     _fields_ = [
-        ("struct_size", C.c_uint32), ("no_fuse", C.c_int32), ("fuse_band_r2", C.c_int32), ("fuse_r2", C.c_int32), ("fuse_wsplit_max", C.c_int32), ("fuse_roll", C.c_int32),
-        ("span_layers_mask", C.c_int32), ("frame5", C.c_int32), ("frame5_bands", C.c_int32), ("frame5_f", C.c_int32),
-        ("frame_layers_mask", C.c_int32), ("frame_bands", C.c_int32 * 4), ("frame_ohb", C.c_int32 * 4), ("frame_f", C.c_int32), ("frame_deep", C.c_int32), ("frame_block", C.c_int32), ("frame_nt", C.c_int32),
-        ("chain_layers", C.c_int32), ("chain_nt", C.c_int32), ("chain_nb", C.c_int32), ("chain_f", C.c_int32), ("dense", C.c_int32), ("ksplit", C.c_int32), ("min_waves", C.c_int32), ("waves", C.c_int32),
-        ("nt_mb", C.c_int32), ("nt_kind", C.c_int32),
+        ("struct_size", C.c_uint32), ("no_fuse", C.c_int32), ("fuse_band_r2", C.c_int32), ("fuse_wsplit_max", C.c_int32), ("fuse_roll", C.c_int32),
+        ("span_layers_mask", C.c_int32), ("frame5", C.c_int32), ("frame_layers_mask", C.c_int32), ("chain_layers", C.c_int32), ("dense", C.c_int32), ("ksplit", C.c_int32),
     ]
 
 

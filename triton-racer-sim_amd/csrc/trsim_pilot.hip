@@ -46,14 +46,11 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;   // 8 binary16 valu
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
-constexpr int kConvBlock = 256;           // 4 waves x 32 output pixels = 128 GEMM rows per workgroup
-constexpr int kRowsPerWg = 128;
 constexpr int kLayers = 11;               // conv1..7, dense1..3, output
 #ifndef TRS_CONV_ABLATE
 #define TRS_CONV_ABLATE 0   /* diagnostic builds of trs_conv_lt_kernel, never shipped: 1 = no steady-state global loads, 2 = no LDS transpose, 3 = no MFMA, 4 = no stores */
 #endif
 constexpr int kConvPrefetch = 4;           // trips (pairs of k-steps) of pixel fragments in flight per wave
-constexpr int kLdsWeightBytes = 32 * 1024;   // per weight stage; 32 KB measured best of 8/16/32/64 (more workgroups per CU hide the A-load latency)
 
 struct ConvParams {
     const void* in;            // fp16 NHWC [N][IH][IW][CIN]   (conv1: uint8 [N][IH][IW][3])
@@ -111,458 +108,8 @@ __device__ __forceinline__ uint2 relu_pack4(float v0, float v1, float v2, float 
     return make_uint2(relu_h16x2(pack_h16x2(v0, v1)), relu_h16x2(pack_h16x2(v2, v3)));
 }
 
-template <int NB, bool U8IN>
-__global__ __launch_bounds__(kConvBlock) void trs_conv_mfma_kernel(const ConvParams p)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [gchunk][COUT_PAD] granules
-    int* lgoff = reinterpret_cast<int*>(psmem + (size_t)p.gchunk * p.COUT_PAD * 16);   // [G_pad]
-    for (int i = tid; i < p.G_pad; i += kConvBlock) lgoff[i] = p.goff[i];
+#include "trsim_pilot_layers.hpp"   // the single-layer kernels: conv1 as its own layer, the span kernel (conv2 unfused, conv3 at 240x320), the quad-load fallback
 
-    // GEMM row of this lane for the A operand: one output pixel (this chunked kernel serves dense1's split-K, whose
-    // fp32 atomics want consecutive lanes on consecutive channels: D[pixel][cout], column = lane & 31)
-    const int m = blockIdx.x * kRowsPerWg + wave * 32 + r;
-    const int mm = min(m, p.M - 1);
-    const int ohw = p.OH * p.OW;
-    const int n = mm / ohw, rem = mm - n * ohw, oy = rem / p.OW, ox = rem - oy * p.OW;
-    const int pixbase = ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-
-    // split-K (dense1: 8 row tiles only): blockIdx.y takes granules [gs, ge) in whole LDS chunks
-    const int nchunks = (p.G_pad + p.gchunk - 1) / p.gchunk;
-    const int cps = (nchunks + p.ksplit - 1) / p.ksplit;
-    const int gs = blockIdx.y * cps * p.gchunk, ge = min(p.G_pad, (blockIdx.y + 1) * cps * p.gchunk);
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const float b = blockIdx.y == 0 ? p.bias[nb * 32 + r] * (1.0f / p.oscale) : 0.0f;      // C/D layout: column = lane & 31 in every register (oscale is a power of two: exact)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][i] = b;
-    }
-    __syncthreads();                                                        // lgoff visible
-    if (gs >= ge) return;                                                   // empty K slice (uniform per workgroup)
-
-    auto load_a = [&](int g) -> h16x8 {
-        if constexpr (U8IN) {
-            // 8 of the 16 bytes of one kernel row, at any byte alignment: 3 aligned dwords, byte-align, exact u8 -> fp16
-            // (0..255 is exact in binary16)
-            const int addr = pixbase + lgoff[g];
-            const int al = addr & ~3;
-            const unsigned sh = (unsigned)addr & 3u;
-            const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
-            const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
-            const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
-            const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-            const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            auto pair = [](unsigned w, int j) -> unsigned {
-                const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                return u8pair_h16(f0, f1);
-            };
-            const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-            return __builtin_bit_cast(h16x8, packed);
-        } else {
-            const u4v raw = __builtin_amdgcn_raw_buffer_load_b128(rin, pixbase + lgoff[g], 0, 0);
-            return __builtin_bit_cast(h16x8, raw);
-        }
-    };
-
-    // A trip = two k-steps (4 granules).  The pixel fragments of kPf trips are in flight: slot t of the register ring is
-    // refilled for trip i + kPf right after trip i's MFMAs have read it (fragments do not depend on the weight stage, so
-    // the prefetch runs across chunk boundaries).  gchunk is a multiple of 4 * kPf, so a trip's slot is a compile-time
-    // index.  Every group of kPf trips but the last reloads UNCONDITIONALLY (clamped granule index): a load inside a
-    // branch makes hipcc drain the whole queue (vmcnt(0)) at the loop head; the last group has no loads and may be ragged.
-    constexpr int kPf = kConvPrefetch;
-    h16x8 ring[2 * kPf];
-#pragma unroll
-    for (int t = 0; t < kPf; ++t) {
-        if (gs + 4 * t < ge) { ring[2 * t] = load_a(gs + 4 * t + h); ring[2 * t + 1] = load_a(gs + 4 * t + 2 + h); }
-    }
-    auto trip_mfma = [&](int gt, int t) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + h) * p.COUT_PAD + nb * 32 + r]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * t], w, acc[nb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + 2 + h) * p.COUT_PAD + nb * 32 + r]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * t + 1], w, acc[nb], 0, 0, 0);
-        }
-    };
-    for (int c0 = gs; c0 < ge; c0 += p.gchunk) {
-        const int gc = min(p.gchunk, ge - c0);
-        __syncthreads();                                                    // previous chunk fully consumed
-        for (int i = tid; i < gc * p.COUT_PAD; i += kConvBlock) lw[i] = p.w[(size_t)c0 * p.COUT_PAD + i];
-        __syncthreads();
-        for (int g2 = 0; g2 < gc; g2 += 4 * kPf) {
-            if (c0 + g2 + 4 * kPf < ge) {                                   // a full group with at least one trip behind it
-#pragma unroll
-                for (int t = 0; t < kPf; ++t) {
-                    trip_mfma(g2 + 4 * t, t);
-                    const int gn = min(c0 + g2 + 4 * t + 4 * kPf, ge - 4);
-                    ring[2 * t] = load_a(gn + h); ring[2 * t + 1] = load_a(gn + 2 + h);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {                                                        // the last group: 1..kPf trips, nothing to fetch
-#pragma unroll
-                for (int t = 0; t < kPf; ++t)
-                    if (g2 + 4 * t < gc) trip_mfma(g2 + 4 * t, t);
-            }
-        }
-    }
-
-    // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int row0 = blockIdx.x * kRowsPerWg + wave * 32;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int col = nb * 32 + r;
-        if (col >= p.COUT) continue;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (row >= p.M) continue;
-            float v = acc[nb][i] * p.oscale;
-            if (p.ksplit > 1) {   // this K slice's partial sums go to its own slab; the consumer adds the slabs in slice order (deterministic, no atomics)
-                static_cast<float*>(p.out)[((size_t)blockIdx.y * p.M + row) * p.COUT + col] = v;
-                continue;
-            }
-            if (p.relu) v = v > 0.0f ? v : 0.0f;
-            if (p.out_f32) static_cast<float*>(p.out)[(size_t)row * p.COUT + col] = v;
-            else static_cast<unsigned short*>(p.out)[(size_t)row * p.COUT + col] = f2h(v);
-        }
-    }
-}
-
-// pixel index -> byte offset of its input window.  The tile's first pixel is wave-uniform, so its frame / remainder split
-// runs on the scalar unit; a lane adds its own offset (at most a few wraps) and divides the in-frame remainder by OW with a
-// float reciprocal + correction (remainders are far below 2^22).
-__device__ __forceinline__ int window_base(const ConvParams& p, int n0, int rem0, int add, float inv_ow)
-{
-    const int ohw = p.OH * p.OW;
-    int n = n0, rem = rem0 + add;
-    while (rem >= ohw) { rem -= ohw; ++n; }
-    int oy = (int)(((float)rem + 0.5f) * inv_ow);
-    int ox = rem - oy * p.OW;
-    if (ox < 0) { --oy; ox += p.OW; } else if (ox >= p.OW) { ++oy; ox -= p.OW; }
-    return ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
-}
-
-// Epilogue of a 32-pixel tile: bias + ReLU + fp16, transposed through the wave's 2 KB LDS stage so that the global stores
-// are 16 bytes per lane and contiguous across lanes (the direct 8-byte stores of the C/D layout cost the addresser one
-// lookup per lane: 31 us of conv2's 131).  Stage layout: [pixel][16-B chunk ^ f(pixel)], f spreads the 16 lanes of a
-// ds_write_b64 / ds_read_b128 group over the bank row.  NB = 2 (128 B per pixel) goes in two passes of 16 pixels.
-template <int NB>
-__device__ __forceinline__ void store_tile_at(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int m_base, int m_limit, int cbase, int lane)
-{   // the tile's 32 pixels are output pixels m_base .. m_base + 31 (consecutive in memory); those >= m_limit are not stored
-    constexpr int CR = NB * 4;                                              // 16-B chunks per pixel row of this slice
-    constexpr int PP = 128 / CR;                                            // pixels per pass (2 KB stage)
-    const int r = lane & 31, h = lane >> 5;
-    const int crv = min(CR, (p.COUT - cbase) >> 3);                         // valid chunks (conv1: 3 of 4)
-    const unsigned magic = (65536u + (unsigned)crv - 1u) / (unsigned)crv;   // g / crv for g < 256
-    uint2* st2 = reinterpret_cast<uint2*>(stage);
-#pragma unroll
-    for (int pass = 0; pass < 32 / PP; ++pass) {
-        const int pr = r - pass * PP;                                       // pixel of this lane within the pass
-        if (pr >= 0 && pr < PP) {
-            const int f = NB == 1 ? (pr >> 1) & 3 : pr & 7;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 b = lbias[nb * 8 + 2 * q + h];
-                    const float os = p.oscale;
-                    float v0 = __builtin_fmaf(acc[nb][4 * q], os, b.x), v1 = __builtin_fmaf(acc[nb][4 * q + 1], os, b.y), v2 = __builtin_fmaf(acc[nb][4 * q + 2], os, b.z), v3 = __builtin_fmaf(acc[nb][4 * q + 3], os, b.w);
-                    st2[(pr * CR + ((4 * nb + q) ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
-                }
-            }
-        }
-        const int total = PP * crv;                                         // 16-B chunks to write out in this pass
-        const size_t pass_byte0 = (size_t)(m_base + pass * PP) * p.COUT * 2;
-        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out) + pass_byte0, 0, PP * p.COUT * 2, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int g = i * 64 + lane;
-            if (g < total) {
-                const int pix = (int)(((unsigned)g * magic) >> 16), c = g - pix * crv;
-                const int m = m_base + pass * PP + pix;
-                const int f = NB == 1 ? (pix >> 1) & 3 : pix & 7;
-                if (m < m_limit) {
-                    const u4v v = stage[pix * CR + (c ^ f)];
-                    // a buffer store so that the cache policy can be chosen per layer (immediate aux bits): activations far
-                    // larger than L2 leave non-temporally and do not displace what the next layer is about to read
-                    const int off = (pix * p.COUT + cbase + 8 * c) * 2;
-                    if (p.nt_out == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 2);         // nt
-                    else if (p.nt_out == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 17);   // sc0 sc1 (write-through)
-                    else __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 0);
-                }
-            }
-        }
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], const float4* lbias, const ConvParams& p, int tile, int cbase, int lane)
-{
-    store_tile_at<NB>(stage, acc, lbias, p, tile * 32, p.M, cbase, lane);
-}
-
-// The same epilogue for a tile whose 32 pixels are a run of a ROW-SEGMENT grid (the fused head's band cut in width: rows of w2
-// pixels inside an output activation of OW pixels per row): pixel pg of the band part = (row pg / w2, column pg % w2), output
-// pixel m_row0 + row * OW + column.  32 output channels (NB = 1).
-__device__ __forceinline__ void store_tile_rows(u4v* stage, const f32x16 (&acc)[1], const float4* lbias, const ConvParams& p, int pg0, int npx, int w2, float inv_w2,
-                                                int m_row0, int OW, int lane)
-{
-    constexpr int CR = 4;
-    const int r = lane & 31, h = lane >> 5;
-    uint2* st2 = reinterpret_cast<uint2*>(stage);
-    {
-        const int f = (r >> 1) & 3;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = lbias[2 * q + h];
-            const float os = p.oscale;
-            float v0 = __builtin_fmaf(acc[0][4 * q], os, b.x), v1 = __builtin_fmaf(acc[0][4 * q + 1], os, b.y), v2 = __builtin_fmaf(acc[0][4 * q + 2], os, b.z), v3 = __builtin_fmaf(acc[0][4 * q + 3], os, b.w);
-            st2[(r * CR + (q ^ f)) * 2 + h] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(p.out), 0, p.M * p.COUT * 2, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = i * 64 + lane, pix = g >> 2, c = g & 3;                // 32 pixels x 4 chunks of 8 channels
-        const int pg = pg0 + pix;
-        if (pg < npx) {
-            int row = (int)(((float)pg + 0.5f) * inv_w2), col = pg - row * w2;
-            if (col < 0) { --row; col += w2; } else if (col >= w2) { ++row; col -= w2; }
-            const int f = (pix >> 1) & 3;
-            const u4v v = stage[pix * CR + (c ^ f)];
-            const int off = ((m_row0 + row * OW + col) * p.COUT + 8 * c) * 2;
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, off, 0, 0);
-        }
-    }
-}
-
-// conv1 (uint8 frame in, kPf = 3 trips = the whole K of 5 kernel rows x 16 bytes): resident weights, persistent workgroups,
-// independent waves, no barrier after the weight stage.  A wave walks 32-pixel tiles; the raw dwords of the NEXT tile are
-// requested before the current tile's MFMAs and epilogue, so their latency hides behind them.
-__global__ __launch_bounds__(1024) void trs_conv_u8_kernel(const ConvParams p)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr int NBW = 32, kGr = 6;                                        // granules per lane: 3 trips x 2 k-steps
-    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
-    int* lgoff = reinterpret_cast<int*>(psmem + (size_t)p.G_pad * NBW * 16);
-    const size_t off_bias = (size_t)p.G_pad * NBW * 16 + (((size_t)p.G_pad * 4 + 15) & ~(size_t)15);
-    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);           // [NBW / 4]
-    u4v* stage = reinterpret_cast<u4v*>(psmem + off_bias + NBW * 4) + wave * 128;   // 2 KB per wave: output transpose
-    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + 4 * i);
-    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
-        const int g = i / NBW, c = i - g * NBW;
-        lw[i] = p.w[(size_t)g * p.COUT_PAD + c];
-    }
-    for (int i = tid; i < p.G_pad; i += blockDim.x) lgoff[i] = p.goff[i];
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-    const int ohw = p.OH * p.OW;
-    const int ntiles = (p.M + 31) >> 5, stride = gridDim.x * nwaves;
-    const float inv_ow = 1.0f / (float)p.OW;
-    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
-    if (tile >= ntiles) return;
-    int goffs[kGr];                                                         // this lane's granules: k-step s, half h -> granule 2s + h
-#pragma unroll
-    for (int s = 0; s < kGr; ++s) goffs[s] = lgoff[min(2 * s + h, p.G_pad - 1)];
-    auto base_of = [&](int t) {                                             // t is wave-uniform: the frame split runs on the scalar unit
-        const int n0 = (t * 32) / ohw, rem0 = t * 32 - n0 * ohw;
-        return window_base(p, n0, rem0, min(r, p.M - 1 - t * 32), inv_ow);
-    };
-    unsigned raw[kGr][3];
-    int pixbase = base_of(tile);
-    auto request = [&](int pb) {
-#pragma unroll
-        for (int s = 0; s < kGr; ++s) {
-            const int al = (pb + goffs[s]) & ~3;
-            raw[s][0] = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
-            raw[s][1] = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
-            raw[s][2] = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
-        }
-    };
-    request(pixbase);
-    while (true) {
-        // 8 of the 16 bytes of a kernel row at any byte alignment: byte-align, then exact u8 -> binary16 (0..255 is exact)
-        h16x8 x[kGr];
-#pragma unroll
-        for (int s = 0; s < kGr; ++s) {
-            const unsigned sh = (unsigned)(pixbase + goffs[s]) & 3u;
-            const unsigned lo = __builtin_amdgcn_alignbyte(raw[s][1], raw[s][0], sh);
-            const unsigned hi = __builtin_amdgcn_alignbyte(raw[s][2], raw[s][1], sh);
-            auto pair = [](unsigned w, int j) -> unsigned {
-                const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                return u8pair_h16(f0, f1);
-            };
-            const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-            x[s] = __builtin_bit_cast(h16x8, packed);
-        }
-        const int next = tile + stride;                                     // uniform
-        const int nbase = base_of(min(next, ntiles - 1));
-        request(nbase);                                                     // unconditional: the last tile re-requests itself
-        f32x16 acc[1];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < kGr; ++s) {
-            if (2 * s < p.G_pad) {
-                const h16x8 w = __builtin_bit_cast(h16x8, lw[(2 * s + h) * NBW + r]);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x[s], acc[0], 0, 0, 0);
-            }
-        }
-        store_tile<1>(stage, acc, lbias, p, tile, 0, lane);
-        if (next >= ntiles) break;
-        tile = next; pixbase = nbase;
-    }
-}
-
-// conv2..conv7 (fp16 input): resident weights + QUAD-COALESCED pixel loads.  Counters showed the per-lane 16-byte loads of
-// the kernel above cost the texture addresser one tag lookup per lane (56-88 per instruction: every lane another line) and
-// bound every layer.  Here the four lanes of a quad fetch the four consecutive granules (64 contiguous bytes) of ONE pixel,
-// so an instruction is 16 pixels x 64 B; the fragments reach the MFMA layout through a 2 KB wave-private LDS stage:
-//   load  (trip T, instruction i): lane l = 4q + jj holds granule 4T + j of pixel 16i + q, j = (jj - (q >> 2)) & 3
-//   write : lane l -> stage[i][l]                                  (linear, conflict-free)
-//   read  (k-step s): lane (r, h) wants granule j = 2s + h of pixel r  ->  stage[r >> 4][4q + ((j + (q >> 2)) & 3)], q = r & 15
-// The rotation by q >> 2 spreads the 16 lanes of every ds_read_b128 group over all 16 slots of the 256-B bank row.
-// Granules of a trip are contiguous in memory: k is ordered (kh, [kw, cin]) and a kernel row is one contiguous run of
-// KW * CIN / 8 granules in NHWC, padded to a multiple of 4 (only conv2: 15 -> 16, zero weights).
-template <int NB>
-__global__ __launch_bounds__(1024) void trs_conv_lt_kernel(const ConvParams p)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr int NBW = NB * 32;
-    const int cbase = blockIdx.y * NBW;
-    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
-    const size_t off_goff = (size_t)p.G_pad * NBW * 16;
-    const size_t off_bias = off_goff + (((size_t)p.G_pad * 4 + 15) & ~(size_t)15);
-    const size_t off_stage = off_bias + NBW * 4;
-    int* lgoff = reinterpret_cast<int*>(psmem + off_goff);
-    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);
-    u4v* stage = reinterpret_cast<u4v*>(psmem + off_stage) + wave * 128;   // [2][64] granules of this wave
-    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * i);
-    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
-        const int g = i / NBW, c = i - g * NBW;
-        lw[i] = p.w[(size_t)g * p.COUT_PAD + cbase + c];
-    }
-    for (int i = tid; i < p.G_pad; i += blockDim.x) lgoff[i] = p.goff[i];
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-    const int ohw = p.OH * p.OW;
-    const int ntiles = (p.M + 31) >> 5;
-    constexpr int kPf = kConvPrefetch;
-    // loader role of this lane: pixel 16 i + lq of the tile, granule lj of every trip
-    const int lq = lane >> 2, lj = ((lane & 3) - (lq >> 2)) & 3;
-    // reader role: slots of k-step 0 and 1 for pixel r, half h
-    const int rq = r & 15;
-    const int rd0 = (r >> 4) * 64 + 4 * rq + ((h + (rq >> 2)) & 3);
-    const int rd1 = (r >> 4) * 64 + 4 * rq + ((2 + h + (rq >> 2)) & 3);
-    const float inv_ow = 1.0f / (float)p.OW;
-    const int stride = gridDim.x * nwaves;
-    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
-    if (tile >= ntiles) return;
-    int lbase[2];
-    auto bases_of = [&](int t, int (&out)[2]) {                             // t is wave-uniform: the frame split runs on the scalar unit
-        const int n0 = (t * 32) / ohw, rem0 = t * 32 - n0 * ohw;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) out[i] = window_base(p, n0, rem0, min(16 * i + lq, p.M - 1 - t * 32), inv_ow);
-    };
-    auto load_q = [&](int g4, int i) -> u4v {                               // g4 = first granule of the trip
-        return __builtin_amdgcn_raw_buffer_load_b128(rin, lbase[i] + lgoff[g4 + lj], 0, 0);
-    };
-    u4v ring[2 * kPf];
-    auto preload = [&]() {
-#pragma unroll
-        for (int t = 0; t < kPf; ++t) {
-            const int g = min(4 * t, p.G_pad - 4);
-            ring[2 * t] = load_q(g, 0); ring[2 * t + 1] = load_q(g, 1);
-        }
-    };
-    bases_of(tile, lbase);
-    preload();
-    while (true) {
-        f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
-        auto trip_mfma = [&](int gt, int t) {
-#if TRS_CONV_ABLATE == 2
-            const h16x8 x0 = __builtin_bit_cast(h16x8, ring[2 * t]);
-            const h16x8 x1 = __builtin_bit_cast(h16x8, ring[2 * t + 1]);
-#else
-            stage[lane] = ring[2 * t];                                      // transpose through the wave's LDS stage (in-order per wave)
-            stage[64 + lane] = ring[2 * t + 1];
-            const h16x8 x0 = __builtin_bit_cast(h16x8, stage[rd0]);
-            const h16x8 x1 = __builtin_bit_cast(h16x8, stage[rd1]);
-#endif
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + h) * NBW + nb * 32 + r]);
-#if TRS_CONV_ABLATE == 3
-                acc[nb][0] += (float)w[0] * (float)x0[0];
-#else
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x0, acc[nb], 0, 0, 0);
-#endif
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const h16x8 w = __builtin_bit_cast(h16x8, lw[(gt + 2 + h) * NBW + nb * 32 + r]);
-#if TRS_CONV_ABLATE == 3
-                acc[nb][1] += (float)w[0] * (float)x1[0];
-#else
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x1, acc[nb], 0, 0, 0);
-#endif
-            }
-        };
-        int g2 = 0;
-        for (; g2 + 4 * kPf < p.G_pad; g2 += 4 * kPf) {
-#pragma unroll
-            for (int t = 0; t < kPf; ++t) {
-                trip_mfma(g2 + 4 * t, t);
-#if TRS_CONV_ABLATE != 1
-                const int gn = min(g2 + 4 * t + 4 * kPf, p.G_pad - 4);
-                ring[2 * t] = load_q(gn, 0); ring[2 * t + 1] = load_q(gn, 1);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < kPf; ++t)
-            if (g2 + 4 * t < p.G_pad) trip_mfma(g2 + 4 * t, t);
-
-        // the next tile's first trips are requested before this tile's epilogue (unconditional: the last tile re-requests itself)
-        const int next = tile + stride;
-        bases_of(min(next, ntiles - 1), lbase);
-        preload();
-#if TRS_CONV_ABLATE != 4
-        store_tile<NB>(stage, acc, lbias, p, tile, cbase, lane);
-#endif
-        if (next >= ntiles) break;
-        tile = next;
-    }
-}
-
-// conv4 .. conv7 (3x3, stride 1): the whole input activation of a frame is 13-26 KB, so F frames of it live in LDS and the nine
-// overlapping windows of every output pixel are read from there — the quad-load kernel above fetched every input byte nine times
-// through the texture addresser.  One workgroup = F frames:
-//   staging   input granules (8 channels = 16 B) global -> LDS by LDS-DMA, XOR-swizzled within the pixel's row of granules
-//             (physical slot q = g ^ swz(pixel); the swizzle goes on the SOURCE address, the LDS side stays lane-linear) so that
-//             the 16 lanes of a ds_read_b128 group — 16 consecutive pixels, one logical granule — cover all 64 banks
-//   work item a super-tile of NT x 32 output pixels (consecutive over the workgroup's frames) x NB x 32 output channels, one wave;
-//             per k-step (16 input channels of one tap): NT ds_read_b128 (pixels, B operand), NB weight granules straight from
-//             L2 (A operand, 512 contiguous bytes per half wave, prefetched kFrameRing k-steps ahead in registers), NT x NB MFMAs.
-//             Each pixel fragment feeds NB MFMAs and each weight fragment NT: LDS and L2 each supply half of what one-to-one
-//             feeding would need (LDS 128 B/clk and L2 64 B/clk per CU are what bound a 32x32x16 MFMA stream otherwise)
-//   epilogue  bias + ReLU + fp16, 8-byte stores (these activations are small: 9-19 KB per frame)
 struct FrameConvParams {
     const u4v* in;             // fp16 NHWC [N][IH][IW][CIN] as 16-B granules
     const u4v* w;              // [KH*KW*cg][COUT_PAD] granules (kernel-row major, then tap, then channel granule)
@@ -749,16 +296,6 @@ struct ChainParams {
 #ifndef TRS_CHAIN_ABLATE
 #define TRS_CHAIN_ABLATE 0   /* timing-only diagnostic builds of the chain's layers, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no MFMA */
 #endif
-#if defined(TRS_CHAIN_STAMPS) && TRS_CHAIN_STAMPS == 2   /* finer: workgroup 7, wave 0, inside each item: prologue | K loop | epilogue; the k-steps of the last layer */
-__device__ unsigned long long g_chain_dbg[64];
-__device__ int g_chain_dbg_n;
-#define CHAIN_ITEM_STAMP() do { if (blockIdx.x == 7 && wave == 0 && lane == 0 && g_chain_dbg_n < 64) g_chain_dbg[g_chain_dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
-__shared__ unsigned long long g_chain_k[80];          // (in LDS: a global store per stamp would join the weight loads' in-order queue)
-#define CHAIN_K_STAMP(k) do { if (HALF == 8 && blockIdx.x == 7 && wave == 0 && lane == 0) g_chain_k[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CHAIN_ITEM_STAMP() do { } while (0)
-#define CHAIN_K_STAMP(k) do { } while (0)
-#endif
 // One layer of the chain.  A wave item = NT x 32 pixels x NB x 32 output channels; the weight ring is R k-steps deep (R x NB granules per
 // lane: NB = 1 takes twice the depth for the same registers and the same lead time in MFMA clocks).
 template <int HALF, int R, int NT, int NB>
@@ -771,7 +308,6 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
     const float4* lbias = reinterpret_cast<const float4*>(lbias_f);
     constexpr int ksteps = 9 * HALF;
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
-        CHAIN_ITEM_STAMP();
         const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
         const int cbase = cgrp * NB * 32;
         int lbase[NT], mo[NT];
@@ -811,13 +347,11 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #endif
             }
         };
-        CHAIN_ITEM_STAMP();
         h16x8 xa[NT], xb[NT];
         pixels(0, xa);
 #pragma unroll
         for (int k = 0; k < ksteps; ++k) {
             const int d = k % R;
-            CHAIN_K_STAMP(k);
             h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
             h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
             if (k + 1 < ksteps) pixels(k + 1, xn);
@@ -838,7 +372,6 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        CHAIN_ITEM_STAMP();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -868,7 +401,6 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 }
             }
         }
-        CHAIN_ITEM_STAMP();
     }
 }
 #ifndef TRS_CHAIN_R
@@ -879,13 +411,8 @@ template <int HALF>
 __device__ __forceinline__ void chain_layer_any(const ChainLayer& L, const u4v* lin, const float* lbias_f, int nu, u4v* lout, int cgs_out, int out_pix0,
                                                 unsigned short* gout, int wave, int nwaves, int lane)
 {
-    if (L.nb == 1) {
-        if (L.nt == 3) chain_layer<HALF, 2 * TRS_CHAIN_R, 3, 1>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
-        else chain_layer<HALF, 2 * TRS_CHAIN_R, 2, 1>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
-    } else {
-        if (L.nt == 3) chain_layer<HALF, TRS_CHAIN_R, 3, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
-        else chain_layer<HALF, TRS_CHAIN_R, 2, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
-    }
+    if (L.nt == 3) chain_layer<HALF, TRS_CHAIN_R, 3, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
+    else chain_layer<HALF, TRS_CHAIN_R, 2, 2>(L, lin, lbias_f, nu, lout, cgs_out, out_pix0, gout, wave, nwaves, lane);
 }
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainParams p)
@@ -911,13 +438,6 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
             }
         }
     };
-#ifdef TRS_CHAIN_STAMPS   /* diagnostic build: shader clocks of workgroup 7's waves 0 and 7 per stage of the chain */
-    unsigned long long cst[12] = {0}, cprev = __builtin_amdgcn_s_memtime(); int cn = 0;
-    const unsigned long long c_t0 = cprev, c_r0 = __builtin_amdgcn_s_memrealtime();   // shader clocks against the 100 MHz counter: the clock the kernel ran at
-#define CHAIN_STAMP() do { if (blockIdx.x == 7 && (tid == 0 || tid == 448)) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); cst[cn++] = tn - cprev; cprev = tn; } } while (0)
-#else
-#define CHAIN_STAMP() do { } while (0)
-#endif
     int li = 0;
     const u4v* cur = A;
     if (p.split_first) {
@@ -928,13 +448,10 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
             if (cnt > 0) stage(L0, u0 + per * pass, cnt, lds0 + p.offB);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            CHAIN_STAMP();
             if (cnt > 0) {
                 chain_layer_any<4>(L0, B, lb, cnt, A, p.L[1].cgs, per * pass * L0.OH * L0.OW, nullptr, wave, nwaves, lane);
             }
-            CHAIN_STAMP();
             __syncthreads();
-            CHAIN_STAMP();
         }
         li = 1;
     } else {
@@ -946,40 +463,13 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
         const ChainLayer& L = p.L[li];
         u4v* const nxt = cur == A ? B : A;
         chain_layer_any<4>(L, cur, lb + li * 128, nu, nxt, p.L[li + 1].cgs, 0, nullptr, wave, nwaves, lane);
-        CHAIN_STAMP();
         __syncthreads();
-        CHAIN_STAMP();
         cur = nxt;
     }
     {
         const ChainLayer& L = p.L[p.nl - 1];
         chain_layer_any<8>(L, cur, lb + (p.nl - 1) * 128, nu, nullptr, 0, 0, p.out + (size_t)u0 * L.OH * L.OW * L.COUT, wave, nwaves, lane);
     }
-#ifdef TRS_CHAIN_STAMPS
-    __syncthreads();   // the printf below is a host call: from a wave that is done early it would run beside the last layer of the others (and did, in
-                       // the first stamped builds: their weight loads then took ~3,000 clocks each - an artefact of the instrument, not of the kernel)
-#endif
-    CHAIN_STAMP();
-#if defined(TRS_CHAIN_STAMPS) && TRS_CHAIN_STAMPS == 2
-    if (blockIdx.x == 7 && tid == 0) {
-        for (int i = 0; i + 3 < g_chain_dbg_n; i += 4)
-            printf("chain item %d of wave 0: prologue %llu | K loop %llu | epilogue %llu | since previous item's end %llu\n", i / 4, g_chain_dbg[i + 1] - g_chain_dbg[i],
-                   g_chain_dbg[i + 2] - g_chain_dbg[i + 1], g_chain_dbg[i + 3] - g_chain_dbg[i + 2], i ? g_chain_dbg[i] - g_chain_dbg[i - 1] : 0ull);
-        g_chain_dbg_n = 0;
-        printf("chain conv7 k-steps of wave 0 [clocks each]:");
-        for (int k = 1; k < 72; ++k) printf(" %llu", g_chain_k[k] - g_chain_k[k - 1]);
-        printf("\n");
-    }
-#endif
-#ifdef TRS_CHAIN_STAMPS
-    if (blockIdx.x == 7 && tid == 0) {
-        const unsigned long long dt = __builtin_amdgcn_s_memtime() - c_t0, dr = __builtin_amdgcn_s_memrealtime() - c_r0;
-        printf("chain, workgroup 7: %llu shader clocks in %llu ticks of 10 ns = %.2f GHz\n", dt, dr, dr ? (double)dt / (10.0 * (double)dr) : 0.0);
-    }
-    if (blockIdx.x == 7 && (tid == 0 || tid == 448))
-        printf("chain, workgroup 7, wave %d [clocks]: stage A %llu | conv4 A work %llu wait %llu | stage B %llu | conv4 B work %llu wait %llu | conv5 work %llu wait %llu | conv6 work %llu wait %llu | conv7 %llu\n",
-               wave, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], cst[7], cst[8], cst[9], cst[10]);
-#endif
 }
 
 // ---- conv3 with its input frames in LDS (round 2) -----------------------------------------------------------------------------
@@ -1115,111 +605,6 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
     }
 }
 
-// conv2 / conv3 (stride-2 5x5): overlapping windows make the kernel above fetch every input byte ~2.5x, and the texture
-// addresser (about one lookup per clock) is what bounds these layers.  Here a wave stages, per kernel row, the CONTIGUOUS
-// input span its 32-pixel tile needs (a tile crosses output rows, so the span is 1..4 segments, one per output row touched)
-// with fully coalesced 1 KB loads, writes it to a wave-private LDS stage, and reads the im2col fragments from there:
-//   virtual granule v of the stage = segment start c_s + (input granule within the segment's span)
-//   loader lane l, instruction k: v = 64 k + l  ->  global address base_s + kh * row_bytes + 16 (v - c_s)
-//   reader lane (pixel r = segment s, position q; half h), k-step t: v = c_s + q * S * cg + 2 t + h
-// The next kernel row's span is requested (registers) before the current row's MFMAs; SWZ (pixel stride of 8 granules,
-// conv3) XOR-swizzles the stage so a ds_read_b128 group covers all 16 slots of the bank row.
-template <int NB, bool SWZ>
-__global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
-{
-    constexpr int kMaxNl = 5, kMaxSeg = 4;                                  // 12 waves per workgroup at most: the segment bookkeeping wants ~150 VGPRs
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    constexpr int NBW = NB * 32;
-    const int cbase = blockIdx.y * NBW;
-    u4v* lw = reinterpret_cast<u4v*>(psmem);                               // [G_pad][NBW] granules
-    const size_t off_bias = (size_t)p.G_pad * NBW * 16;
-    const size_t off_stage = off_bias + NBW * 4;
-    float4* lbias = reinterpret_cast<float4*>(psmem + off_bias);
-    u4v* stage = reinterpret_cast<u4v*>(psmem + off_stage) + wave * (p.span_nl * 64);   // span_nl KB per wave
-    for (int i = tid; i < NBW / 4; i += blockDim.x) lbias[i] = *reinterpret_cast<const float4*>(p.bias + cbase + 4 * i);
-    for (int i = tid; i < p.G_pad * NBW; i += blockDim.x) {
-        const int g = i / NBW, c = i - g * NBW;
-        lw[i] = p.w[(size_t)g * p.COUT_PAD + cbase + c];
-    }
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-    const int ohw = p.OH * p.OW;
-    const int ntiles = (p.M + 31) >> 5, stride = gridDim.x * nwaves;
-    const int row_bytes = p.IW * p.in_px_bytes;
-    const int pix_gran = p.S * p.cg;                                        // granules between neighbouring output pixels
-    const int tail = p.run_pad;                                             // granules a segment's last pixel needs (window + run padding)
-    auto swz = [](int v) { return SWZ ? v ^ ((v >> 4) & 7) : v; };
-
-    int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
-    if (tile >= ntiles) return;
-    int laddr[kMaxNl];                                                      // loader: byte address of this lane's granule of instruction k, kernel row 0
-    auto setup = [&](int t, int& roff) {                                    // roff: virtual granule of this lane's pixel, k-step 0, half h
-        // t is wave-uniform: the segment list is scalar work
-        const int m0 = t * 32;
-        const int n0 = m0 / ohw, rem0 = m0 - n0 * ohw;
-        int n = n0, oy = rem0 / p.OW, ox = rem0 - oy * p.OW;
-        int left = 32, cum = 0, c = 0;
-        roff = 0;
-#pragma unroll
-        for (int k = 0; k < kMaxNl; ++k) laddr[k] = p.in_bytes;             // out of range: the buffer load returns zeros
-#pragma unroll
-        for (int sgi = 0; sgi < kMaxSeg; ++sgi) {
-            if (left > 0) {
-                const int len = min(left, p.OW - ox);
-                const int sg = (len - 1) * pix_gran + tail;                 // granules of this segment's span
-                const int base = ((n * p.IH + oy * p.S) * p.IW + ox * p.S) * p.in_px_bytes;
-                if (r >= cum && r < cum + len) roff = c + (r - cum) * pix_gran + h;
-#pragma unroll
-                for (int k = 0; k < kMaxNl; ++k) {
-                    const int v = 64 * k + lane;
-                    if (k < p.span_nl && v >= c && v < c + sg) laddr[k] = base + (v - c) * 16;
-                }
-                left -= len; cum += len; c += sg;
-                ox = 0; ++oy;
-                if (oy == p.OH) { oy = 0; ++n; }
-            }
-        }
-    };
-    u4v regs[kMaxNl];
-    auto request = [&](int kh) {
-#pragma unroll
-        for (int k = 0; k < kMaxNl; ++k)
-            if (k < p.span_nl) regs[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, laddr[k] == p.in_bytes ? p.in_bytes : laddr[k] + kh * row_bytes, 0, 0);
-    };
-    int roff_cur = 0, roff_next = 0;
-    setup(tile, roff_cur);
-    request(0);
-    while (true) {
-        f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
-        const int next = tile + stride;                                     // uniform
-        for (int kh = 0; kh < p.KH; ++kh) {
-#pragma unroll
-            for (int k = 0; k < kMaxNl; ++k)
-                if (k < p.span_nl) stage[swz(64 * k + lane)] = regs[k];     // this kernel row's span -> LDS (in-order per wave)
-            if (kh + 1 < p.KH) request(kh + 1);                             // uniform branch; next row's span flies during the MFMAs
-            else { setup(min(next, ntiles - 1), roff_next); request(0); }   // ... or the next tile's first row (the last tile re-requests itself)
-            const int gbase = kh * p.run_pad;
-            for (int t = 0; t < p.run_pad; t += 2) {                        // (fetching step t + 1's fragments by hand before step t's MFMAs measured 5-10 % slower)
-                const h16x8 x = __builtin_bit_cast(h16x8, stage[swz(roff_cur + t)]);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const h16x8 w = __builtin_bit_cast(h16x8, lw[(gbase + t + h) * NBW + nb * 32 + r]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, acc[nb], 0, 0, 0);
-                }
-            }
-        }
-        store_tile<NB>(stage, acc, lbias, p, tile, cbase, lane);
-        if (next >= ntiles) break;
-        tile = next; roff_cur = roff_next;
-    }
-}
-
 // conv1 -> conv2 fused: conv1's activation (217 KB per 120x160 frame, the largest tensor of the network: 222 MB per 1024
 // frames, written once and read once) never leaves the CU.  A workgroup takes a band of R2 conv2 output rows of one
 // frame, computes the 2 R2 + 3 conv1 rows it needs into an LDS tile (same bias + ReLU + fp16 rounding as the unfused
@@ -1248,117 +633,13 @@ struct Fuse12Params {
     unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
 };
 
-__global__ __launch_bounds__(1024) void trs_conv12_kernel(const Fuse12Params q)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    u4v* lw1 = reinterpret_cast<u4v*>(psmem);                              // [12][32]
-    u4v* lw2 = reinterpret_cast<u4v*>(psmem + q.off_w2);                   // [80][32]
-    float4* lb1 = reinterpret_cast<float4*>(psmem + q.off_b);              // [8]
-    float4* lb2 = lb1 + 8;                                                 // [8]
-    int* lgoff1 = reinterpret_cast<int*>(psmem + q.off_goff);              // [12]
-    unsigned char* tile1 = psmem + q.off_tile;                             // [r1][OW1][24] fp16 (+ padding)
-    u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + wave * 128;
-    for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
-    for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
-    for (int i = tid; i < 8; i += blockDim.x) { lb1[i] = *reinterpret_cast<const float4*>(q.b1 + 4 * i); lb2[i] = *reinterpret_cast<const float4*>(q.c2.bias + 4 * i); }
-    for (int i = tid; i < 12; i += blockDim.x) lgoff1[i] = q.goff1[i];
-    for (int i = tid; i < q.tile_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(tile1)[i] = (u4v)(0u);   // never multiply an uninitialised bit pattern by a zero weight
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
-    const float inv_ow1 = 1.0f / (float)q.OW1, inv_ow2 = 1.0f / (float)q.OW2;
-    int goffs[6];
-#pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6) goffs[s6] = lgoff1[min(2 * s6 + h, 11)];
-    auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
-        qt = (int)(((float)v + 0.5f) * inv); rm = v - qt * d;
-        if (rm < 0) { --qt; rm += d; } else if (rm >= d) { ++qt; rm -= d; }
-    };
-    for (int wt = blockIdx.x; wt < q.N * q.bands; wt += gridDim.x) {
-        const int n = wt / q.bands, b = wt - n * q.bands;
-        const int y2_0 = b * q.R2, r2 = min(q.R2, q.OH2 - y2_0);
-        const int y1_0 = 2 * y2_0, r1 = 2 * (r2 - 1) + 5;
-        // ---- phase 1: conv1 rows y1_0 .. y1_0 + r1 - 1 of frame n -> LDS tile (fp16 NHWC) ----
-        const int npx1 = r1 * q.OW1, ntile1 = (npx1 + 31) >> 5;
-#if TRS_FUSE_ABLATE != 1   /* diagnostic build 1: no conv1 phase */
-        for (int t1 = wave; t1 < ntile1; t1 += nwaves) {                    // (requesting the next tile's dwords ahead measured 6 % slower)
-            const int pp = min(t1 * 32 + r, npx1 - 1);
-            int yl, x;
-            divmod(pp, q.OW1, inv_ow1, yl, x);
-            const int fbase = ((n * q.IH + (y1_0 + yl) * 2) * q.IW + x * 2) * 3;
-            h16x8 xf[6];
-#pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) {
-                const int addr = fbase + goffs[s6], al = addr & ~3;
-                const unsigned sh = (unsigned)addr & 3u;
-                const unsigned w0 = __builtin_amdgcn_raw_buffer_load_b32(rin, al, 0, 0);
-                const unsigned w1 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 4, 0, 0);
-                const unsigned w2 = __builtin_amdgcn_raw_buffer_load_b32(rin, al + 8, 0, 0);
-                const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                const unsigned hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                auto pair = [](unsigned w, int j) -> unsigned {
-                    const float f0 = (float)((w >> (8 * j)) & 255u), f1 = (float)((w >> (8 * j + 8)) & 255u);
-                    return u8pair_h16(f0, f1);
-                };
-                const u4v packed = {pair(lo, 0), pair(lo, 2), pair(hi, 0), pair(hi, 2)};
-                xf[s6] = __builtin_bit_cast(h16x8, packed);
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-            for (int s6 = 0; s6 < 6; ++s6) {
-                const h16x8 w = __builtin_bit_cast(h16x8, lw1[(2 * s6 + h) * 32 + r]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xf[s6], acc, 0, 0, 0);
-            }
-            if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
-                uint2* dst = reinterpret_cast<uint2*>(tile1 + (size_t)pp * 48);
-#pragma unroll
-                for (int qd = 0; qd < 3; ++qd) {
-                    const float4 bb = lb1[2 * qd + h];
-                    float v0 = __builtin_fmaf(acc[4 * qd], kConv1Scale, bb.x), v1 = __builtin_fmaf(acc[4 * qd + 1], kConv1Scale, bb.y), v2 = __builtin_fmaf(acc[4 * qd + 2], kConv1Scale, bb.z), v3 = __builtin_fmaf(acc[4 * qd + 3], kConv1Scale, bb.w);
-                    dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
-                }
-            }
-        }
-#endif
-        __syncthreads();
-        // ---- phase 2: conv2 rows y2_0 .. y2_0 + r2 - 1 from the tile ----
-        const int npx2 = r2 * q.OW2, ntile2 = (npx2 + 31) >> 5;
-        const int m0 = (n * q.OH2 + y2_0) * q.OW2;                          // first output pixel of the band (consecutive in memory)
-#if TRS_FUSE_ABLATE != 2   /* diagnostic build 2: no conv2 phase */
-        for (int t2 = wave; t2 < ntile2; t2 += nwaves) {
-            const int mm = min(t2 * 32 + r, npx2 - 1);
-            int yl2, x2;
-            divmod(mm, q.OW2, inv_ow2, yl2, x2);
-            const unsigned char* abase = tile1 + (size_t)((2 * yl2) * q.OW1 + 2 * x2) * 48 + h * 16;
-            f32x16 acc2[1];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
-            for (int kh = 0; kh < 5; ++kh) {
-                const unsigned char* arow = abase + (size_t)kh * q.OW1 * 48;
-#pragma unroll
-                for (int t = 0; t < 16; t += 2) {
-                    const h16x8 xa = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4v*>(arow + t * 16));
-                    const h16x8 w = __builtin_bit_cast(h16x8, lw2[(kh * 16 + t + h) * 32 + r]);
-                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xa, acc2[0], 0, 0, 0);
-                }
-            }
-            store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
-        }
-#endif
-        __syncthreads();                                                    // the tile is rewritten by the next band
-    }
-}
-
-// The same fused head with conv1's input staged once per band.  In the kernel above every conv1 tile fetches its windows
-// straight from the frame: 18 scattered dword loads and ~100 VALU ops (byte alignment, u8 -> fp16) per lane and 32-pixel tile
-// for 6 MFMAs, each frame byte fetched and unpacked ~6 times - conv1's phase is 70 of the 131 us and bound by the texture
-// addresser.  Here the workgroup loads the band's frame rows ONCE (contiguous in the frame: one coalesced 16-byte load per
+// The fused head with conv1's input staged once per band.  (Rounds 1-2 had a direct form whose conv1 tiles fetched their windows
+// straight from the frame: 18 scattered dword loads and ~100 VALU ops per lane and 32-pixel tile for 6 MFMAs, each frame byte fetched and
+// unpacked ~6 times — conv1's phase was 70 of 131 us, bound by the texture addresser; removed in round 4, a frame shape whose band does not
+// fit runs the two layers unfused.)  Here the workgroup loads the band's frame rows ONCE (contiguous in the frame: one coalesced 16-byte load per
 // thread, requested one item ahead so that its latency hides behind conv1 of the current item), unpacks them once into a fp16
 // image in LDS, and conv1 reads its k-steps (8 consecutive values, 4-byte aligned) from there with two ds_read2_b32.
-// Same values into the same MFMA order: bit-identical to the kernel above and to the separate layers.
+// Same fp16 values as the separate layers; conv2's k dimension runs in column-parity order (see the tile layout below).
 constexpr int kBandPf = 2;                                                  // 16-byte chunks of the band per loader thread (waves 8..15: 512 threads; 4 until round 2:
                                                                             // the 8 registers now hold conv1's bias)
 template <bool SPLIT>
@@ -1498,15 +779,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
 #pragma unroll
     for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
-#ifdef TRS_BAND_STAMPS   /* diagnostic build: shader clocks of workgroup 7's wave 0 (a conv2 wave) and wave 8 (a loader), summed over its items */
-    unsigned long long bst[6] = {0, 0, 0, 0, 0, 0}, bprev = 0; int bitems = 0;
-    const unsigned long long b_t0 = __builtin_amdgcn_s_memtime(), b_r0 = __builtin_amdgcn_s_memrealtime();
-#define BAND_STAMP(k) do { if (blockIdx.x == 7 && lane == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if ((k) > 0) bst[k] += tn - bprev; bprev = tn; } } while (0)
-#else
-#define BAND_STAMP(k) do { } while (0)
-#endif
     while (wt < total) {
-        BAND_STAMP(0);
         const int nxt = wt + 1;                                             // uniform per workgroup
         int n, y2_0, r2, r1, x2_0, w2, w1, skip;
         geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1, skip);
@@ -1554,9 +827,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
         }
 #endif
-        BAND_STAMP(1);
         __syncthreads();                                                    // the tile is complete, the band image is free
-        BAND_STAMP(2);
         if (loader) {
             if (nxt < total) {
                 unpack(raw);                                                // the next item's band (requested an item ago)
@@ -1600,22 +871,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
 #endif
         }
-        BAND_STAMP(3);
         __syncthreads();                                                    // the tile is free, the next band image is complete
-        BAND_STAMP(4);
-#ifdef TRS_BAND_STAMPS
-        ++bitems;
-#endif
         wt = nxt;
     }
-#ifdef TRS_BAND_STAMPS
-    if (blockIdx.x == 7 && tid == 0) {
-        const unsigned long long dt = __builtin_amdgcn_s_memtime() - b_t0, dr = __builtin_amdgcn_s_memrealtime() - b_r0;
-        printf("band head, workgroup 7: %llu shader clocks in %llu ticks of 10 ns = %.2f GHz\n", dt, dr, dr ? (double)dt / (10.0 * (double)dr) : 0.0);
-    }
-    if (blockIdx.x == 7 && lane == 0)
-        printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %llu | wait at barrier %llu | phase 2 work %llu | wait at barrier %llu\n", wave, bitems, bst[1], bst[2], bst[3], bst[4]);
-#endif
 }
 
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
@@ -2052,13 +1310,13 @@ __global__ void trs_zero_controls_kernel(float* a, float* b, float* c, int n)
     } while (0)
 
 struct ConvLayer {
-    int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad, gchunk, lds, ksplit = 1;
+    int KH, KW, S, CIN, COUT, COUT_PAD, IH, IW, OH, OW, G, G_pad;
     bool u8in, out_f32, relu;
-    bool resident = false;                // conv1..7: weights (or a 64-channel slice) live in LDS, persistent workgroups
+    // conv1..7 on the single-layer kernels (trs_conv_u8_kernel, trs_conv_lt_kernel, trs_conv_span_kernel): the weights (or a 64-channel
+    // slice) live in LDS, persistent workgroups
     int res_nb = 1, res_ysplit = 1, res_lds = 0, res_block = 512, res_wg_per_cu = 1;
-    bool res_lt = false;                  // trs_conv_lt_kernel (quad-coalesced loads)
-    bool frame = false, frame_deep = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0, frame_block = 512;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
-    bool frame5 = false; int frame5_f = 1, frame5_lds = 0, frame5_bands = 1, frame5_ohb = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, input frames in LDS)
+    bool frame = false; int frame_f = 1, frame_lds = 0, frame_bands = 1, frame_ohb = 0;   // trs_conv_frame_kernel (3x3 stride-1 layers: F frames' input activations in LDS)
+    bool frame5 = false; int frame5_lds = 0, frame5_bands = 1, frame5_ohb = 0;   // trs_conv_frame5_kernel (conv3: 5x5 stride 2 over 32 channels, one input frame / band per workgroup in LDS)
     bool res_span = false; int span_nl = 0, run_pad = 0;   // trs_conv_span_kernel (stride-2 5x5 layers: per-row input spans staged in LDS)
     u4v* w = nullptr; float* bias = nullptr; int* goff = nullptr;
 };
@@ -2078,11 +1336,10 @@ struct PilotCtx {
     uint8_t* tmp_frames = nullptr; size_t tmp_cap = 0;
     int last_n = 0, last_slices = 1;
     bool no_fuse = false;
-    bool fuse12 = false, fuse_band = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel (conv1's activation stays in LDS)
+    bool fuse12 = false; int fuse_r2 = 0, fuse_lds = 0; Fuse12Params fuse{};   // conv1 -> conv2 in one kernel, band form (conv1's activation stays in LDS)
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
-    bool dense_new = false;               // dense1 (and dense4) on trs_pilot_dense_kernel
-    int chain_first = -1, chain_lds = 0, chain_block = 512; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
+    int chain_first = -1, chain_lds = 0; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
     bool chain_mid_valid = true;          // act[chain_first .. 5] hold the last pass (the chain never writes them; the debug getter runs the single layers on demand)
     u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
     trs_pilot_tuning tun{};               // the kernel choices this context was loaded with (trs_pilot_set_tuning, else the defaults)
@@ -2114,50 +1371,26 @@ int upload(T** dst, const std::vector<T>& v)
     return TRS_OK;
 }
 
-// split-K only as far as it takes to fill the chip about twice (every extra slice is another slab for the tail kernel to add;
-// dense1 at 240x320: 551 one-chunk slices x 4 row tiles spent 166 us), and never an empty slice
-int split_k_slices(const ConvLayer& l, int n_img, int cu_count, const trs_pilot_tuning& T)
-{
-    if (l.ksplit <= 1) return 1;
-    const int M = n_img * l.OH * l.OW, grid = (M + kRowsPerWg - 1) / kRowsPerWg;
-    int want = std::max(1, (2 * cu_count + grid - 1) / grid);
-    if (T.ksplit > 0) want = T.ksplit;
-    const int ks = std::min(l.ksplit, want);
-    const int nchunks = (l.G_pad + l.gchunk - 1) / l.gchunk, cps = (nchunks + ks - 1) / ks;
-    return (nchunks + cps - 1) / cps;
-}
-
-int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count, const trs_pilot_tuning& T)
+int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, int n_img, hipStream_t s, int cu_count)
 {
     ConvParams p{};
     p.in = in; p.w = l.w; p.bias = l.bias; p.goff = l.goff; p.out = out;
     if (in_bytes > 0x7FFFFFFFull) return trs_internal_fail(TRS_ERR_LIMIT, "activation larger than 2 GiB: lower the batch");
     p.in_bytes = (int)in_bytes;
     p.N = n_img; p.IH = l.IH; p.IW = l.IW; p.CIN = l.CIN; p.OH = l.OH; p.OW = l.OW; p.COUT = l.COUT; p.COUT_PAD = l.COUT_PAD; p.S = l.S;
-    p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW; p.gchunk = l.gchunk;
+    p.G = l.G; p.G_pad = l.G_pad; p.M = n_img * l.OH * l.OW;
     p.relu = l.relu; p.out_f32 = l.out_f32; p.in_px_bytes = l.u8in ? 3 : l.CIN * 2;
-    p.ksplit = l.ksplit;
     p.oscale = l.u8in ? kConv1Scale : 1.0f;
-    {
-        const size_t nt_mb = (size_t)std::max(0, T.nt_mb);                 // outputs above this many MB (128) leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
-        const int nt_kind = T.nt_kind;
-        p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > (nt_mb << 20)) ? nt_kind : 0;
-    }
+    // outputs above 128 MB leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
+    p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > ((size_t)128 << 20)) ? 1 : 0;
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
-    if (l.frame5) {
+    if (l.frame5) {                                                         // one unit (frame or row band) per 4-wave workgroup, two workgroups per CU
         Frame5Params q{};
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
-        q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = l.frame5_f; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
+        q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = 1; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
         q.bands = l.frame5_bands; q.ohb = l.frame5_ohb; q.ihb = l.frame5_bands == 1 ? l.IH : 2 * l.frame5_ohb + 3;
-        const int n_units = n_img * q.bands;
-#define LAUNCH_F5(NT_, BLOCK_, MINB_, GRID_)                                                                                  \
-    do {                                                                                                                      \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((trs_conv_frame5_kernel<NT_, 4, BLOCK_, MINB_>), dim3(GRID_), dim3(BLOCK_), l.frame5_lds, s, q);  \
-    } while (0)
-        if (q.F == 1) LAUNCH_F5(2, 256, 2, n_units);                        // one unit per workgroup, two workgroups per CU
-        else LAUNCH_F5(2, 512, 1, (n_units + q.F - 1) / q.F);
-#undef LAUNCH_F5
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<2, 4, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((trs_conv_frame5_kernel<2, 4, 256, 2>), dim3(n_img * q.bands), dim3(256), l.frame5_lds, s, q);
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
@@ -2168,68 +1401,34 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
         q.bands = l.frame_bands; q.ohb = l.frame_ohb; q.ihb = l.frame_ohb + l.KH - 1;
         const int grid = (n_img * q.bands + q.F - 1) / q.F;
-#define LAUNCH_FRAME(NT_, HALF_, R_, BLOCK_)                                                                                  \
+#define LAUNCH_FRAME(NT_, HALF_)                                                                                              \
     do {                                                                                                                      \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<NT_, 2, HALF_, R_, BLOCK_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((trs_conv_frame_kernel<NT_, 2, HALF_, R_, BLOCK_>), dim3(grid), dim3(BLOCK_), l.frame_lds, s, q);  \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<NT_, 2, HALF_, 4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((trs_conv_frame_kernel<NT_, 2, HALF_, 4, 512>), dim3(grid), dim3(512), l.frame_lds, s, q);        \
     } while (0)
         // 32-pixel tiles per wave item: 2, or 3 where that leaves the busiest SIMD no more MFMAs (3 streams a third less weights through L1)
         const int px = std::min(q.F, n_img * q.bands) * q.ohb * q.OW, cgrps = q.COUT_PAD / 64;
         auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
-        int nt = busiest(3) <= busiest(2) ? 3 : 2;
-        if (T.frame_nt == 2 || T.frame_nt == 3) nt = T.frame_nt;
-        if (l.frame_deep) nt = 2;
-        if (l.frame_block == 256 && !l.frame_deep) {                       // four waves per workgroup, two workgroups per CU (trs_pilot_tuning.frame_block)
-            if (q.cg == 8) { if (nt == 3) LAUNCH_FRAME(3, 4, 4, 256); else LAUNCH_FRAME(2, 4, 4, 256); }
-            else { if (nt == 3) LAUNCH_FRAME(3, 8, 4, 256); else LAUNCH_FRAME(2, 8, 4, 256); }
-        } else if (q.cg == 8) { if (l.frame_deep) LAUNCH_FRAME(2, 4, 12, 512); else if (nt == 3) LAUNCH_FRAME(3, 4, 4, 512); else LAUNCH_FRAME(2, 4, 4, 512); }
-        else { if (l.frame_deep) LAUNCH_FRAME(2, 8, 8, 512); else if (nt == 3) LAUNCH_FRAME(3, 8, 4, 512); else LAUNCH_FRAME(2, 8, 4, 512); }
+        const int nt = busiest(3) <= busiest(2) ? 3 : 2;
+        if (q.cg == 8) { if (nt == 3) LAUNCH_FRAME(3, 4); else LAUNCH_FRAME(2, 4); }
+        else { if (nt == 3) LAUNCH_FRAME(3, 8); else LAUNCH_FRAME(2, 8); }
 #undef LAUNCH_FRAME
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
-    if (l.resident) {
-        const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
-        const int grid_x = std::max(1, std::min((ntiles + waves - 1) / waves, cu_count * l.res_wg_per_cu));
-#define LAUNCH_RES(NB, U8)                                                                                                   \
+    const int waves = l.res_block / 64, ntiles = (p.M + 31) / 32;
+    const int grid_x = std::max(1, std::min((ntiles + waves - 1) / waves, cu_count * l.res_wg_per_cu));
+#define LAUNCH_K(KERNEL)                                                                                                     \
     do {                                                                                                                     \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_u8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
-        hipLaunchKernelGGL((trs_conv_u8_kernel), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p); \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
+        hipLaunchKernelGGL((KERNEL), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);                        \
     } while (0)
-#define LAUNCH_LT(NB)                                                                                                        \
-    do {                                                                                                                     \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_lt_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
-        hipLaunchKernelGGL((trs_conv_lt_kernel<NB>), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);        \
-    } while (0)
-#define LAUNCH_SPAN(NB, SW)                                                                                                  \
-    do {                                                                                                                     \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_span_kernel<NB, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, l.res_lds)); \
-        hipLaunchKernelGGL((trs_conv_span_kernel<NB, SW>), dim3(grid_x, l.res_ysplit), dim3(l.res_block), l.res_lds, s, p);  \
-    } while (0)
-        const bool swz = (l.S * (l.CIN / 8)) % 8 == 0;
-        if (l.u8in) LAUNCH_RES(1, true);   // conv1
-        else if (l.res_span && l.res_nb == 1 && swz) LAUNCH_SPAN(1, true);
-        else if (l.res_span && l.res_nb == 1) LAUNCH_SPAN(1, false);
-        else if (l.res_span && swz) LAUNCH_SPAN(2, true);
-        else if (l.res_span) LAUNCH_SPAN(2, false);
-        else if (l.res_lt && l.res_nb == 1) LAUNCH_LT(1);
-        else LAUNCH_LT(2);
-#undef LAUNCH_LT
-#undef LAUNCH_SPAN
-#undef LAUNCH_RES
-        HIPCHK(hipGetLastError());
-        return TRS_OK;
-    }
-    const int grid = (p.M + kRowsPerWg - 1) / kRowsPerWg;
-    const int ks = split_k_slices(l, n_img, cu_count, T);                  // > 1: `out` is the slab buffer [ks][M][COUT]
-    p.ksplit = ks;
-    const int nb = l.COUT_PAD / 32;
-#define LAUNCH(NB, U8) hipLaunchKernelGGL((trs_conv_mfma_kernel<NB, U8>), dim3(grid, ks), dim3(kConvBlock), l.lds, s, p)
-    if (l.u8in) LAUNCH(1, true);
-    else if (nb == 1) LAUNCH(1, false);
-    else if (nb == 2) LAUNCH(2, false);
-    else LAUNCH(4, false);
-#undef LAUNCH
+    if (l.u8in) LAUNCH_K(trs_conv_u8_kernel);                               // conv1 as its own layer
+    else if (l.res_span && l.res_nb == 1) LAUNCH_K((trs_conv_span_kernel<1, false>));   // conv2 unfused (24 input channels: 6 granules per pixel pair, no swizzle)
+    else if (l.res_span) LAUNCH_K((trs_conv_span_kernel<2, true>));         // conv3 where its frames do not fit LDS (240x320)
+    else if (l.res_nb == 1) LAUNCH_K(trs_conv_lt_kernel<1>);                // the fallback of every other (layer, shape)
+    else LAUNCH_K(trs_conv_lt_kernel<2>);
+#undef LAUNCH_K
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
@@ -2289,19 +1488,14 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         q.c2.nt_out = 0;
         int grid = std::max(1, std::min(n * q.bands * std::max(1, q.wsplit), c->cu_count));
         // rolling bands when there are enough (frame, part) streams for every CU (a small batch keeps one band per workgroup: more parallelism)
-        q.roll = (c->fuse_band && c->tun.fuse_roll && n * std::max(1, q.wsplit) >= c->cu_count && q.bands > 1) ? 1 : 0;
+        q.roll = (c->tun.fuse_roll && n * std::max(1, q.wsplit) >= c->cu_count && q.bands > 1) ? 1 : 0;
         if (q.roll) grid = std::min(n * std::max(1, q.wsplit), c->cu_count);
-        if (c->fuse_band) {
-            if (q.wsplit > 1) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
-                hipLaunchKernelGGL(trs_conv12_band_kernel<true>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
-            } else {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
-                hipLaunchKernelGGL(trs_conv12_band_kernel<false>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
-            }
+        if (q.wsplit > 1) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+            hipLaunchKernelGGL(trs_conv12_band_kernel<true>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
         } else {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
-            hipLaunchKernelGGL(trs_conv12_kernel, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv12_band_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, c->fuse_lds));
+            hipLaunchKernelGGL(trs_conv12_band_kernel<false>, dim3(grid), dim3(1024), c->fuse_lds, v.stream, q);
         }
         HIPCHK(hipGetLastError());
         in = c->act[1];
@@ -2313,13 +1507,8 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         if (i == c->chain_first) {                                          // conv(i + 1) .. conv7 in one launch, activations in LDS
             ChainParams q = c->chain;
             q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
-            if (c->chain_block == 256) {                                     // two workgroups of four waves per CU (their LDS images fit side by side)
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
-                hipLaunchKernelGGL(trs_conv_chain_kernel<256>, dim3((n + q.F - 1) / q.F), dim3(256), c->chain_lds, v.stream, q);
-            } else {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
-                hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
-            }
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
+            hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
             HIPCHK(hipGetLastError());
             in = c->act[6];
             in_bytes = (size_t)n * c->act_elems[6] * 2;
@@ -2328,8 +1517,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
         }
         void* out = c->act[i];
         if (i == 7) {                                                       // dense1: one fp32 slab per K slice, added in order by the tail kernel
-            if (c->dense_new) { int gps; dense_plan(c->L[7], n, c->cu_count, c->tun, &gps, &c->last_slices); }
-            else c->last_slices = split_k_slices(c->L[7], n, c->cu_count, c->tun);
+            { int gps; dense_plan(c->L[7], n, c->cu_count, c->tun, &gps, &c->last_slices); }
             const size_t need = (size_t)c->last_slices * n * c->act_elems[7] * sizeof(float);
             if (c->slab_bytes < need) {
                 HIPCHK(hipStreamSynchronize(v.stream));
@@ -2339,16 +1527,14 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             }
             out = c->slab;
         }
-        int rc = (i == 7 && c->dense_new) ? launch_dense(c, c->L[7], in, n, out, v.stream)
-                                          : launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count, c->tun);
+        int rc = i == 7 ? launch_dense(c, c->L[7], in, n, out, v.stream) : launch_conv(c->L[i], in, in_bytes, out, n, v.stream, c->cu_count);
         if (rc) return rc;
         if (i == 0) c->act0_valid = true;
         in = c->act[i];
         in_bytes = (size_t)n * c->act_elems[i] * (c->L[i].out_f32 ? 4 : 2);
     }
     if (c->arch == TRS_PILOT_FULL_HOUSE) {                                 // the steering head's dense4 reads conv7's output as well
-        if (c->dense_new) { int gps; dense_plan(c->L[8], n, c->cu_count, c->tun, &gps, &c->last_slices2); }
-        else c->last_slices2 = split_k_slices(c->L[8], n, c->cu_count, c->tun);
+        { int gps; dense_plan(c->L[8], n, c->cu_count, c->tun, &gps, &c->last_slices2); }
         const size_t need = (size_t)c->last_slices2 * n * c->act_elems[8] * sizeof(float);
         if (c->slab2_bytes < need) {
             HIPCHK(hipStreamSynchronize(v.stream));
@@ -2356,8 +1542,7 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
             HIPCHK(hipMalloc(&c->slab2, need));
             c->slab2_bytes = need;
         }
-        int rc = c->dense_new ? launch_dense(c, c->L[8], c->act[6], n, c->slab2, v.stream)
-                              : launch_conv(c->L[8], c->act[6], (size_t)n * c->act_elems[6] * 2, c->slab2, n, v.stream, c->cu_count, c->tun);
+        int rc = launch_dense(c, c->L[8], c->act[6], n, c->slab2, v.stream);
         if (rc) return rc;
     }
     c->last_n = n;
@@ -2443,8 +1628,8 @@ TRS_EXPORT void trs_default_pilot_tuning(trs_pilot_tuning* t)
     if (!t) return;
     std::memset(t, 0, sizeof *t);
     t->struct_size = (uint32_t)sizeof *t;
-    t->fuse_band_r2 = 6; t->fuse_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
-    t->fuse_roll = 1; t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->chain_nb = 2; t->dense = 1; t->min_waves = 7; t->nt_mb = 128; t->nt_kind = 1;
+    t->fuse_band_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
+    t->fuse_roll = 1; t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->dense = 1;
 }
 
 TRS_EXPORT int trs_pilot_set_tuning(trs_env* e, const trs_pilot_tuning* t)
@@ -2492,18 +1677,10 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         const int run = l.u8in ? 2 : l.KW * l.CIN / 8, run_pad = l.u8in ? 2 : (run + 3) & ~3;
         l.G = l.KH * run_pad;
         l.G_pad = (l.G + 3) & ~3;
-        l.gchunk = std::max(4, std::min(l.G_pad, (kLdsWeightBytes / (l.COUT_PAD * 16)) & ~3));
-        l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
-        if (i >= 7) {      // dense1: few row tiles, long K -> one LDS chunk per workgroup along K (ReLU moves into the tail kernel)
-            l.gchunk = std::min(l.gchunk, 16);
-            l.lds = l.gchunk * l.COUT_PAD * 16 + l.G_pad * 4;
-            l.ksplit = (l.G_pad + l.gchunk - 1) / l.gchunk;
-        }
-        if (i < 7) {       // conv layers: resident weights, at most 64 output channels per slice (NB <= 2 keeps 16 waves per CU in registers)
-            l.resident = true;
+        if (i >= 7 && (l.COUT_PAD != 128 || l.G % 16 != 0)) return trs_internal_fail(TRS_ERR_LIMIT, "dense1's shape does not suit trs_pilot_dense_kernel");   // (never for Keras_2D_CNN: 100 outputs, 16 granules per pixel of conv7's output)
+        if (i < 7) {       // conv layers on their single-layer kernels: resident weights, at most 64 output channels per slice (NB <= 2 keeps 16 waves per CU in registers)
             l.res_nb = std::min(2, l.COUT_PAD / 32);
             l.res_ysplit = l.COUT_PAD / (32 * l.res_nb);
-            l.res_lt = !l.u8in;                                               // fp16 inputs: quad-coalesced loads + LDS transpose
             l.run_pad = run_pad;
             // stride-2 layers with wide kernels re-fetch every byte ~2.5x through overlapping windows: span staging instead
             const int cgr = l.CIN / 8, pix_gran = l.S * cgr;
@@ -2516,10 +1693,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             }
             const int stage_per_wave = l.res_span ? l.span_nl * 1024 : 2048;  // input transpose / span stage; output transpose (all kernels)
             auto lds_for = [&](int nb, int waves) { return l.G_pad * nb * 32 * 16 + ((l.G_pad * 4 + 15) & ~15) + nb * 32 * 4 + waves * stage_per_wave; };
-            const int min_waves = T.min_waves;                                // 7: conv7's 64-channel slices at 7 waves beat 32-channel slices at 16 (240x320: 199 -> 143 us; the pixels are read twice instead of four times)
-            if (lds_for(l.res_nb, min_waves) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // conv7: 32-channel slices
-            const int base = lds_for(l.res_nb, 0);
-            if (base + 4 * stage_per_wave > 160 * 1024) l.resident = false;    // does not happen for Keras_2D_CNN; the chunked kernel takes over
+            // conv7's 64-channel slices at 7 waves beat 32-channel slices at 16 (240x320: 199 -> 143 us; the pixels are read twice instead of four times)
+            if (lds_for(l.res_nb, 7) > 160 * 1024) { l.res_nb = 1; l.res_ysplit = l.COUT_PAD / 32; }    // 32-channel slices
+            if (lds_for(l.res_nb, 4) > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "a convolution's weight slice does not fit LDS");   // (never for Keras_2D_CNN)
             // workgroups per CU and waves per workgroup: about 16 waves per CU when LDS allows
             l.res_wg_per_cu = 1;
             for (int wg = 4; wg >= 1; --wg) {
@@ -2531,11 +1707,6 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             while (waves > 4 && l.res_wg_per_cu * (lds_for(l.res_nb, waves) + 512) > 160 * 1024) --waves;
             l.res_block = 64 * waves;
             l.res_lds = lds_for(l.res_nb, waves);
-            if (T.waves > 0) {                                                // tuning: waves per CU
-                const int wv = std::max(4, std::min(32, (int)T.waves));
-                const int w2 = std::max(1, std::min(16, wv / l.res_wg_per_cu));
-                if (l.res_wg_per_cu * (lds_for(l.res_nb, w2) + 512) <= 160 * 1024) { l.res_block = 64 * w2; l.res_lds = lds_for(l.res_nb, w2); }
-            }
         }
         if (i >= 3 && i < 7) {   // conv4..7: frames in LDS when they fit (240x320: conv7's 167 KB frame does not: the quad-load kernel stays)
             const int mask = T.frame_layers_mask;                             // bit i = conv(i+1) (0x78)
@@ -2545,21 +1716,12 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 // a frame larger than ~110 KB is cut into row bands (conv7 at 240x320: 21 x 31 x 128 = 167 KB -> 2 bands of 10 / 9 rows)
                 int bands = 1;
                 while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
-                if (T.frame_bands[i - 3] > 0) bands = std::max(bands, std::min((int)T.frame_bands[i - 3], l.OH));   // tuning (0 = automatic)
-                int ohb = (l.OH + bands - 1) / bands;
-                if (T.frame_ohb[i - 3] > 0) { ohb = std::min((int)T.frame_ohb[i - 3], l.OH); bands = (l.OH + ohb - 1) / ohb; }   // tuning: rows per band (the last band takes what is left)
+                const int ohb = (l.OH + bands - 1) / bands;
                 const int ihb = ohb + l.KH - 1;
                 const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
                 // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
                 int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
-                if (T.frame_f > 0) f = T.frame_f;
                 while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
-                l.frame_block = 512;
-                if (T.frame_block == 256 && 2 * (unit_bytes + l.COUT_PAD * 4) <= 158 * 1024) {   // two 4-wave workgroups per CU, as many units each as fit side by side
-                    l.frame_block = 256;
-                    f = (int)std::max<size_t>(1, std::min<size_t>(f, (78 * 1024) / unit_bytes));
-                }
-                l.frame_deep = T.frame_deep != 0;
                 l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
                 l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
             }
@@ -2571,21 +1733,13 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             // two workgroups of one band per CU)
             int bands = 1;
             while (bands < l.OH && (size_t)(bands == 1 ? l.IH : 2 * ((l.OH + bands - 1) / bands) + 3) * l.IW * 64 > 78 * 1024) ++bands;
-            if (T.frame5_bands > 0) bands = std::max(bands, std::min((int)T.frame5_bands, l.OH));
             const int ohb = (l.OH + bands - 1) / bands, ihb = bands == 1 ? l.IH : 2 * ohb + 3;
             const size_t unit = (size_t)ihb * l.IW * 64;
-            int f = (int)std::min<size_t>(4, (156 * 1024) / unit);
-            if (bands > 1) f = std::min(f, 1);
-            // two or three frames per CU: one frame per workgroup of four waves, two workgroups side by side - one stages its frame while the
-            // other computes (round 3: closed loop 192.7 -> 189.3 us on one box, 193.5 -> 193.3 on another; never slower)
-            if (T.frame5_f > 0) f = std::max(1, std::min(f, (int)T.frame5_f));
-            else {
-                if (f >= 2 && f <= 3) f = 1;
-                while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
-            }
-            // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; TRS_PILOT_FRAME5 = 2 forces bands)
-            if (on && (bands == 1 || on >= 2) && shape_ok && f >= 1 && f * unit + 256 <= 158 * 1024) {
-                l.frame5 = true; l.frame5_f = f; l.frame5_lds = (int)(f * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
+            // one unit (frame or band) per workgroup of four waves, two or more workgroups side by side on a CU: one stages its frame while the
+            // other computes (round 3: closed loop 192.7 -> 189.3 us on one box, 193.5 -> 193.3 on another; never slower than two frames per 8-wave workgroup)
+            // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; frame5 = 2 forces bands)
+            if (on && (bands == 1 || on >= 2) && shape_ok && unit + 256 <= 158 * 1024) {
+                l.frame5 = true; l.frame5_lds = (int)unit + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
             }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of fp16 and the per-granule input offsets ----
@@ -2662,8 +1816,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
-        const int want_r2 = std::max(1, (int)T.fuse_r2);                  // 6: measured at 120x160 x 1024 frames: R2 = 8 / 6 / 5 / 4 / 3 -> 145 / 132 / 151 / 148 / 169 us
-        c->fuse12 = false; c->fuse_band = false; c->no_fuse = T.no_fuse != 0;
+        c->fuse12 = false; c->no_fuse = T.no_fuse != 0;
         // band form (conv1's input staged once per band as a fp16 image): tile + band image + 8 wave stages
         // (measured, 1024 frames of 120x160: R2 = 7 / 6 / 5 -> 129 / 114 / 125 us against 131 for the direct form; 512 frames of
         // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
@@ -2678,7 +1831,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * ((l0.OW + 1) / 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;   // two column-parity planes per row
             q.off_band = off; q.band_bytes = rows_in * row_in * 2 + 64; off += q.band_bytes;
             q.off_stage = off; off += 8 * 2048;
-            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; q.wsplit = 1; break; }
+            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; q.wsplit = 1; break; }
         }
         // the band cut in width (240x320: a whole-width band does not fit): parts of w2p conv2 columns, each with its own conv1 tile and
         // staged frame-row segments (a part re-stages 2 x 3 + 3 input columns and recomputes 3 conv1 columns of its neighbour)
@@ -2698,7 +1851,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 q.off_band = off; q.band_bytes = rows_in * cpr * 32 + 64; off += q.band_bytes;
                 q.off_stage = off; off += 8 * 2048;
                 if (off > 160 * 1024) continue;
-                c->fuse12 = true; c->fuse_band = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2;
+                c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2;
                 q.wsplit = ws; q.w2p = w2p; q.cpr = cpr;
                 q.magic_full = (unsigned)((0x100000000ull + (unsigned)w1m - 1u) / (unsigned)w1m);
                 q.magic_last = (unsigned)((0x100000000ull + (unsigned)w1_last - 1u) / (unsigned)w1_last);
@@ -2706,17 +1859,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 break;
             }
         }
-        for (int r2 = std::min(want_r2, l1.OH); shape_ok && !c->fuse12 && r2 >= 1; --r2) {
-            int off = 12 * 32 * 16;
-            q.off_w2 = off; off += 80 * 32 * 16;
-            q.off_b = off; off += 16 * 16;
-            q.off_goff = off; off += 64;
-            q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * l0.OW * 48 + 64) + 15) & ~15; off += q.tile_bytes;
-            q.off_stage = off; off += 16 * 2048;
-            if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; break; }
-        }
     }
-    if (c->fuse12 && c->fuse_band) {           // the band kernel reads conv1 columns by parity: conv2's granules in that order
+    if (c->fuse12) {                            // the band kernel reads conv1 columns by parity: conv2's granules in that order
         const ConvLayer& l1 = c->L[1];
         std::vector<u4v> orig((size_t)l1.G_pad * l1.COUT_PAD), perm(orig.size());
         HIPCHK(hipMemcpy(orig.data(), l1.w, orig.size() * sizeof(u4v), hipMemcpyDeviceToHost));
@@ -2744,7 +1888,6 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             auto in_bytes_of = [&](int i) { return (size_t)c->L[i].IH * c->L[i].IW * c->L[i].CIN * 2; };
             for (int f = 4; f >= 2 && c->chain_first < 0; f -= 2) {
                 if (f > 2 && (c->n_cap + f - 1) / f < c->cu_count) continue;          // keep a workgroup per CU
-                if (T.chain_f == 2 && f > 2) continue;
                 const bool split = nl == 4;
                 size_t a, b;
                 if (split) { a = std::max(f * out_bytes(3), f * out_bytes(5)); b = std::max((size_t)(f / 2) * in_bytes_of(3), f * out_bytes(4)); }
@@ -2754,8 +1897,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 if (total > 158 * 1024) continue;
                 ChainParams& q = c->chain;
                 q = ChainParams{};
-                // waves per workgroup: 8 (one workgroup per CU), or 4 when two workgroups' LDS images fit a CU side by side (trs_pilot_tuning.chain_f = 2)
-                const int nw = (T.chain_f == 2 && f == 2 && 2 * total <= 158 * 1024) ? 4 : 8;
+                constexpr int nw = 8;                                               // waves per workgroup, one workgroup per CU
                 q.F = f; q.nl = nl; q.split_first = split ? 1 : 0; q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
                 for (int j = 0; j < nl; ++j) {
                     const ConvLayer& l = c->L[first + j];
@@ -2773,41 +1915,21 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         }
                         return worst;
                     };
-                    auto pick = [&](int cnb, int& nt_out, int& items_out) {          // the better tile height for cnb channel blocks
-                        int best = 1 << 30, best_waves = 0;
-                        for (int cnt = 3; cnt >= 2; --cnt) {
-                            if (T.chain_nt == 2 || T.chain_nt == 3) { if (cnt != T.chain_nt) continue; }
-                            int wv = 0;
-                            const int m = busiest(cnt, cnb, wv);
-                            if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt_out = cnt; }
-                        }
-                        items_out = ((px + 32 * nt_out - 1) / (32 * nt_out)) * (l.COUT / (32 * cnb));
-                        return best;
-                    };
-                    int nt = 2, nb = 2, items2 = 0;
-                    const int m2 = pick(2, nt, items2);
-                    if (T.chain_nb == 1) { int it1; pick(1, nt, it1); nb = 1; }
-                    else if (T.chain_nb == 0 && 2 * items2 <= nw) {                  // automatic: 32-channel items where 64-channel items leave half the waves idle
-                        int nt1 = 2, it1 = 0;
-                        if (pick(1, nt1, it1) <= m2) { nt = nt1; nb = 1; }
+                    // the better tile height (2 or 3 tiles of 32 pixels) for items of 64 output channels (items of 32 channels — twice the ring depth,
+                    // two waves on every SIMD — were measured in round 3: the kernel 105 k against 107 k clocks, the closed loop equal; removed in round 4)
+                    int nt = 2, best = 1 << 30, best_waves = 0;
+                    for (int cnt = 3; cnt >= 2; --cnt) {
+                        int wv = 0;
+                        const int m = busiest(cnt, 2, wv);
+                        if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt = cnt; }
                     }
-                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, nb};
+                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, 2};
                 }
-                c->chain_first = first; c->chain_lds = (int)total; c->chain_block = nw * 64;
+                c->chain_first = first; c->chain_lds = (int)total;
             }
         }
     }
-    {   // dense1 (and dense4) on trs_pilot_dense_kernel; TRS_PILOT_DENSE = 0: the chunked kernel (A/B measurements)
-        const int mode = T.dense;
-        c->dense_new = mode >= 1 && c->L[7].COUT_PAD == 128 && c->L[7].G % 16 == 0;
-    }
     HIPCHK(hipMalloc((void**)&c->raw, (size_t)c->n_cap * 2 * sizeof(float)));
-    for (const ConvLayer& l : c->L) {
-        const int nb = l.COUT_PAD / 32;
-        const void* fn = l.u8in ? (const void*)trs_conv_mfma_kernel<1, true> : nb == 1 ? (const void*)trs_conv_mfma_kernel<1, false>
-                       : nb == 2 ? (const void*)trs_conv_mfma_kernel<2, false> : (const void*)trs_conv_mfma_kernel<4, false>;
-        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    }
     *slot = guard.release();
     return TRS_OK;
 }
@@ -2911,14 +2033,14 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
     if (n_floats != total) return trs_internal_fail(TRS_ERR_ARG, "size mismatch");
     HIPCHK(hipSetDevice(v.device));
     if (layer == 0 && !c->act0_valid) {                                     // the fused head never wrote conv1's activation: run the unfused conv1 now
-        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count, c->tun);
+        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count);
         if (rc) return rc;
         c->act0_valid = true;
     }
     if (c->chain_first >= 0 && layer >= c->chain_first && layer < 6 && !c->chain_mid_valid) {   // the chain kept these activations in LDS: run the single layers now
         for (int j = c->chain_first; j < 6; ++j) {
             const void* src = j == 0 ? (const void*)c->last_frames : c->act[j - 1];
-            int rc = launch_conv(c->L[j], src, (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count, c->tun);
+            int rc = launch_conv(c->L[j], src, (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count);
             if (rc) return rc;
         }
         c->chain_mid_valid = true;
@@ -2944,13 +2066,13 @@ TRS_EXPORT int trs_pilot_debug_layer(trs_env* e, int layer, float* h_dst, size_t
 static int materialise_layers(PilotCtx* c, const TrsEnvView& v, int upto)
 {
     if (!c->act0_valid) {
-        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count, c->tun);
+        int rc = launch_conv(c->L[0], c->last_frames, (size_t)c->last_n * c->H * c->W * 3, c->act[0], c->last_n, v.stream, c->cu_count);
         if (rc) return rc;
         c->act0_valid = true;
     }
     if (c->chain_first >= 0 && upto >= c->chain_first && !c->chain_mid_valid) {
         for (int j = c->chain_first; j < 6; ++j) {
-            int rc = launch_conv(c->L[j], c->act[j - 1], (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count, c->tun);
+            int rc = launch_conv(c->L[j], c->act[j - 1], (size_t)c->last_n * c->act_elems[j - 1] * 2, c->act[j], c->last_n, v.stream, c->cu_count);
             if (rc) return rc;
         }
         c->chain_mid_valid = true;

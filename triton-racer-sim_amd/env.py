@@ -410,7 +410,7 @@ class BatchedEnv:
 
     def pilot_tuning(self, **choices):
         """Override kernel choices of the NEXT ``pilot_load`` (``trs_pilot_tuning``, include/trsim.h) — tests that compare a kernel
-        with the one it replaced, and measurements.  No arguments: back to the defaults.  ``frame_bands`` and ``frame_ohb`` take 4 ints."""
+        with the one it replaced, and measurements.  No arguments: back to the defaults."""
         if not choices:
             self.api.check(self.api.pilot_set_tuning(self._h, None), "pilot_set_tuning")
             return
@@ -420,11 +420,7 @@ class BatchedEnv:
         for k, v in choices.items():
             if k not in names:
                 raise ValueError(f"trs_pilot_tuning has no field {k!r}")
-            if k in ("frame_bands", "frame_ohb"):
-                for i, b in enumerate(v):
-                    getattr(t, k)[i] = int(b)
-            else:
-                setattr(t, k, int(v))
+            setattr(t, k, int(v))
         self.api.check(self.api.pilot_set_tuning(self._h, C.byref(t)), "pilot_set_tuning")
 
     def resident_lifetime(self, life_us):
