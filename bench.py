@@ -386,8 +386,8 @@ def main():
         run = lambda k_: env.step_pilot(k_)
     else:
         run = lambda k_: env.step_synthetic(k_, spl)
-    # the resident worker renders; physics-only envs and the pilot loop go through launches (the pilot's kernels need the CUs' LDS)
-    resident = bool((args.resident or args.step_mode == "resident") and render and not args.pilot and spl == 1)
+    # the pilot loop goes through launches (the pilot's kernels need the CUs' LDS); physics-only envs have their own resident worker since round 4
+    resident = bool((args.resident or args.step_mode == "resident") and not args.pilot and spl == 1)
     if resident:
         # idle_us: the worker leaves by itself after this long without a post.  The library's default (2 ms) suits an interactive loop; a
         # benchmark whose host thread can be descheduled for milliseconds (a tracer attached, the GIL) would see its worker leave and be
@@ -683,7 +683,7 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_key": traffic_key,
                 "frac_by_wall_clock": round(B * n * args.steps / wall / 1e9 / HBM_PEAK_GBS, 5),
-                "kernel": "trs_worker_kernel" if resident else ("trs_step_kernel" if render else "trs_physics_kernel"), "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                "kernel": ("trs_worker_kernel" if render else "trs_physics_worker_kernel") if resident else ("trs_step_kernel" if render else "trs_physics_kernel"), "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "bytes_per_env_step": B, "env_steps_per_launch": round(per_launch, 2), "launches": launches,
             },
         }
