@@ -687,18 +687,22 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
     }
     Duties none{false, false, 0};
     u64 owed = wp.start;                                     // oldest step this wave has not arrived for
-    // One step's inputs: the entry of the device ring and this env's controls.  While step s integrates (~2 us of dependent arithmetic) the
-    // inputs of step s + 1 are already on their way when that step is posted: its entry read and its control loads — two dependent memory
-    // round trips, ~1.5 us — leave the step's critical path (a tick posted on its own: 3.9 -> ~2.5 us at 256 envs).
-    struct StepIn { float steer, thr, brk; uint8_t rin; int synth; };
-    auto fetch_inputs = [&](u64 s) -> StepIn {
+    // One step's inputs come through two dependent memory round trips: the step's entry in the device ring (control POINTERS, ~0.7 us), then
+    // this env's controls (system-scope loads, ~1 us).  Both leave the critical path when the consumer keeps steps queued: while step s
+    // integrates (~2 us of dependent arithmetic), the controls of step s + 1 and the entry of step s + 2 are already on their way
+    // (a tick posted on its own: 3.9 us with neither, 3.0 with the controls, see profiles/r04_sweep.txt for both).
+    struct Ctl { float steer, thr, brk; uint8_t rin; int synth; };
+    auto entry_load = [&](u64 s) -> u64 {                    // lanes 1..5: steer, thr, brk, reset, synth of step s (WEntry words)
         const u64* en = reinterpret_cast<const u64*>(&wp.dc->ring[s & (kSlots - 1)]);
-        const u64 ev = lane < 6 ? agent_load64(en + lane) : 0ull;   // words 1..5 of the entry (WEntry): steer, thr, brk, reset, synth
-        const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 1));   // (the readlanes wait for the load)
+        return lane < 6 ? agent_load64(en + lane) : 0ull;
+    };
+    auto ctl_load = [&](u64 ev) -> Ctl {                     // reading the entry's lanes waits for its load; the control loads are only issued here
+        const float* const c_st = reinterpret_cast<const float*>(lane_u64(ev, 1));
         const float* const c_th = reinterpret_cast<const float*>(lane_u64(ev, 2));
         const float* const c_br = reinterpret_cast<const float*>(lane_u64(ev, 3));
         const uint8_t* const c_rs = reinterpret_cast<const uint8_t*>(lane_u64(ev, 4));
-        StepIn in{0.f, 0.f, 0.f, 0, (int)(unsigned)lane_u64(ev, 5)};
+        Ctl in{0.f, 0.f, 0.f, 0, (int)(unsigned)lane_u64(ev, 5)};
+        asm volatile("" :: "s"(c_st), "s"(c_th), "s"(in.synth) : "memory");   // the entry HAS returned here (and with it every older store of this wave)
         if (!in.synth) {
             in.steer = sys_load_val(&c_st[e]); in.thr = sys_load_val(&c_th[e]);
             if (c_br) in.brk = sys_load_val(&c_br[e]);
@@ -706,8 +710,9 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
         }
         return in;
     };
-    bool have_next = false;                                  // the inputs of step s are already in `nxt` (requested while step s - 1 integrated)
-    StepIn nxt{};
+    bool have_ctl = false, have_ent = false;                 // the controls of step s / the entry of step s + 1 were requested by an earlier iteration
+    Ctl nxt{};
+    u64 ent_next = 0ull;
     u64 clean_below = wp.start;                              // every store of the steps below this index has been acknowledged
     for (u64 s = wp.start;; ++s) {
         if (owed < s && (lds_load64(l.word) & kCountMask) <= s) {   // nothing further posted: the consumer may be waiting for step s - 1
@@ -715,25 +720,33 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
             for (; owed < s; ++owed) raster_arrive(l, owed, lane);
             clean_below = s;
         }
-        StepIn in;
-        if (have_next) {
-            in = nxt;                                        // its loads were issued BEFORE step s - 1's stores: their return says nothing about those
+        Ctl in;
+        if (have_ctl) {
+            in = nxt;
         } else {
             if (!wait_posted(wp, l, none, s, lane)) {
                 drain_vmem();
                 for (; owed < s; ++owed) raster_arrive(l, owed, lane);
                 return;
             }
-            in = fetch_inputs(s);
+            in = ctl_load(entry_load(s));                    // (an entry in flight implies controls in flight: have_ent is false here)
             drain_vmem();                                    // loads return in order behind every older store of this wave: steps < s are in memory
             clean_below = s;
         }
+        const u64 count = lds_load64(l.word) & kCountMask;
+        // the controls of step s + 1: their entry was requested one iteration ago (behind the stores of step s - 2: once it is read, the steps
+        // below s - 1 are in memory) or is read now (behind the stores of step s - 1)
+        have_ctl = count > s + 1;
+        if (have_ctl) {
+            const bool was_prefetched = have_ent;
+            nxt = ctl_load(was_prefetched ? ent_next : entry_load(s + 1));
+            const u64 c = was_prefetched ? s - 1 : s;
+            clean_below = c > clean_below ? c : clean_below;
+        }
+        // the entry of step s + 2, not waited for
+        have_ent = have_ctl && count > s + 2;
+        if (have_ent) ent_next = entry_load(s + 2);
         for (; owed < clean_below; ++owed) raster_arrive(l, owed, lane);   // lagged arrivals: no drain of their own
-        // step s + 1 already posted?  Request its inputs now, in front of this step's arithmetic.  Issued AFTER the stores of step s - 1 and
-        // before those of step s: once they have returned (they are consumed at the top of the next iteration), steps < s are in memory.
-        have_next = (lds_load64(l.word) & kCountMask) > s + 1;
-        if (have_next) nxt = fetch_inputs(s + 1);
-        const u64 clean_after = have_next ? s : clean_below;
         const float epr_before = st.epr;
         StepOut o;
         env_advance<true, false>(P, smem, e, st, (uint32_t)s, in.synth, in.steer, in.thr, in.brk, in.rin, lane, o);
@@ -750,7 +763,6 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
 #pragma unroll
             for (int k = 0; k < 13; ++k) tel = lane == k ? vals[k] : tel;
         }
-        clean_below = clean_after;                           // (fetch_inputs waited for the entry it read — a load issued behind the stores of step s - 1)
         if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
