@@ -72,3 +72,20 @@ def test_bench_two_ranks_rehearsal_sharing_the_gpu():
     ag = d["allgather"]
     assert ag["ranks"] == 2 and ag["floats_per_rank"] == 256 and ag["us"] > 0 and ag["backend"] == "gloo"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_nccl_branch_at_world_size_one():
+    """`--force-dist`: the process groups of the N > 1 branch at world size 1 on this box's GPU — nccl (= RCCL) for the one all-gather, a gloo group
+    for the host barriers and the MAX over ranks — and the exchange through nccl: every call of the N > 1 branch that the two-rank rehearsal (gloo
+    only: RCCL refuses two ranks on one device) cannot reach."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "512",
+                          "--no-also", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = _json_lines(out)
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    ag = d["allgather"]
+    assert ag["backend"] == "nccl" and ag["ranks"] == 1 and ag["floats_per_rank"] == 512 and ag["us"] > 0
+    assert d["n_gpus"] == 1 and d["value"] > 1e6
