@@ -388,12 +388,16 @@ def main():
         run = lambda k_: env.step_synthetic(k_, spl)
     # the pilot loop goes through launches (the pilot's kernels need the CUs' LDS); physics-only envs have their own resident worker since round 4
     resident = bool((args.resident or args.step_mode == "resident") and not args.pilot and spl == 1)
+    if args.share_gpu:
+        # Rehearsal with several ranks on ONE GPU: their resident workers cannot be on the GPU together (each needs a workgroup slot with ~126 KB of LDS
+        # on every CU).  Two workers that each hold a part of the CUs wait for the rest until the 2 s safety gives up ("resident worker gave up", seen in
+        # round 4).  The rehearsal is about the N > 1 code path of THIS file, so the ranks step by launches; one GPU per rank (the real run) is resident.
+        resident = False
     if resident:
         # idle_us: the worker leaves by itself after this long without a post.  The library's default (2 ms) suits an interactive loop; a
         # benchmark whose host thread can be descheduled for milliseconds (a tracer attached, the GIL) would see its worker leave and be
-        # relaunched mid-run — every explicit boundary below asks it to leave (quiesce) instead.  (Rehearsal with several ranks on ONE GPU:
-        # their workers cannot be resident together, so each must leave quickly for the next one to start.)
-        env.set_step_mode(True, 2000 if args.share_gpu else 100000)
+        # relaunched mid-run — every explicit boundary below asks it to leave (quiesce) instead.
+        env.set_step_mode(True, 100000)
 
     # The timed region is triton_racer_sim_amd.shard.timed_steps: [env.sync + stream synchronisation + barrier] t0 - K steps - env.sync t1
     # [stream synchronisation + barrier], MAX of (t1 - t0) over ranks.  env.sync() = every step handed to the env so far is complete in memory
@@ -713,7 +717,7 @@ def main():
                                          "[worker asked to leave, host barrier] t0 - all_gather_into_tensor - device synchronisation t1, MAX over ranks; never inside `value`"}
             line["config"]["allgather_returns_mean"] = line["allgather"]["returns_mean"]
         if args.share_gpu:
-            line["config"]["rehearsal"] = f"{world} ranks SHARING GPU 0 over gloo: a rehearsal of the N > 1 code path, not a measurement (the ranks' workers take turns on the one GPU)"
+            line["config"]["rehearsal"] = f"{world} ranks SHARING GPU 0 over gloo: a rehearsal of the N > 1 code path, not a measurement (the ranks step by launches: two resident workers cannot share a GPU)"
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(min(n, 1024), args.img_h, args.img_w) if render else None
             if cb:

@@ -162,7 +162,11 @@ int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h
  *     handles (cfg.render == 0, BASELINE configs[1]) get their own worker since round 4 (trs_physics_worker_kernel: one env per wave,
  *     the same mailbox and completion flags; a tick costs a post instead of a launch).  Every frame filter of trs_set_frame_filter is rendered by the worker (the dynamic-brightness one by its own
  *     instantiation since round 3).
- *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident. */
+ *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident.
+ *     ONE resident worker per GPU at a time: a worker needs a workgroup slot with most of the LDS on every CU, so the workers of two handles (or of two
+ *     processes) on the same GPU cannot be resident together — the second starts when the first has left (idle_us without a post, trs_quiesce), and
+ *     two that are launched against each other while both keep receiving posts can each end up holding a part of the CUs: both then wait until the
+ *     2 s safety gives up (TRS_ERR_DEVICE "resident worker gave up").  Sharded runs give every handle its own GPU. */
 enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
 int trs_set_step_mode(trs_env* env, int mode, int idle_us);
 /* Resident mode only (a no-op otherwise): the worker leaves the GPU now — every posted step is complete in memory when the call

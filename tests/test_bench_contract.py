@@ -58,9 +58,10 @@ def test_bench_self_launch_on_the_gpu():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal_sharing_the_gpu():
-    """The N > 1 branch of bench.py end to end on the one GPU of this box: two self-launched ranks, each with its own shard and resident worker,
-    K steps between host barriers, MAX over ranks, one all-gather timed on its own.  Both ranks share GPU 0, so the group is gloo (RCCL refuses
-    two ranks on one device) and the value is not a measurement — the line says so."""
+    """The N > 1 branch of bench.py end to end on the one GPU of this box: two self-launched ranks, each with its own shard, K steps between host
+    barriers, MAX over ranks, one all-gather timed on its own.  Both ranks share GPU 0, so the group is gloo (RCCL refuses two ranks on one device),
+    the ranks step by launches (two resident workers cannot be on one GPU together: each needs most of every CU's LDS — with both resident the
+    rehearsal failed one run in three with "resident worker gave up") and the value is not a measurement — the line says so."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5", "--total-envs", "512"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]

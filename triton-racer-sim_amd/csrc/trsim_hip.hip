@@ -476,7 +476,8 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     short* const mag = reinterpret_cast<short*>(work + p.off_mag);           // pixel (x, y) at mag[(y + 1) * MP + x + 4]: a group's 4 values are 8-byte aligned
     unsigned char* const map = work + p.off_map;
     int* const s_tab = reinterpret_cast<int*>(smem + p.off_tab);
-    unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [kEdgeBlock / 64][3]
+    unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [2][3] channel sums of the brightness rows, by frame parity: the waves ADD their totals (LDS atomics;
+                                                                             // round 4: the delta phase's 16-lane 64-bit shuffle reductions are gone; < 2^24 per channel)
     float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
     unsigned* const s_trim = reinterpret_cast<unsigned*>(s_delta + 4);        // [256] this frame's trim of every byte value
     unsigned* const s_rng = s_trim + 256;                                    // [3][256] byte ch = 0xFF: value x of component c (h, s, v) lies inside the range of the filter that owns channel ch's mask (mask_pixel)
@@ -515,11 +516,13 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
             }
         }
     };
-    auto publish_sums = [&](unsigned sr, unsigned sg, unsigned sb) {           // wave totals -> s_part (read by the delta phase behind a barrier)
+    auto publish_sums = [&](unsigned sr, unsigned sg, unsigned sb, int par) {  // wave totals -> s_part[par] (read by the delta phase behind a barrier)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-        if (lane == 0) { s_part[wave * 3] = sr; s_part[wave * 3 + 1] = sg; s_part[wave * 3 + 2] = sb; }
+        if (lane == 0) { atomicAdd(&s_part[par * 3], sr); atomicAdd(&s_part[par * 3 + 1], sg); atomicAdd(&s_part[par * 3 + 2], sb); }
     };
+    if (tid < 6) s_part[tid] = 0u;                                            // (behind the first barrier below before anyone adds)
+    int par = 0;                                                              // parity of the current frame of this workgroup
     bool sums_ready = false;                                                  // uniform: s_part already holds this frame's sums
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         EDGE_STAMP(0);
@@ -555,30 +558,21 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                 if (c > 0) fetch(rs, c, R);
                 chunk_sums(R, c, sr, sg, sb);
             }
-            publish_sums(sr, sg, sb);
+            __syncthreads();                                                  // (the zeroing of s_part[par] is complete: kernel start, or the previous frame's delta phase)
+            publish_sums(sr, sg, sb, par);
             __syncthreads();
         }
         EDGE_STAMP(1);
-        // every wave of the table's 256 threads adds the 16 partial sums itself (lanes 0..15 one wave's three sums each, 4 shuffle steps:
-        // exact integers, any order) and evaluates the same binary64 expression: no serial pass by one thread, no barrier for the delta
+        // every thread of the table reads the three totals (the waves added theirs with LDS atomics: exact integers, any order) and evaluates the same
+        // binary64 expression: no serial pass by one thread, no barrier for the delta, no reduction in this phase (round 3 reduced 16 partial sums per
+        // channel here with 64-bit shuffles)
         if (tid < 256) {                                                    // this frame's trim of every byte value, in numpy's operation order (:92-99)
-            unsigned long long t3[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                unsigned v = lane < kEdgeBlock / 64 ? s_part[lane * 3 + ch] : 0u;
-                unsigned long long tot = v;
-#pragma unroll
-                for (int off = 8; off >= 1; off >>= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)tot, off, 64), hi = __shfl_xor((unsigned)(tot >> 32), off, 64);
-                    tot += ((unsigned long long)hi << 32) | lo;
-                }
-                t3[ch] = tot;                                               // lanes 0..15 hold the total; lane 0's is broadcast below
-            }
+            if (tid < 3) s_part[(par ^ 1) * 3 + tid] = 0u;                   // the NEXT frame's sums start from zero (its adders are behind this phase's barrier)
             const double cnt = (double)(p.r1 - p.r0) * (double)W;
             double cur = 0.0;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const unsigned long long tot = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(t3[ch] >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)t3[ch]);
+                const unsigned tot = s_part[par * 3 + ch];                  // (a uniform LDS read: exact integer totals, any order of the adds)
                 cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
             }
             cur = cur + 0.0;
@@ -647,7 +641,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         if (one_chunk && img + (int)gridDim.x < p.n_img) {
             unsigned sr = 0, sg = 0, sb = 0;
             chunk_sums(R, 0, sr, sg, sb);
-            publish_sums(sr, sg, sb);
+            publish_sums(sr, sg, sb, par ^ 1);
             sums_ready = true;
         }
         // ---- non-maximum suppression + double threshold: map <- 0 = weak / 1 = no / 2 = edge ----
@@ -757,6 +751,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
         }
         __syncthreads();   // LDS is reused by the next frame of this workgroup
+        par ^= 1;
         EDGE_STAMP(7);
     }
 #ifdef TRS_EDGE_STAMPS
