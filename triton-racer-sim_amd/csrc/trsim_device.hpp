@@ -508,6 +508,19 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
 // inside the range of the filter whose mask goes to channel ch, so the AND of three lookups is the pixel's masks in place; sel has 0xFF in the
 // channels that carry a mask (a later filter on the same channel replaces an earlier one, :57-63), the others keep the trimmed value.
 // (Round 3: one table lookup chain and one v_bfi per pixel instead of a bit test, a compare and a select per channel.)
+// (mask_pixel_rgb: the same for a caller that holds the three trimmed components apart — trs_preprocess_kernel's table lookups — and would otherwise pack
+// them only to have them unpacked here: 3 instructions per pixel of ~44)
+__device__ __forceinline__ unsigned mask_pixel_rgb(int r, int g, int b, const int* tab, const unsigned* rngb, unsigned sel)
+{
+    const unsigned P = (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16);
+    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+    const int sat = (__mul24(diff, tab[v]) + (1 << 11)) >> 12;
+    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+    h = (__mul24(h, tab[256 + diff]) + (1 << 11)) >> 12;
+    h = h < 0 ? h + 180 : h;
+    const unsigned m = rngb[min(h, 255)] & rngb[256 + min(sat, 255)] & rngb[512 + v];
+    return (m & sel) | (P & ~sel);
+}
 __device__ __forceinline__ unsigned mask_pixel(unsigned P, const int* tab, const unsigned* rngb, unsigned sel)
 {
     const int r = (int)(P & 255u), g = (int)((P >> 8) & 255u), b = (int)((P >> 16) & 255u);

@@ -367,13 +367,15 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
             const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
             // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3 -> four trimmed pixels (r, g, b, 0)
             auto tr = [&](unsigned word, int k) -> unsigned { return s_trim[(word >> (8 * k)) & 255u]; };
-            unsigned P0 = tr(w.x, 0) | (tr(w.x, 1) << 8) | (tr(w.x, 2) << 16);
-            unsigned P1 = tr(w.x, 3) | (tr(w.y, 0) << 8) | (tr(w.y, 1) << 16);
-            unsigned P2 = tr(w.y, 2) | (tr(w.y, 3) << 8) | (tr(w.z, 0) << 16);
-            unsigned P3 = tr(w.z, 1) | (tr(w.z, 2) << 8) | (tr(w.z, 3) << 16);
-            if (p.color) {
-                P0 = mask_pixel(P0, s_tab, &s_rng[0][0], sel); P1 = mask_pixel(P1, s_tab, &s_rng[0][0], sel);
-                P2 = mask_pixel(P2, s_tab, &s_rng[0][0], sel); P3 = mask_pixel(P3, s_tab, &s_rng[0][0], sel);
+            const unsigned t00 = tr(w.x, 0), t01 = tr(w.x, 1), t02 = tr(w.x, 2), t10 = tr(w.x, 3), t11 = tr(w.y, 0), t12 = tr(w.y, 1);
+            const unsigned t20 = tr(w.y, 2), t21 = tr(w.y, 3), t22 = tr(w.z, 0), t30 = tr(w.z, 1), t31 = tr(w.z, 2), t32 = tr(w.z, 3);
+            unsigned P0, P1, P2, P3;
+            if (p.color) {                                                  // the components go to the masks as they come out of the trim table (round 4: not packed and unpacked again)
+                P0 = mask_pixel_rgb((int)t00, (int)t01, (int)t02, s_tab, &s_rng[0][0], sel); P1 = mask_pixel_rgb((int)t10, (int)t11, (int)t12, s_tab, &s_rng[0][0], sel);
+                P2 = mask_pixel_rgb((int)t20, (int)t21, (int)t22, s_tab, &s_rng[0][0], sel); P3 = mask_pixel_rgb((int)t30, (int)t31, (int)t32, s_tab, &s_rng[0][0], sel);
+            } else {
+                P0 = t00 | (t01 << 8) | (t02 << 16); P1 = t10 | (t11 << 8) | (t12 << 16);
+                P2 = t20 | (t21 << 8) | (t22 << 16); P3 = t30 | (t31 << 8) | (t32 << 16);
             }
             const u3v out = pack_rgb4(P0, P1, P2, P3);
             __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
     unsigned* const s_trim = reinterpret_cast<unsigned*>(s_delta + 4);        // [256] this frame's trim of every byte value
     unsigned* const s_rng = s_trim + 256;                                    // [3][256] byte ch = 0xFF: value x of component c (h, s, v) lies inside the range of the filter that owns channel ch's mask (mask_pixel)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // Every phase takes its thread index through `fresh`: an empty asm the compiler cannot see through, so that what a phase derives from
     // the index (row / column splits, addresses) is computed where it is used.  Left alone, hipcc hoisted those values of ALL phases in
     // front of the frame loop and kept them alive across it: 65 spilled registers, 240 bytes of scratch per lane = 63 MB written at
