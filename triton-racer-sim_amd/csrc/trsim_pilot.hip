@@ -108,6 +108,25 @@ __device__ __forceinline__ uint2 relu_pack4(float v0, float v1, float v2, float 
     return make_uint2(relu_h16x2(pack_h16x2(v0, v1)), relu_h16x2(pack_h16x2(v2, v3)));
 }
 
+// The epilogues' half exchange.  Register quad q of a 32x32 accumulator block holds channels 8q + 4h .. + 3 of pixel r in lane (r, h): the two lanes of a
+// pixel hold the two halves of every 8-channel group.  So that each lane stores whole 16-byte groups — lane h = 0 groups 0 and 1, lane h = 1 groups 2
+// and 3 — lane h = 0 needs its partner's half of groups 0, 1 and lane h = 1 its partner's half of groups 2, 3.  v_permlane32_swap_b32 a, b exchanges
+// the upper 32 lanes of a with the lower 32 lanes of b (gfx950): with a = a word of group q and b = the same word of group q + 2, BOTH halves of the wave
+// end with (own half, partner's half) of the group they store, in (a, b) order — one full-rate VALU instruction per word where rounds 2-3 used a select,
+// a ds_bpermute through the LDS crossbar and two more selects (round 4; the same bytes in the same places).
+__device__ __forceinline__ void half_swap(unsigned& a, unsigned& b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void quad_groups(const uint2 (&w)[4], u4v& g0, u4v& g1)
+{
+    unsigned a0 = w[0].x, a1 = w[0].y, b0 = w[2].x, b1 = w[2].y, c0 = w[1].x, c1 = w[1].y, d0 = w[3].x, d1 = w[3].y;
+    half_swap(a0, b0); half_swap(a1, b1); half_swap(c0, d0); half_swap(c1, d1);
+    g0 = u4v{a0, a1, b0, b1};                               // h = 0: channels 0..7 of group 0; h = 1: channels 0..7 of group 2
+    g1 = u4v{c0, c1, d0, d1};                               // h = 0: group 1; h = 1: group 3
+}
+
 #include "trsim_pilot_layers.hpp"   // the single-layer kernels: conv1 as its own layer, the span kernel (conv2 unfused, conv3 at 240x320), the quad-load fallback
 
 struct FrameConvParams {
@@ -252,11 +271,8 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
                     w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
                 }
-                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores
-                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
-                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
-                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};
-                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};
+                u4v g0, g1;
+                quad_groups(w, g0, g1);                                   // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
 #if TRS_FRAME_ABLATE == 3
                 asm volatile("" :: "v"(g0), "v"(g1)); (void)o;
 #else
@@ -383,11 +399,8 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
                     w[q] = relu_pack4(v0, v1, v2, v3);
                 }
-                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane keeps (see trs_conv_frame_kernel)
-                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
-                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
-                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};   // channels cbase + nb*32 + 16h .. + 7
-                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};   // ... + 8 .. + 15
+                u4v g0, g1;
+                quad_groups(w, g0, g1);                                   // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
                 if (mo[nt] >= 0) {
                     if (lout) {                                               // the next layer's image: pixel slot, granule ^ swizzle
                         const int po = out_pix0 + mo[nt], q0 = (cbase + nb * 32 + 16 * h) >> 3, sw = frame_swz(po, cgs_out);
@@ -591,11 +604,8 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
                     float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
                     w[q] = relu_pack4(v0, v1, v2, v3);
                 }
-                const uint2 s0 = h ? w[0] : w[2], s1 = h ? w[1] : w[3];       // what the partner lane stores (see trs_conv_frame_kernel)
-                const uint2 r0 = make_uint2(__shfl_xor(s0.x, 32, 64), __shfl_xor(s0.y, 32, 64));
-                const uint2 r1 = make_uint2(__shfl_xor(s1.x, 32, 64), __shfl_xor(s1.y, 32, 64));
-                const u4v g0 = h ? u4v{r0.x, r0.y, w[2].x, w[2].y} : u4v{w[0].x, w[0].y, r0.x, r0.y};
-                const u4v g1 = h ? u4v{r1.x, r1.y, w[3].x, w[3].y} : u4v{w[1].x, w[1].y, r1.x, r1.y};
+                u4v g0, g1;
+                quad_groups(w, g0, g1);                                   // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
                 if (mo[nt] >= 0) {
                     *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;
                     *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;
