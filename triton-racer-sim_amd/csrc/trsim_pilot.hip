@@ -126,6 +126,21 @@ __device__ __forceinline__ void quad_groups(const uint2 (&w)[4], u4v& g0, u4v& g
     g0 = u4v{a0, a1, b0, b1};                               // h = 0: channels 0..7 of group 0; h = 1: channels 0..7 of group 2
     g1 = u4v{c0, c1, d0, d1};                               // h = 0: group 1; h = 1: group 3
 }
+// The accumulators of a wave item start at the layer's bias (the MFMA's C operand adds it) instead of at zero with 16 v_add per 32 x 32 block in
+// the epilogue: register 4 q + j of block nb = channel cbase + nb*32 + 8 q + 4 h + j.  (fp32 sum order: bias first — the same fp16 activations up to
+// the last bit of the fp32 sum; tests/test_pilot.py compares against the PyTorch mirror.)
+template <int NT, int NB>
+__device__ __forceinline__ void acc_from_bias(f32x16 (&acc)[NT][NB], const float4* lbias, int cbase, int h)
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { acc[nt][nb][4 * q] = b.x; acc[nt][nb][4 * q + 1] = b.y; acc[nt][nb][4 * q + 2] = b.z; acc[nt][nb][4 * q + 3] = b.w; }
+        }
+}
 
 #include "trsim_pilot_layers.hpp"   // the single-layer kernels: conv1 as its own layer, the span kernel (conv2 unfused, conv3 at 240x320), the quad-load fallback
 
@@ -212,12 +227,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
         const u4v* wnext = wl + (size_t)(2 * R + h) * p.COUT_PAD;
         [[maybe_unused]] h16x8 xkeep[NT];
         f32x16 acc[NT][NB];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        acc_from_bias<NT, NB>(acc, lbias, cbase, h);
         // All ksteps k-steps are unrolled (3 x 12 or 9 x 8 ...): ONE basic block, no back edge — the compiler counts the weight
         // loads in flight exactly (vmcnt(N) per k-step) instead of draining the queue at a loop head or behind a branch.  The pixel
         // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
@@ -267,8 +277,7 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
                 uint2 w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
-                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
                     w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
                 }
                 u4v g0, g1;
@@ -342,12 +351,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * L.COUT + nb * 32];
         const u4v* wnext = wl + (size_t)(2 * R + h) * L.COUT;
         f32x16 acc[NT][NB];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        acc_from_bias<NT, NB>(acc, lbias, cbase, h);
         [[maybe_unused]] h16x8 xkeep[NT];
         auto pixels = [&](int k, h16x8 (&x)[NT]) {
             const int tap = k / HALF, g = 2 * (k % HALF) + h;
@@ -395,8 +399,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 uint2 w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 b = lbias[(cbase + nb * 32 + 8 * q + 4 * h) >> 2];
-                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
                     w[q] = relu_pack4(v0, v1, v2, v3);
                 }
                 u4v g0, g1;
@@ -557,12 +560,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
             for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * COUT + nb * 32];
         const u4v* wnext = wl + (size_t)(2 * R + h) * COUT;
         f32x16 acc[NT][NB];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][nb][i] = 0.0f;
+        acc_from_bias<NT, NB>(acc, lbias, 0, h);
         auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
             const int tap = k / 2, g = 2 * (k % 2) + h;
             const int kh = tap / KW, kw = tap % KW;
@@ -600,8 +598,7 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
                 uint2 w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 b = lbias[(nb * 32 + 8 * q + 4 * h) >> 2];
-                    float v0 = acc[nt][nb][4 * q] + b.x, v1 = acc[nt][nb][4 * q + 1] + b.y, v2 = acc[nt][nb][4 * q + 2] + b.z, v3 = acc[nt][nb][4 * q + 3] + b.w;
+                    float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
                     w[q] = relu_pack4(v0, v1, v2, v3);
                 }
                 u4v g0, g1;
