@@ -1,0 +1,7 @@
+#!/bin/bash
+# traced time of the fused head for prebuilt variants scripts/ab_bin/libtrsim_v_<tag>.so (and `prev`), alternating, ROUNDS times
+cd "$(dirname "$0")/.."
+for round in $(seq 1 ${ROUNDS:-2}); do for tag in "$@"; do
+  lib=$PWD/scripts/ab_bin/libtrsim_v_$tag.so; [ $tag = prev ] && lib=$PWD/scripts/ab_bin/libtrsim_prev.so
+  echo -n "$tag: "; TRS_HIP_LIB=$lib PL_TAG=v_$tag bash scripts/pilot_layers.sh 2>&1 | grep "conv1+2\|all kernels" | tr '\n' ' '; echo
+done; done

@@ -626,6 +626,26 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
 #ifndef TRS_FUSE_ABLATE
 #define TRS_FUSE_ABLATE 0
 #endif
+#ifndef TRS_C2_ABLATE
+#define TRS_C2_ABLATE 0
+#endif
+#ifndef TRS_C2_NT
+#define TRS_C2_NT 1      /* conv2 tiles of the fused head per wave item (one weight fragment feeds that many MFMAs); 2 measured: see the kernel */
+#endif
+#ifndef TRS_LOADER_PRIO
+#define TRS_LOADER_PRIO 0   /* s_setprio 3 on the loader waves while they unpack: measured, see the kernel */
+#endif
+#ifndef TRS_C2_DEPTH
+#define TRS_C2_DEPTH 4   /* k-steps of fragments in flight */
+#endif
+#ifndef TRS_BAND_STAMPS
+#define TRS_BAND_STAMPS 0   /* diagnostic build, never shipped: workgroup 7's waves 0 and 8 add up the shader clocks of their phases and print them behind a last barrier */
+#endif
+#if TRS_BAND_STAMPS
+#define BAND_STAMP(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_[i] += t_ - t0_; t0_ = t_; } while (0)
+#else
+#define BAND_STAMP(i) do { } while (0)
+#endif
 struct Fuse12Params {
     const uint8_t* frames; int frames_bytes;
     const u4v* w1; const float* b1; const int* goff1;      // conv1: [12][32] granules, [32], [12]
@@ -667,7 +687,6 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     unsigned char* tile1 = psmem + q.off_tile;
     const int plane_px = SPLIT ? q.w2p + 2 : (q.OW1 + 1) >> 1, plane_bytes = plane_px * 48, tile_pitch = 2 * plane_bytes;   // (a part's conv1 width is 2 w2p + 3)
     unsigned char* band = psmem + q.off_band;                              // [2 r1 + 3][IW * 3] fp16 (+ padding)
-    u4v* stage = reinterpret_cast<u4v*>(psmem + q.off_stage) + (wave & 7) * 128;   // conv2's output transpose: waves 0..7 only
     for (int i = tid; i < 12 * 32; i += blockDim.x) lw1[i] = q.w1[i];
     for (int i = tid; i < 80 * 32; i += blockDim.x) lw2[i] = q.w2[i];
     for (int i = tid; i < 8; i += blockDim.x) { lb1[i] = *reinterpret_cast<const float4*>(q.b1 + 4 * i); lb2[i] = *reinterpret_cast<const float4*>(q.c2.bias + 4 * i); }
@@ -675,6 +694,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     for (int i = tid; i < q.band_bytes / 16; i += blockDim.x) reinterpret_cast<u4v*>(band)[i] = (u4v)(0u);
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout2 = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(q.c2.out), 0, q.c2.M * 64, 0x00020000);   // conv2's activation: 32 couts
     const float inv_ow2 = 1.0f / (float)q.OW2;
     const int row_in = q.IW * 3;                                            // bytes per frame row
     const int bpitch = SPLIT ? q.cpr * 16 : row_in;                         // values per row of the band image
@@ -726,18 +746,20 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         int n, y2_0, r2, r1, x2_0, w2, w1, skip;
         geometry(it, n, y2_0, r2, r1, x2_0, w2, w1, skip);
         const int row0 = 4 * y2_0 + 2 * skip, rows = 2 * (r1 - skip) + 3;   // the frame rows under the conv1 rows this item computes
+        int tl = tid - 512;                                                  // this loader thread; opaque to the optimiser: the per-chunk indices below are
+        asm volatile("" : "+v"(tl));                                         // a few shifts per band, not eight registers held (and spilled) through both phases
         if constexpr (SPLIT) {
             const int start = ((n * q.IH + row0) * q.IW + 4 * x2_0) * 3, nchunk = rows * q.cpr;
 #pragma unroll
             for (int j = 0; j < 2 * kBandPf; ++j) {
-                const int hc = (tid - 512) + j * 512, c = hc >> 1, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
+                const int hc = tl + j * 512, c = hc >> 1, row = (int)__umulhi((unsigned)max(c, 0), q.magic_cpr), kk = c - row * q.cpr;
                 raw[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rin, c < nchunk ? start + row * row_in + 16 * kk + 8 * (hc & 1) : q.frames_bytes, 0, 0));   // past the end: zeros
             }
         } else {
             const int start = (n * q.IH + row0) * row_in, nchunk = (rows * row_in) >> 4;
 #pragma unroll
             for (int j = 0; j < 2 * kBandPf; ++j) {
-                const int hc = (tid - 512) + j * 512;
+                const int hc = tl + j * 512;
                 raw[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rin, (hc >> 1) < nchunk ? start + 8 * hc : q.frames_bytes, 0, 0));   // past the end: zeros
             }
         }
@@ -772,20 +794,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         if (wt + 1 < total) request(wt + 1, raw);                           // the second item's band is on its way
     }
     __syncthreads();
-    // conv1's weights are the same for every tile of every band: this lane's five granules stay in registers (they were 6 of the
-    // 11 LDS reads of a conv1 tile, in a phase that is bound by LDS bandwidth: 11 KB per 6 MFMAs and wave)
-    u4v wv[5];
-#pragma unroll
-    for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
-#pragma unroll
-    for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
-    // ... and so does its bias (couts 8 qd + 4 h .. + 3): three broadcast ds_read_b128 per tile were 0.9 of the 3.2 thousand LDS clocks
-    // of a band's conv1 phase (SQ_LDS_IDX_ACTIVE of the phase builds, profiles/r02_pilot_pmc.txt)
-    float4 bb1[3];
-#pragma unroll
-    for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
-#pragma unroll
-    for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
+#if TRS_BAND_STAMPS
+    long long st_[6] = {0, 0, 0, 0, 0, 0}, t0_ = (long long)__builtin_amdgcn_s_memtime();
+#endif
     while (wt < total) {
         const int nxt = wt + 1;                                             // uniform per workgroup
         int n, y2_0, r2, r1, x2_0, w2, w1, skip;
@@ -794,6 +805,20 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         const int s0 = q.roll ? (2 * y2_0) % NR : 0;                        // ring slot of the band's first conv1 row
         // ---- phase 1: the band's conv1 rows that are not in the tile yet (all of them, or all but the first 3), from the fp16 image ----
         const int rows1 = r1 - skip, npx1 = rows1 * w1, ntile1 = (npx1 + 31) >> 5;
+        // conv1's weights are the same for every tile: this lane's five granules are read once per band and stay in registers through the phase
+        // (they were 6 of the 11 LDS reads of a conv1 tile), and so does its bias (couts 8 qd + 4 h .. + 3: three broadcast ds_read_b128 per tile were
+        // 0.9 of the 3.2 thousand LDS clocks of a band's conv1 phase, profiles/r02_pilot_pmc.txt).  Re-read per band, not held across phase 2: conv2's
+        // pair of accumulators and its fragment ring want those 32 registers.
+        u4v wv[5];
+#pragma unroll
+        for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
+#pragma unroll
+        for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));     // one read per band: do not re-read them per tile
+        float4 bb1[3];
+#pragma unroll
+        for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
+#pragma unroll
+        for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
 #if TRS_FUSE_ABLATE != 1
         for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
             // the tile's first pixel splits into (row, column) on the scalar unit; a lane adds its r (OW1 >= 32: one wrap at most);
@@ -834,11 +859,19 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             }
         }
 #endif
+        BAND_STAMP(0);                                                      // conv1 tiles
         __syncthreads();                                                    // the tile is complete, the band image is free
+        BAND_STAMP(1);                                                      // wait at the barrier
         if (loader) {
             if (nxt < total) {
+#if TRS_LOADER_PRIO
+                __builtin_amdgcn_s_setprio(3);
+#endif
                 unpack(raw);                                                // the next item's band (requested an item ago)
                 if (nxt + 1 < total) request(nxt + 1, raw);
+#if TRS_LOADER_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
         } else {
             // ---- phase 2: conv2 rows from the tile (waves 0..7: at most a handful of tiles per band) ----
@@ -846,41 +879,117 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             const int m0 = (n * q.OH2 + y2_0) * q.OW2 + x2_0;               // first output pixel of the band (a whole band is consecutive in memory)
             const float inv_w2 = SPLIT ? 1.0f / (float)w2 : inv_ow2;
 #if TRS_FUSE_ABLATE != 2
-            // (Two tiles per wave on waves 0..3, one weight fragment feeding two MFMAs, was measured in round 2: 107 -> 130 us; eight
-            // waves of 256 registers with conv2's 40 weight fragments in registers — no weight reads from LDS at all — 100 -> 117 us:
-            // two waves per SIMD do not hide conv1's LDS round trips; the same with conv2's K split over two waves, two tiles per
-            // wave: 100 -> 125 us, profiles/r02_pilot_head_reg.txt.)
-            for (int t2 = wave; t2 < ntile2; t2 += 8) {
-                const int mm = min(t2 * 32 + r, npx2 - 1);
-                int yl2, x2;
-                divmod(mm, w2, inv_w2, yl2, x2);
-                const unsigned char* abase = tile1 + (size_t)x2 * 48;        // even plane, pixel x2; the row: ring slot of conv1 row 2 yl2 + kh
-                const int trow = s0 + 2 * yl2;
-                f32x16 acc2[1];
+            // Phase stamps of round 4 (-DTRS_BAND_STAMPS=1, profiles/r04_pilot_head_stamps.txt; clocks per band of 7 tiles at 120x160):
+            //   * The K loop is bound by LDS bandwidth: every MFMA takes 2 KB out of LDS (its weight and its pixel fragment), 560 KB per band =
+            //     4.4 k clocks at 128 B/clk; the waves of a SIMD finish in age order, the phase ends ~4.4 k clocks after it began.
+            //   * Until round 4 the epilogue went through a wave-private LDS stage (four broadcast bias reads, then the transpose: six dependent LDS
+            //     round trips of ~200 clocks each while the other waves saturate the LDS): 1.4 k clocks per tile.  Now the accumulators start at the
+            //     bias and the epilogue is ReLU + fp16 + v_permlane32_swap_b32 + two 16-byte stores per lane, no LDS: ~0.6 k.  Head 95.9 -> 88.5 us.
+            //   * TRS_C2_NT = 2 (a wave takes a PAIR of tiles, one weight fragment feeds two MFMAs: 480 KB per band; fragments kC2Depth k-steps ahead
+            //     by hand): the pairs run on four waves, one per SIMD, and each needs 3.7 k clocks for its 80 MFMAs + 1.0 k for two epilogues — 95.7 us
+            //     on the same box.  (Round 2 measured the same split with compiler-scheduled reads: 107 -> 130 us; conv2's 40 weight fragments in
+            //     registers on eight waves of 256 registers 100 -> 117 us, the same with K split over two waves 100 -> 125 us, r02_pilot_head_reg.txt.)
+            //   * TRS_LOADER_PRIO = 1 (s_setprio 3 while the loader waves unpack: they finish in 1.0 k instead of 3.0 k clocks, but the conv2 waves
+            //     they displace are the critical path): 90.0 us.  Deeper fragment rings (6, 8 k-steps): no change.
+            constexpr int kC2Nt = TRS_C2_NT, kC2Depth = TRS_C2_DEPTH;
+            // window slot sl = 2 ks + h of a kernel row (ks = k-step within the row): 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero
+            // weights: the odd run's next 16 bytes).  Per lane that is three bases (+ 32 ks as the instruction's immediate offset):
+            const unsigned off_lo = 16 * h;                                              // ks 0..3: slots 0..7
+            const unsigned off_mid = h ? (unsigned)plane_bytes : 128u;                   // ks 4: slot 8 (even run) / 9 (odd run, first)
+            const unsigned off_hi = (unsigned)plane_bytes - 144u + 16 * h;               // ks 5..7: slots 10..15 = odd run + (2 ks + h - 9) * 16
+            const unsigned wbase = (unsigned)q.off_w2 + (unsigned)(h * 32 + r) * 16u;    // lw2[(kh * 16 + 2 ks + h) * 32 + r]
+            for (int tp = wave_u; kC2Nt * tp < ntile2; tp += 8) {
+                unsigned abase[kC2Nt]; int trow[kC2Nt], moff[kC2Nt];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc2[0][i] = 0.0f;
-                for (int kh = 0; kh < 5; ++kh) {
-                    int tr = trow + kh;
-                    tr = tr >= NR ? tr - NR : tr;
-                    const unsigned char* arow = abase + (size_t)tr * tile_pitch;
+                for (int j = 0; j < kC2Nt; ++j) {
+                    const int px = (kC2Nt * tp + j) * 32 + r, mm = min(px, npx2 - 1);   // (lanes past the band's last pixel compute it again: never stored)
+                    int yl2, x2;
+                    divmod(mm, w2, inv_w2, yl2, x2);
+                    abase[j] = (unsigned)q.off_tile + (unsigned)__mul24(x2, 48);   // even plane, pixel x2
+                    trow[j] = s0 + 2 * yl2;                                  // ring slot of conv1 row 2 yl2 + kh: trow + kh (mod NR)
+                    moff[j] = px < npx2 ? ((m0 + __mul24(yl2, q.OW2) + x2) * 32 + 16 * h) * 2 : -1;   // this lane's 32 bytes of the pixel in conv2's activation
+                }
+                // the accumulators start at conv2's bias: register 4 qd + j = cout 8 qd + 4 h + j (read once per item, under the first fragments' latency)
+                f32x16 acc2[kC2Nt];
 #pragma unroll
-                    for (int t = 0; t < 16; t += 2) {
-                        // slot t + h of the window: 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero weights: the odd run's next 16 bytes)
-                        const int slot = t + h;
-                        const unsigned char* src = slot < 9 ? arow + slot * 16 : arow + plane_bytes + (slot - 9) * 16;
-                        const h16x8 xa = __builtin_bit_cast(h16x8, *reinterpret_cast<const u4v*>(src));
-                        const h16x8 w = __builtin_bit_cast(h16x8, lw2[(kh * 16 + t + h) * 32 + r]);
-                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, xa, acc2[0], 0, 0, 0);
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 b = lb2[2 * qd + h];
+#pragma unroll
+                    for (int j = 0; j < kC2Nt; ++j) { acc2[j][4 * qd] = b.x; acc2[j][4 * qd + 1] = b.y; acc2[j][4 * qd + 2] = b.z; acc2[j][4 * qd + 3] = b.w; }
+                }
+                u4v fw[kC2Depth], fx[kC2Depth][kC2Nt];
+                unsigned arow[kC2Nt], cur[kC2Nt];
+                auto fetch = [&](int k, int d) {                             // k-step k = kernel row k / 8, window slots 2 (k % 8) + h (compile-time k after unrolling)
+                    const int kh = k >> 3, ks = k & 7;
+#pragma unroll
+                    for (int j = 0; j < kC2Nt; ++j) {
+                        if (ks == 0) {
+                            int tr = trow[j] + kh;
+                            tr = tr >= NR ? tr - NR : tr;
+                            arow[j] = abase[j] + (unsigned)__mul24(tr, tile_pitch);
+                            cur[j] = arow[j] + off_lo;
+                        } else if (ks == 4) cur[j] = arow[j] + off_mid;
+                        else if (ks == 5) cur[j] = arow[j] + off_hi;
+                    }
+                    const unsigned imm = ks == 4 ? 0u : 32u * ks;
+                    fw[d] = *reinterpret_cast<const u4v*>(psmem + (wbase + (unsigned)(kh * 16 + 2 * ks) * 512u));
+#pragma unroll
+                    for (int j = 0; j < kC2Nt; ++j) fx[d][j] = *reinterpret_cast<const u4v*>(psmem + (cur[j] + imm));
+                };
+#pragma unroll
+                for (int d = 0; d < kC2Depth; ++d) fetch(d, d);
+#pragma unroll
+                for (int k = 0; k < 40; ++k) {
+                    const int d = k % kC2Depth;
+                    const h16x8 w = __builtin_bit_cast(h16x8, fw[d]);
+#pragma unroll
+                    for (int j = 0; j < kC2Nt; ++j) {
+#if TRS_C2_ABLATE == 2
+                        asm volatile("" :: "v"(w), "v"(fx[d][j]));
+#else
+                        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, __builtin_bit_cast(h16x8, fx[d][j]), acc2[j], 0, 0, 0);
+#endif
+                    }
+                    if (k + kC2Depth < 40 && TRS_C2_ABLATE != 1) fetch(k + kC2Depth, d);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                BAND_STAMP(2);                                               // conv2: set-up and K loop (loaders: unpack + request)
+#if TRS_C2_ABLATE == 3
+                asm volatile("" :: "v"(acc2[0]));
+                continue;
+#endif
+                // Epilogue without LDS: ReLU + fp16, the two lanes of a pixel swap half of their channel quads (v_permlane32_swap_b32) and each stores
+                // 32 contiguous bytes (couts 16 h .. + 15).  (Until round 4 the tile went through a wave-private LDS stage — four broadcast bias reads and
+                // the transpose, six dependent LDS round trips at ~200 clocks each while the other waves saturate the LDS: 1.4 k of a band's 6.5 k clocks
+                // of phase 2 per tile, profiles/r04_pilot_head_stamps.txt.)
+#pragma unroll
+                for (int j = 0; j < kC2Nt; ++j) {
+                    uint2 w[4];
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+                        w[qd] = q.c2.relu ? relu_pack4(acc2[j][4 * qd], acc2[j][4 * qd + 1], acc2[j][4 * qd + 2], acc2[j][4 * qd + 3])
+                                          : make_uint2(pack_h16x2(acc2[j][4 * qd], acc2[j][4 * qd + 1]), pack_h16x2(acc2[j][4 * qd + 2], acc2[j][4 * qd + 3]));
+                    u4v g0, g1;
+                    quad_groups(w, g0, g1);
+                    if (moff[j] >= 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(g0, rout2, moff[j], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(g1, rout2, moff[j] + 16, 0, 0);
                     }
                 }
-                if constexpr (SPLIT) store_tile_rows(stage, acc2, lb2, q.c2, t2 * 32, npx2, w2, inv_w2, m0, q.OW2, lane);
-                else store_tile_at<1>(stage, acc2, lb2, q.c2, m0 + t2 * 32, m0 + npx2, 0, lane);
             }
 #endif
         }
+        BAND_STAMP(3);                                                      // conv2: epilogue and stores (loaders: all of phase 2)
         __syncthreads();                                                    // the tile is free, the next band image is complete
+        BAND_STAMP(4);                                                      // wait at the barrier
         wt = nxt;
     }
+#if TRS_BAND_STAMPS
+    __syncthreads();
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3 || wave == 8))
+        printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %lld | barrier %lld | conv2 K loop %lld | conv2 stores (loaders: phase 2) %lld | barrier %lld\n",
+               wave, total, st_[0], st_[1], st_[2], st_[3], st_[4]);
+#endif
 }
 
 // dense2 -> dense3 -> output in fp32 (keras_train.py:161-168), then KerasPilot.step for CNN_2D_SPD_CTL (keras_pilot.py:78-95)
@@ -1821,7 +1930,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q.c2 = ConvParams{};
         q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1; q.c2.oscale = 1.0f;
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
-        const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
+        const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.COUT == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
         c->fuse12 = false; c->no_fuse = T.no_fuse != 0;
         // band form (conv1's input staged once per band as a fp16 image): tile + band image + 8 wave stages
