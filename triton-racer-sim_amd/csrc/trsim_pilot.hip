@@ -626,6 +626,9 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
 #ifndef TRS_FUSE_ABLATE
 #define TRS_FUSE_ABLATE 0
 #endif
+#ifndef TRS_C1_ABLATE
+#define TRS_C1_ABLATE 0   /* timing-only builds of the head's conv1 phase: 1 = fragments read for a wave's first tile only, 2 = no tile writes, 3 = no MFMA */
+#endif
 #ifndef TRS_C2_ABLATE
 #define TRS_C2_ABLATE 0
 #endif
@@ -645,6 +648,11 @@ __global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Fram
 #define BAND_STAMP(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_[i] += t_ - t0_; t0_ = t_; } while (0)
 #else
 #define BAND_STAMP(i) do { } while (0)
+#endif
+#if TRS_BAND_STAMPS == 2   /* also inside the conv1 tile loop (perturbs it: every stamp drains the wave's LDS queue) */
+#define BAND_STAMP2(i) BAND_STAMP(i)
+#else
+#define BAND_STAMP2(i) do { } while (0)
 #endif
 struct Fuse12Params {
     const uint8_t* frames; int frames_bytes;
@@ -769,9 +777,11 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         for (int j = 0; j < 2 * kBandPf; ++j) {
             const int hc = (tid - 512) + j * 512;
             if (hc * 16 + 16 > q.band_bytes) continue;
-            auto pair = [](unsigned w, int k) -> unsigned {
+            auto pair = [](unsigned w, int k) -> unsigned {                  // two pixels as x / 256 in binary16 (exact: 0, 2^-8 .. 255 x 2^-8)
                 const float f0 = (float)((w >> (8 * k)) & 255u), f1 = (float)((w >> (8 * k + 8)) & 255u);
-                return u8pair_h16(f0, f1);
+                typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+                const h16x2 scale = {(_Float16)kConv1Scale, (_Float16)kConv1Scale};
+                return __builtin_bit_cast(unsigned, __builtin_bit_cast(h16x2, u8pair_h16(f0, f1)) * scale);   // one v_pk_mul_f16 per pair
             };
             *reinterpret_cast<u4v*>(band + (size_t)hc * 16) = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
         }
@@ -794,8 +804,27 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         if (wt + 1 < total) request(wt + 1, raw);                           // the second item's band is on its way
     }
     __syncthreads();
+    // conv1's weights are the same for every tile of every band: this lane's five granules stay in registers for the whole kernel (they were 6 of the
+    // 11 LDS reads of a conv1 tile; re-reading them per band — two dependent LDS round trips in front of every band's first tile — was measured in
+    // round 4: ~0.5 k of a band's 4 k clocks of phase 1).  So does the bias: it is the first MFMA's C operand (16 registers: couts 8 qd + 4 h + j in
+    // register 4 qd + j, zeros for the padding couts 24..31), and the band image holds the pixels as x / 256 (exact), so the sums need no 2^-8 and
+    // no bias FMA.
+    u4v wv[5];
+#pragma unroll
+    for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
+#pragma unroll
+    for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));         // keep them in registers: do not re-read them per tile
+    f32x16 bias16;
+#pragma unroll
+    for (int qd = 0; qd < 3; ++qd) {
+        const float4 bb = lb1[2 * qd + h];
+        bias16[4 * qd] = bb.x; bias16[4 * qd + 1] = bb.y; bias16[4 * qd + 2] = bb.z; bias16[4 * qd + 3] = bb.w;
+    }
+#pragma unroll
+    for (int i = 12; i < 16; ++i) bias16[i] = 0.0f;
+    asm volatile("" : "+v"(bias16));
 #if TRS_BAND_STAMPS
-    long long st_[6] = {0, 0, 0, 0, 0, 0}, t0_ = (long long)__builtin_amdgcn_s_memtime();
+    long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
     while (wt < total) {
         const int nxt = wt + 1;                                             // uniform per workgroup
@@ -805,57 +834,75 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         const int s0 = q.roll ? (2 * y2_0) % NR : 0;                        // ring slot of the band's first conv1 row
         // ---- phase 1: the band's conv1 rows that are not in the tile yet (all of them, or all but the first 3), from the fp16 image ----
         const int rows1 = r1 - skip, npx1 = rows1 * w1, ntile1 = (npx1 + 31) >> 5;
-        // conv1's weights are the same for every tile: this lane's five granules are read once per band and stay in registers through the phase
-        // (they were 6 of the 11 LDS reads of a conv1 tile), and so does its bias (couts 8 qd + 4 h .. + 3: three broadcast ds_read_b128 per tile were
-        // 0.9 of the 3.2 thousand LDS clocks of a band's conv1 phase, profiles/r02_pilot_pmc.txt).  Re-read per band, not held across phase 2: conv2's
-        // pair of accumulators and its fragment ring want those 32 registers.
-        u4v wv[5];
-#pragma unroll
-        for (int s6 = 0; s6 < 5; ++s6) wv[s6] = lw1[(2 * s6 + h) * 32 + r];
-#pragma unroll
-        for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(wv[s6]));     // one read per band: do not re-read them per tile
-        float4 bb1[3];
-#pragma unroll
-        for (int qd = 0; qd < 3; ++qd) bb1[qd] = lb1[2 * qd + h];
-#pragma unroll
-        for (int qd = 0; qd < 3; ++qd) asm volatile("" : "+v"(bb1[qd].x), "+v"(bb1[qd].y), "+v"(bb1[qd].z), "+v"(bb1[qd].w));
 #if TRS_FUSE_ABLATE != 1
-        for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
-            // the tile's first pixel splits into (row, column) on the scalar unit; a lane adds its r (OW1 >= 32: one wrap at most);
-            // lanes past the band's last pixel compute it again (never stored)
-            const int p0 = t1 * 32, yl0 = (int)__umulhi((unsigned)p0, magic), x0 = p0 - yl0 * w1;
-            int x = x0 + r, yl = yl0;
-            if (x >= w1) { x -= w1; ++yl; }
-            if (p0 + r >= npx1) { yl = rows1 - 1; x = w1 - 1; }
-            // (24-bit multiplies: full rate - every factor here is far below 2^23; the 32-bit v_mul_lo_u32 the plain products compile to is quarter rate,
-            // and this phase is bound by its ~70 vector instructions per tile, not by its 5 MFMAs)
-            const unsigned char* wbase = band + (unsigned)(__mul24(2 * yl, bpitch) + __mul24(x, 6) + 8 * h) * 2u;   // kernel row 0 of this lane's window, half h
-            f32x16 acc;
+        {
+            // A lane walks its pixels p = 32 t1 + r, t1 = wave, wave + 16, ... incrementally: (row yl, column x), the LDS address of its window in
+            // the band image and its ring slot in the tile advance by wave-uniform steps with one wrap (the phase is bound by its vector instructions
+            // — ~70 per tile until round 4, a third of them this address arithmetic and the bias FMAs — not by its 5 MFMAs).
+            const int step = nwaves * 32;
+            const int adv_y = (int)__umulhi((unsigned)step, magic), adv_x = step - adv_y * w1;          // step = adv_y rows + adv_x columns
+            const int adv_slot = adv_y % NR;
+            int pp = wave_u * 32 + r;
+            int yl = (int)__umulhi((unsigned)pp, magic), x = pp - yl * w1;
+            const unsigned band_off = (unsigned)q.off_band + 16u * h;
+            unsigned ra = band_off + (unsigned)(__mul24(2 * yl, bpitch) + __mul24(x, 6)) * 2u;             // kernel row 0 of this lane's window, half h
+            const unsigned ra_last = band_off + (unsigned)(__mul24(2 * (rows1 - 1), bpitch) + (w1 - 1) * 6) * 2u;   // lanes past the band's last pixel compute it again (never stored)
+            const unsigned ra_step = (unsigned)(adv_y * 2 * bpitch + adv_x * 6) * 2u, ra_wrap = (unsigned)(2 * bpitch - w1 * 6) * 2u;
+            int slot1 = s0 + skip + yl;                                      // (< 2 NR)
+            slot1 = slot1 >= NR ? slot1 - NR : slot1;
+            for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
+                BAND_STAMP2(5);                                             // (stamps level 2) loop overhead since the last tile's writes
+                const unsigned rd = min(ra, ra_last);
+                u4v xv[5];                                                  // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
+#if TRS_C1_ABLATE == 1
+                if (t1 == wave_u)
+#endif
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            u4v xv[5];                                                      // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
-#pragma unroll
-            for (int s6 = 0; s6 < 5; ++s6) {
-                const unsigned* src = reinterpret_cast<const unsigned*>(wbase + (unsigned)(s6 * bpitch * 2));
-                xv[s6] = u4v{src[0], src[1], src[2], src[3]};
-            }
-            __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
-#pragma unroll
-            for (int s6 = 0; s6 < 5; ++s6)                                  // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
-            if (t1 * 32 + r < npx1) {                                       // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
-                // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
-                // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
-                // its selects cost more than the conflict; the same swap instead of ds_bpermute_b32 in the frame kernels' epilogues: no change)
-                int slot1 = s0 + skip + yl;                                  // (yl counts the rows computed here; < 2 NR)
-                slot1 = slot1 >= NR ? slot1 - NR : slot1;
-                uint2* dst = reinterpret_cast<uint2*>(tile1 + (unsigned)(__mul24(slot1, tile_pitch) + ((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)));
-#pragma unroll
-                for (int qd = 0; qd < 3; ++qd) {
-                    const float4 bb = bb1[qd];
-                    float v0 = __builtin_fmaf(acc[4 * qd], kConv1Scale, bb.x), v1 = __builtin_fmaf(acc[4 * qd + 1], kConv1Scale, bb.y), v2 = __builtin_fmaf(acc[4 * qd + 2], kConv1Scale, bb.z), v3 = __builtin_fmaf(acc[4 * qd + 3], kConv1Scale, bb.w);
-                    dst[2 * qd + h] = relu_pack4(v0, v1, v2, v3);
+                for (int s6 = 0; s6 < 5; ++s6) {
+                    const unsigned* src = reinterpret_cast<const unsigned*>(psmem + (rd + (unsigned)(s6 * bpitch * 2)));
+                    xv[s6] = u4v{src[0], src[1], src[2], src[3]};
                 }
+#if TRS_C1_ABLATE == 1
+                else {
+#pragma unroll
+                    for (int s6 = 0; s6 < 5; ++s6) { xv[s6] = u4v{rd, rd, rd, rd}; asm volatile("" : "+v"(xv[s6])); }
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);                          // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
+                BAND_STAMP2(6);                                             // address + the ten reads issued (the stamp waits for them)
+#if TRS_C1_ABLATE == 3
+                f32x16 acc = bias16;
+#pragma unroll
+                for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(acc) : "v"(xv[s6]), "v"(wv[s6]));
+#else
+                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[0]), __builtin_bit_cast(h16x8, xv[0]), bias16, 0, 0, 0);
+#pragma unroll
+                for (int s6 = 1; s6 < 5; ++s6)                              // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
+#endif
+#if TRS_BAND_STAMPS == 2
+                { const int done_ = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0])); asm volatile("" :: "s"(done_)); }
+#endif
+                BAND_STAMP2(7);                                             // the five MFMAs complete
+                if (pp < npx1) {                                            // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
+                    // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
+                    // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
+                    // its selects cost more than the conflict)
+                    uint2* dst = reinterpret_cast<uint2*>(tile1 + (unsigned)(__mul24(slot1, tile_pitch) + ((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)));
+#pragma unroll
+                    for (int qd = 0; qd < 3; ++qd) {
+                        const uint2 v = relu_pack4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+#if TRS_C1_ABLATE == 2
+                        asm volatile("" :: "v"(v), "v"(dst));
+#else
+                        dst[2 * qd + h] = v;
+#endif
+                    }
+                }
+                BAND_STAMP2(8);                                             // epilogue + the writes issued (the stamp waits for them)
+                pp += step; x += adv_x; slot1 += adv_slot; ra += ra_step;
+                if (x >= w1) { x -= w1; slot1 += 1; ra += ra_wrap; }
+                slot1 = slot1 >= NR ? slot1 - NR : slot1;
             }
         }
 #endif
@@ -989,6 +1036,11 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3 || wave == 8))
         printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %lld | barrier %lld | conv2 K loop %lld | conv2 stores (loaders: phase 2) %lld | barrier %lld\n",
                wave, total, st_[0], st_[1], st_[2], st_[3], st_[4]);
+#if TRS_BAND_STAMPS == 2
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3 || wave == 8 || wave == 12))
+        printf("  conv1 tile loop, wave %d: loop overhead %lld | address + reads %lld | MFMAs %lld | epilogue + writes %lld | (rest, in 'conv1 tiles' above) %lld\n",
+               wave, st_[5], st_[6], st_[7], st_[8], st_[0]);
+#endif
 #endif
 }
 
