@@ -938,6 +938,9 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             //     registers on eight waves of 256 registers 100 -> 117 us, the same with K split over two waves 100 -> 125 us, r02_pilot_head_reg.txt.)
             //   * TRS_LOADER_PRIO = 1 (s_setprio 3 while the loader waves unpack: they finish in 1.0 k instead of 3.0 k clocks, but the conv2 waves
             //     they displace are the critical path): 90.0 us.  Deeper fragment rings (6, 8 k-steps): no change.
+            //   * The odd k-steps' weight fragments straight from global memory (buffer loads, three in flight = six k-steps of lead; the LDS then delivers
+            //     1.5 KB per MFMA and the L1 the rest): K loop 2.5 k -> 3.5 k clocks per band, head 76.3 -> 81 us (240x320: 162 -> 191) — the frames the
+            //     loader waves stream through the same 32 KB L1 evict the weights, and an L2 hit is longer than the lead 128 registers leave room for.
             constexpr int kC2Nt = TRS_C2_NT, kC2Depth = TRS_C2_DEPTH;
             // window slot sl = 2 ks + h of a kernel row (ks = k-step within the row): 0..8 = the even run, 9..14 = the odd run, 15 = padding (zero
             // weights: the odd run's next 16 bytes).  Per lane that is three bases (+ 32 ks as the instruction's immediate offset):
