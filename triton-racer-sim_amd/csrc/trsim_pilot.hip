@@ -1859,7 +1859,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             const int cgr = l.CIN / 8, pix_gran = l.S * cgr;
             const int nseg_max = 30 / l.OW + 2;
             const int span_mask = T.span_layers_mask;                         // bit i = conv(i+1) uses the span kernel: conv2 and conv3 (0x6)
-            l.res_span = !l.u8in && l.S == 2 && l.KW >= 5 && nseg_max <= 4 && ((span_mask >> i) & 1);
+            l.res_span = !l.u8in && l.S == 2 && l.KW >= 5 && nseg_max <= 4 && ((span_mask >> i) & 1) && l.COUT % 32 == 0;   // (whole 32-channel blocks: its epilogue stores 16 channels per lane)
             if (l.res_span) {
                 l.span_nl = ((32 - nseg_max) * pix_gran + nseg_max * run_pad + 63) / 64;
                 if (l.span_nl > 5) l.res_span = false;

@@ -84,6 +84,44 @@ __device__ __forceinline__ void store_tile(u4v* stage, const f32x16 (&acc)[NB], 
     store_tile_at<NB>(stage, acc, lbias, p, tile * 32, p.M, cbase, lane);
 }
 
+// The epilogue without LDS (round 4; the fused head's conv2 and the frame kernels use the same): the accumulators STARTED at the bias (acc_bias),
+// so what is left is ReLU + fp16, the exchange of channel quads between the two lanes of a pixel (v_permlane32_swap_b32) and two 16-byte
+// stores per lane and 32-channel block (couts cbase + nb*32 + 16 h .. + 15).  The staged epilogue above costs a tile six dependent LDS round
+// trips (four broadcast bias reads + the transpose): 1.4 k clocks in the head (profiles/r04_pilot_head_stamps.txt).  For whole 32-channel blocks
+// (COUT % 32 == 0) and oscale == 1 only: the span kernel's layers.
+template <int NB>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[NB], const float4* lbias, int h)
+{
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = lbias[nb * 8 + 2 * q + h];
+            acc[nb][4 * q] = b.x; acc[nb][4 * q + 1] = b.y; acc[nb][4 * q + 2] = b.z; acc[nb][4 * q + 3] = b.w;
+        }
+}
+template <int NB>
+__device__ __forceinline__ void store_tile_direct(const f32x16 (&acc)[NB], const ConvParams& p, const __amdgpu_buffer_rsrc_t rout, int tile, int cbase, int lane)
+{
+    const int r = lane & 31, h = lane >> 5, m = tile * 32 + r;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        uint2 w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            w[q] = p.relu ? relu_pack4(acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3])
+                          : make_uint2(pack_h16x2(acc[nb][4 * q], acc[nb][4 * q + 1]), pack_h16x2(acc[nb][4 * q + 2], acc[nb][4 * q + 3]));
+        u4v g0, g1;
+        quad_groups(w, g0, g1);
+        if (m < p.M) {
+            const int off = (m * p.COUT + cbase + nb * 32 + 16 * h) * 2;
+            if (p.nt_out == 1) { __builtin_amdgcn_raw_buffer_store_b128(g0, rout, off, 0, 2); __builtin_amdgcn_raw_buffer_store_b128(g1, rout, off + 16, 0, 2); }          // nt
+            else if (p.nt_out == 2) { __builtin_amdgcn_raw_buffer_store_b128(g0, rout, off, 0, 17); __builtin_amdgcn_raw_buffer_store_b128(g1, rout, off + 16, 0, 17); }   // sc0 sc1
+            else { __builtin_amdgcn_raw_buffer_store_b128(g0, rout, off, 0, 0); __builtin_amdgcn_raw_buffer_store_b128(g1, rout, off + 16, 0, 0); }
+        }
+    }
+}
+
 // The same epilogue for a tile whose 32 pixels are a run of a ROW-SEGMENT grid (the fused head's band cut in width: rows of w2
 // pixels inside an output activation of OW pixels per row): pixel pg of the band part = (row pg / w2, column pg % w2), output
 // pixel m_row0 + row * OW + column.  32 output channels (NB = 1).
@@ -369,6 +407,7 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.M * p.COUT * 2, 0x00020000);
     const int ohw = p.OH * p.OW;
     const int ntiles = (p.M + 31) >> 5, stride = gridDim.x * nwaves;
     const int row_bytes = p.IW * p.in_px_bytes;
@@ -417,10 +456,7 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
     request(0);
     while (true) {
         f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+        acc_bias<NB>(acc, lbias, h);                                        // the sums start at the bias
         const int next = tile + stride;                                     // uniform
         for (int kh = 0; kh < p.KH; ++kh) {
 #pragma unroll
@@ -438,7 +474,7 @@ __global__ __launch_bounds__(768) void trs_conv_span_kernel(const ConvParams p)
                 }
             }
         }
-        store_tile<NB>(stage, acc, lbias, p, tile, cbase, lane);
+        store_tile_direct<NB>(acc, p, rout, tile, cbase, lane);
         if (next >= ntiles) break;
         tile = next; roff_cur = roff_next;
     }
