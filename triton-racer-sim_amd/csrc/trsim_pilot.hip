@@ -233,6 +233,9 @@ __global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvPa
         // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
         // that keeps "MFMAs of k, then the refill of k's ring slot" in place would otherwise also pin each k-step's LDS reads
         // right in front of its own MFMAs: one LDS latency per 4 MFMAs).
+        // (Round 4: a second sched_barrier between those reads and the MFMAs — hipcc sinks the reads behind three of a k-step's four MFMAs — was
+        // measured in the frame kernels, the chain and frame5: all slower, chain 46.2 -> 48.4 us, conv7 96.1 -> 100.5: the address arithmetic then runs
+        // as a burst with no MFMA beside it.)
         auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
             const int tap = k / HALF, g = 2 * (k % HALF) + h;
             const int tap_off = (tap / 3) * p.IW + tap % 3;
@@ -496,6 +499,16 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
 // Stride 2 changes the LDS image: a row is stored as its even columns, then its odd columns, so the windows of consecutive
 // output pixels are consecutive 64-byte slots for every tap; granule g of slot s sits at g ^ ((s >> 2) & 3) — 16 consecutive
 // slots of one logical granule cover all 64 banks.
+#ifndef TRS_F5_R
+#define TRS_F5_R 4   /* weight ring depth of trs_conv_frame5_kernel in k-steps */
+#endif
+#ifndef TRS_F5_NB
+#define TRS_F5_NB 2        /* 32-channel blocks per wave item */
+#define TRS_F5_COMPUTE 4   /* compute waves (+ 4 loader waves); 1 x 8 and 2 x 8 measured: see the kernel */
+#endif
+#ifndef TRS_F5_STAMPS
+#define TRS_F5_STAMPS 0   /* diagnostic build, never shipped: workgroups 7 and 700 print the shader clocks of their staging and K loops */
+#endif
 struct Frame5Params {
     const u4v* in;             // fp16 NHWC [N][IH][IW][32]
     const u4v* w;              // [KH*KW*4][64] granules: row (kh, kw, c8), 2 k + h = granule of k-step k, half h
@@ -505,111 +518,157 @@ struct Frame5Params {
     int bands, ohb, ihb;                  // a frame that does not fit LDS is cut into `bands` bands of ohb output rows = ihb = 2 ohb + 3 input rows (bands == 1: ohb = OH, ihb = IH)
 };
 
-template <int NT, int R, int BLOCK, int MINB>
-__global__ __launch_bounds__(BLOCK, MINB) void trs_conv_frame5_kernel(const Frame5Params p)
+// Round 4: the workgroup is persistent and double-buffered.  Until then a 4-wave workgroup took ONE unit (two workgroups per CU, "one stages
+// while the other computes") — but all workgroups of a launch start together, so both of a CU staged at the same time and then computed at the
+// same time: stamps (-DTRS_F5_STAMPS=1) showed 10-12 k clocks of staging — 512 workgroups pulling 64 KB each at once: the fabric's ~6.5 TB/s —
+// in front of 10-11 k clocks of K loops, twice over for the 1024 frames.  Now one 8-wave workgroup per CU walks its units: waves 0..3 compute unit i
+// (one NT x 2 item each at 120x160) from one LDS buffer while waves 4..7 run the LDS-DMA of unit i + 1 into the other; one barrier per unit.
+// conv3 33.5 -> 31.1 us per 1024 frames.  What is left (stamps of the persistent form, profiles/r04_pilot_frame5.txt): a unit's K loops take 10.5-11.6 k
+// s_memtime ticks for 200 MFMAs per wave (5.6 k at the MFMA rate: ONE compute wave per SIMD keeps its pipe ~55 % busy; two waves per SIMD of the old form
+// kept it full, but staged and computed in lockstep).  Timing-only builds: no weight refills -8 %, refills always from L1 -7 %, no pixel reads -2 % —
+// neither operand stream is what holds a lone wave back.  Measured and not kept: 8 compute waves on 32-channel items (NB = 1: twice the LDS
+// traffic) 32.4 us; 8 compute waves on the four NB = 2 items (half of them idle) 31.4; weight rings 8 and 12 k-steps deep (possible since the
+// weights come by buffer load: 138 registers instead of 234) 32.3 / 32.5.
+template <int NT, int NB, int R, int BLOCK, int COMPUTE>
+__global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5Params p)
 {
-    constexpr int NB = 2, KW = 5, ksteps = 50;
+    constexpr int KW = 5, ksteps = 50, kCompute = COMPUTE;                  // waves 0 .. COMPUTE - 1 compute, the others stage
     const int COUT = p.COUT;                                                // 64; a run-time value on purpose: with a constant the compiler folds the ring's running
                                                                             // pointer into 46 precomputed addresses (92 live registers, spills)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nwaves = BLOCK / 64;
+    static_assert(nwaves > kCompute, "loader waves");
     const int r = lane & 31, h = lane >> 5;
     const int n_units = p.N * p.bands;
-    const int u0 = blockIdx.x * p.F, nu = min(p.F, n_units - u0);
-    const int upix = p.ihb * p.IW, uout = p.ohb * p.OW;                     // input pixels staged / output pixel slots per unit
-    {   // staging: slot sl = 4 * lpix + q holds granule q ^ ((lpix >> 2) & 3) of the pixel that lives in slot lpix
-        const int total = nu * upix * 4;
-        const unsigned lds_base = (unsigned)(uintptr_t)psmem;
-        for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
+    const int upix = p.ihb * p.IW;                                          // input pixels staged per unit
+    const unsigned buf_bytes = (unsigned)upix * 64u;                        // one unit in LDS (a multiple of 64)
+    const unsigned lds_base = (unsigned)(uintptr_t)psmem;
+#if TRS_F5_STAMPS
+    long long f5_t0 = (long long)__builtin_amdgcn_s_memtime(), f5_st = 0, f5_k = 0, f5_w = 0;
+#endif
+    // staging of unit u into the buffer at byte offset `off` by waves w0 .. w0 + nw - 1: slot sl = 4 * lpix + q holds granule q ^ ((lpix >> 2) & 3) of the
+    // pixel that lives in slot lpix
+    auto stage = [&](int u, unsigned off, int w0, int nw) {
+        const int total = upix * 4;
+        const int f = u / p.bands, band = u - f * p.bands;
+        for (int s0 = (wave - w0) * 64; s0 < total; s0 += nw * 64) {
             const int sl = s0 + lane;
             if (sl < total) {
                 const int lpix = sl >> 2, g = (sl & 3) ^ ((lpix >> 2) & 3);
-                const int ul = lpix / upix, rp = lpix - ul * upix, iyl = rp / p.IW, s = rp - iyl * p.IW;
-                const int col = s < p.ev ? 2 * s : 2 * (s - p.ev) + 1;
-                const int u = u0 + ul, f = u / p.bands, band = u - f * p.bands;
+                const int iyl = lpix / p.IW, sx = lpix - iyl * p.IW;
+                const int col = sx < p.ev ? 2 * sx : 2 * (sx - p.ev) + 1;
                 const int iy = min(2 * band * p.ohb + iyl, p.IH - 1);         // (rows below the frame are never read by a valid pixel)
                 const size_t gpix = ((size_t)f * p.IH + iy) * p.IW + col;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + gpix * 4 + g),
-                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + off + s0 * 16), 16, 0, 0);
             }
         }
-        float* lb = reinterpret_cast<float*>(psmem + (size_t)p.F * upix * 64);
-        for (int i = tid; i < COUT; i += BLOCK) lb[i] = p.bias[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const u4v* lin = reinterpret_cast<const u4v*>(psmem);
-    const float4* lbias = reinterpret_cast<const float4*>(psmem + (size_t)p.F * upix * 64);
-    const int m_wg = nu * uout, n_tiles = (m_wg + NT * 32 - 1) / (NT * 32);
-    for (int item = wave; item < n_tiles; item += nwaves) {
-        int lbase[NT];
-        long long mo[NT];                                                   // output pixel index in the layer's activation, -1 = no such pixel
+    };
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(p.w), 0, 100 * COUT * 16, 0x00020000);   // [25 taps x 4 granules][COUT] granules
+    const int wvoff = (h * COUT + r) * 16;
+    float* lb = reinterpret_cast<float*>(psmem + 2 * (size_t)buf_bytes);
+    const float4* lbias = reinterpret_cast<const float4*>(lb);
+    int u = blockIdx.x;
+    if (u < n_units) stage(u, 0u, 0, nwaves);                               // the first unit: all waves
+    for (int i = tid; i < COUT; i += BLOCK) lb[i] = p.bias[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#if TRS_F5_STAMPS
+    { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); f5_st += t_ - f5_t0; f5_t0 = t_; }
+#endif
+    for (int it = 0; u < n_units; ++it, u += gridDim.x) {
+        const unsigned cur = (it & 1) ? buf_bytes : 0u;
+        if (wave >= kCompute) {                                             // loaders: the next unit into the other buffer
+            if (u + (int)gridDim.x < n_units) stage(u + (int)gridDim.x, buf_bytes - cur, kCompute, nwaves - kCompute);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const u4v* lin = reinterpret_cast<const u4v*>(psmem + cur);
+            const int f = u / p.bands, band = u - f * p.bands;
+            const int m_wg = min(p.ohb, p.OH - band * p.ohb) * p.OW;         // a short last band has no tiles for the rows below the frame
+            const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = COUT / (NB * 32);
+            for (int it2 = wave; it2 < n_tiles * n_cgrp; it2 += kCompute) {
+                const int cgrp = it2 / n_tiles, item = it2 - cgrp * n_tiles, cbase = cgrp * NB * 32;   // (the waves of one SIMD take different tiles where they can)
+                int lbase[NT];
+                long long mo[NT];                                           // output pixel index in the layer's activation, -1 = no such pixel
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int m = item * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-            const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
-            const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
-            lbase[nt] = (ul * p.ihb + 2 * oyl) * p.IW + ox;                 // slot of input pixel (2 oyl, 2 ox) of the unit: even plane, position ox
-            mo[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
-        }
-        const u4v* wl = p.w + r;
-        u4v ring[R][NB];
-#pragma unroll
-        for (int d = 0; d < R; ++d)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * COUT + nb * 32];
-        const u4v* wnext = wl + (size_t)(2 * R + h) * COUT;
-        f32x16 acc[NT][NB];
-        acc_from_bias<NT, NB>(acc, lbias, 0, h);
-        auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
-            const int tap = k / 2, g = 2 * (k % 2) + h;
-            const int kh = tap / KW, kw = tap % KW;
-            const int tap_off = kh * p.IW + ((kw & 1) ? p.ev : 0) + (kw >> 1);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int pix = lbase[nt] + tap_off;
-                x[nt] = __builtin_bit_cast(h16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
-            }
-        };
-        h16x8 xa[NT], xb[NT];
-        pixels(0, xa);
-#pragma unroll
-        for (int k = 0; k < ksteps; ++k) {
-            const int d = k % R;
-            h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
-            h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
-            if (k + 1 < ksteps) pixels(k + 1, xn);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
-            if (k + R < ksteps) {
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
-                wnext += 2 * COUT;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            unsigned short* o = p.out + (size_t)(mo[nt] < 0 ? 0 : mo[nt]) * COUT;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                uint2 w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
-                    w[q] = relu_pack4(v0, v1, v2, v3);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int m = item * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
+                    const int oyl = mc / p.OW, ox = mc - oyl * p.OW;
+                    const int oy = band * p.ohb + oyl;
+                    lbase[nt] = 2 * oyl * p.IW + ox;                        // slot of input pixel (2 oyl, 2 ox) of the unit: even plane, position ox
+                    mo[nt] = m < m_wg ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
                 }
-                u4v g0, g1;
-                quad_groups(w, g0, g1);                                   // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
-                if (mo[nt] >= 0) {
-                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;
-                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;
+                // weight granule (2 k + h, cout nb*32 + r) by buffer load: ONE lane offset + a scalar per (k-step, block) — a 64-bit address per load
+                // (or a running pointer per ring slot) cost this kernel ~80 registers, and with them a ring deep enough to cover an L2 hit
+                u4v ring[R][NB];
+                auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (2 * k * COUT + cbase + nb * 32) * 16, 0)); };
+#pragma unroll
+                for (int d = 0; d < R; ++d)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
+                f32x16 acc[NT][NB];
+                acc_from_bias<NT, NB>(acc, lbias, cbase, h);
+                auto pixels = [&](int k, h16x8 (&x)[NT]) {                  // k is a compile-time constant after unrolling
+                    const int tap = k / 2, g = 2 * (k % 2) + h;
+                    const int kh = tap / KW, kw = tap % KW;
+                    const int tap_off = kh * p.IW + ((kw & 1) ? p.ev : 0) + (kw >> 1);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int pix = lbase[nt] + tap_off;
+                        x[nt] = __builtin_bit_cast(h16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
+                    }
+                };
+                h16x8 xa[NT], xb[NT];
+                pixels(0, xa);
+#pragma unroll
+                for (int k = 0; k < ksteps; ++k) {
+                    const int d = k % R;
+                    h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+                    h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+                    if (k + 1 < ksteps) pixels(k + 1, xn);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+                    if (k + R < ksteps) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    unsigned short* o = p.out + (size_t)(mo[nt] < 0 ? 0 : mo[nt]) * COUT + cbase;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        uint2 w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
+                            w[q] = relu_pack4(v0, v1, v2, v3);
+                        }
+                        u4v g0, g1;
+                        quad_groups(w, g0, g1);                           // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
+                        if (mo[nt] >= 0) {
+                            *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;
+                            *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;
+                        }
+                    }
                 }
             }
         }
+#if TRS_F5_STAMPS
+        { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); f5_k += t_ - f5_t0; f5_t0 = t_; }
+#endif
+        __syncthreads();                                                    // the next unit is in LDS, this one has been read
+#if TRS_F5_STAMPS
+        { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); f5_w += t_ - f5_t0; f5_t0 = t_; }
+#endif
     }
+#if TRS_F5_STAMPS
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == kCompute - 1 || wave == kCompute))
+        printf("frame5, workgroup 7, wave %d [clocks]: first staging %lld | units: work %lld, wait at the barrier %lld\n", wave, f5_st, f5_k, f5_w);
+#endif
 }
 
 // conv1 -> conv2 fused: conv1's activation (217 KB per 120x160 frame, the largest tensor of the network: 222 MB per 1024
@@ -1557,13 +1616,13 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
     // outputs above 128 MB leave non-temporally (measured: conv1's 222 MB -> conv1 88 -> 81 us, conv2 85 -> 82; at 48 MB conv3 loses)
     p.nt_out = (!l.out_f32 && (size_t)p.M * l.COUT * 2 > ((size_t)128 << 20)) ? 1 : 0;
     p.KH = l.KH; p.KW = l.KW; p.run_pad = l.run_pad; p.cg = l.u8in ? 0 : l.CIN / 8; p.span_nl = l.span_nl;
-    if (l.frame5) {                                                         // one unit (frame or row band) per 4-wave workgroup, two workgroups per CU
+    if (l.frame5) {                                                         // one persistent 8-wave workgroup per CU: a unit (frame or row band) computed from one LDS buffer, the next staged into the other
         Frame5Params q{};
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = 1; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
         q.bands = l.frame5_bands; q.ohb = l.frame5_ohb; q.ihb = l.frame5_bands == 1 ? l.IH : 2 * l.frame5_ohb + 3;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<2, 4, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        hipLaunchKernelGGL((trs_conv_frame5_kernel<2, 4, 256, 2>), dim3(n_img * q.bands), dim3(256), l.frame5_lds, s, q);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<2, TRS_F5_NB, TRS_F5_R, 64 * (TRS_F5_COMPUTE + 4), TRS_F5_COMPUTE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((trs_conv_frame5_kernel<2, TRS_F5_NB, TRS_F5_R, 64 * (TRS_F5_COMPUTE + 4), TRS_F5_COMPUTE>), dim3(std::min(n_img * q.bands, cu_count)), dim3(64 * (TRS_F5_COMPUTE + 4)), l.frame5_lds, s, q);
         HIPCHK(hipGetLastError());
         return TRS_OK;
     }
@@ -1908,11 +1967,10 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             while (bands < l.OH && (size_t)(bands == 1 ? l.IH : 2 * ((l.OH + bands - 1) / bands) + 3) * l.IW * 64 > 78 * 1024) ++bands;
             const int ohb = (l.OH + bands - 1) / bands, ihb = bands == 1 ? l.IH : 2 * ohb + 3;
             const size_t unit = (size_t)ihb * l.IW * 64;
-            // one unit (frame or band) per workgroup of four waves, two or more workgroups side by side on a CU: one stages its frame while the
-            // other computes (round 3: closed loop 192.7 -> 189.3 us on one box, 193.5 -> 193.3 on another; never slower than two frames per 8-wave workgroup)
+            // (round 3: one unit per 4-wave workgroup, two workgroups per CU; round 4: one persistent double-buffered workgroup per CU — see the kernel)
             // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; frame5 = 2 forces bands)
-            if (on && (bands == 1 || on >= 2) && shape_ok && unit + 256 <= 158 * 1024) {
-                l.frame5 = true; l.frame5_lds = (int)unit + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
+            if (on && (bands == 1 || on >= 2) && shape_ok && 2 * unit + 256 <= 158 * 1024) {           // two buffers: the unit being computed and the next one
+                l.frame5 = true; l.frame5_lds = (int)(2 * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
             }
         }
         // ---- pack the kernel into granules [g][cout_pad][8] of fp16 and the per-granule input offsets ----
