@@ -340,7 +340,7 @@ typedef struct trs_pilot_tuning {
     int32_t fuse_wsplit_max;     /* 4: a band may be cut into up to this many parts in width (240x320 needs 2); 1: never (a frame whose whole-width band does not fit LDS then runs unfused) */
     int32_t fuse_roll;           /* 1: with a (frame, part) per CU or more, a workgroup walks a frame's bands top to bottom and computes the 3 conv1 rows two bands share once; 0: never */
     int32_t span_layers_mask;    /* 0x6: bit i = conv(i+1) on trs_conv_span_kernel when it is not served by a fused / frame kernel (else trs_conv_lt_kernel) */
-    int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel when whole input frames fit LDS; 0: span kernel; 2: also in row bands */
+    int32_t frame5;              /* 1: conv3 on trs_conv_frame5_kernel (whole input frames in LDS, or row bands of them where a frame does not fit: 240x320); 0: span kernel; 2 = 1 (until round 4: "also in row bands") */
     int32_t frame_layers_mask;   /* 0x78: bit i = conv(i+1) (3x3 layers) on trs_conv_frame_kernel where its input fits LDS (else trs_conv_lt_kernel) */
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
     int32_t dense;               /* 1: dense1 / dense4 with 64 frames per workgroup where K is long (240x320), else 32; 2: always 32 (A/B) */

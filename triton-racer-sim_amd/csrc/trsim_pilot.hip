@@ -1968,8 +1968,9 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             const int ohb = (l.OH + bands - 1) / bands, ihb = bands == 1 ? l.IH : 2 * ohb + 3;
             const size_t unit = (size_t)ihb * l.IW * 64;
             // (round 3: one unit per 4-wave workgroup, two workgroups per CU; round 4: one persistent double-buffered workgroup per CU — see the kernel)
-            // (row bands were measured at 240x320: 89 us against the span kernel's 86 — only whole frames by default; frame5 = 2 forces bands)
-            if (on && (bands == 1 || on >= 2) && shape_ok && 2 * unit + 256 <= 158 * 1024) {           // two buffers: the unit being computed and the next one
+            // (row bands at 240x320: 89 us against the span kernel's 86 in round 3, one unit per workgroup; 72.0 against 83.1 on the persistent double-buffered
+            // workgroup of round 4: bands by default where a frame does not fit)
+            if (on && shape_ok && 2 * unit + 256 <= 158 * 1024) {           // two buffers: the unit being computed and the next one
                 l.frame5 = true; l.frame5_lds = (int)(2 * unit) + 64 * 4; l.frame5_bands = bands; l.frame5_ohb = ohb;
             }
         }
