@@ -159,143 +159,191 @@ struct FrameConvParams {
 // group of R k-steps is a whole number of taps: 12 = one kernel row of 3 taps at 64 input channels (4 k-steps per tap), 8 = one
 // tap at 128 input channels.
 
+#ifndef TRS_FRAME_STAMPS
+#define TRS_FRAME_STAMPS 0   /* diagnostic build, never shipped: workgroup 7 prints the s_memtime ticks of its staging, work and waits */
+#endif
+#ifndef TRS_FRAME_LOADERS
+#define TRS_FRAME_LOADERS 4   /* loader waves of trs_conv_frame_kernel beside its 8 compute waves */
+#endif
+#ifndef TRS_FRAME_R
+#define TRS_FRAME_R 4   /* weight ring depth of trs_conv_frame_kernel in k-steps */
+#endif
 #ifndef TRS_FRAME_ABLATE
-#define TRS_FRAME_ABLATE 0   /* timing-only diagnostic builds of trs_conv_frame_kernel, never shipped: 1 = no weight refills, 2 = one LDS pixel read per item, 3 = no stores, 4 = no staging */
+#define TRS_FRAME_ABLATE 0   /* timing-only diagnostic builds of trs_conv_frame_kernel, never shipped: 1 = no weight refills, 3 = no stores, 4 = no staging */
 #endif
 __device__ __forceinline__ int frame_swz(int pix, int cgs) { return cgs == 3 ? ((pix >> 1) & 7) : (pix & 15); }
 
-template <int NT, int NB, int HALF, int R, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trs_conv_frame_kernel(const FrameConvParams p)
+// Round 4: persistent and double-buffered, like trs_conv_frame5_kernel.  Until then a workgroup staged its F units, computed them and ended; its
+// ~150-200 registers allow one 8-wave workgroup per CU, so nothing ran beside the staging: a timing-only build without it (-DTRS_FRAME_ABLATE=4)
+// put it at 16-25 % of the 240x320 layers (conv4 49.1 -> 36.8 us, conv5 39.2 -> 29.8, conv6 58.9 -> 49.6, conv7 99.4 -> 83.7 per 512 frames).
+// Now one workgroup per CU walks its groups of F units: COMPUTE waves work on group i from one LDS buffer while LOADERS waves run the LDS-DMA
+// of group i + 1 into the other; one barrier per group.  The weights come by buffer load (one lane offset + a scalar per k-step: no 64-bit
+// address per ring slot — ~60 registers less, which is what lets 12 waves of <= 168 registers share the CU).
+template <int NT, int NB, int HALF, int R, int COMPUTE, int LOADERS>
+__global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_kernel(const FrameConvParams p)
 {
-    // R = HALF x TAPS (deep ring, 4 waves per workgroup with the whole register file each) or R = 4 (one tap or half a tap per
-    // group: ~150 registers, 8 waves per workgroup, the second wave of a SIMD hides what the short ring does not)
     static_assert(R >= 1 && R <= 9 * HALF, "ring depth in k-steps");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    constexpr int nwaves = COMPUTE + LOADERS, BLOCK = 64 * nwaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int n_units = p.N * p.bands;
-    const int u0 = blockIdx.x * p.F, nu = min(p.F, n_units - u0);
+    const int n_units = p.N * p.bands, n_groups = (n_units + p.F - 1) / p.F;
     const int upix = p.ihb * p.IW, uout = p.ohb * p.OW;                     // input pixels staged / output pixel slots per unit
-    {   // staging
-        const int total = (nu * upix) << p.cgs;
-        const unsigned lds_base = (unsigned)(uintptr_t)psmem;
-        for (int s0 = wave * 64; s0 < total; s0 += nwaves * 64) {
-            const int sl = s0 + lane;
-            if (sl < total && TRS_FRAME_ABLATE != 4) {
-                const int pix = sl >> p.cgs, q = sl & (p.cg - 1);
-                const int g = q ^ frame_swz(pix, p.cgs);
-                const int ul = pix / upix, rp = pix - ul * upix, iyl = rp / p.IW, ix = rp - iyl * p.IW;
-                const int u = u0 + ul, f = u / p.bands, band = u - f * p.bands;
-                const int iy = min(band * p.ohb + iyl, p.IH - 1);             // (rows below the frame are never read by a valid pixel)
-                const size_t gpix = ((size_t)f * p.IH + iy) * p.IW + ix;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + (gpix << p.cgs) + g),
-                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(lds_base + s0 * 16), 16, 0, 0);
+    const unsigned buf_bytes = (unsigned)((p.F * upix) << p.cgs) * 16u;     // one group of units in LDS
+    const unsigned lds_base = (unsigned)(uintptr_t)psmem;
+    // staging of group g into the buffer at byte offset `off` by waves w0 .. w0 + nw - 1 (LDS-DMA: 1 KB per wave instruction; the XOR swizzle goes
+    // on the SOURCE address, the LDS side stays lane-linear)
+    // A unit's input rows are whole rows of one frame: ONE contiguous run of upix x cg granules in memory (the rows a last band asks for below its
+    // frame are never read by a valid pixel: their addresses are clamped into the activation).  So a slot's source is base + slot ^ swizzle — a shift,
+    // a mask and an XOR per DMA instruction (the general (unit, row, column) split of rounds 2-3 cost ~80 instructions per 1 KB: four loader waves
+    // then needed as long for a group as eight compute waves for its MFMAs).
+    const int last_gran = (int)(((size_t)p.N * p.IH * p.IW) << p.cgs) - 1;
+    auto stage = [&](int g, unsigned off, int w0, int nw) {
+        const int u0 = g * p.F, nu = min(p.F, n_units - u0);
+        const int total = upix << p.cgs;                                    // granule slots of one unit
+        for (int ul = 0; ul < nu; ++ul) {
+            const int u = u0 + ul, f = u / p.bands, band = u - f * p.bands;  // (wave-uniform: scalar unit)
+            const int base = ((f * p.IH + band * p.ohb) * p.IW) << p.cgs;     // first granule of the unit in the activation (< 2^31: in_bytes fits an int)
+            const unsigned dst = lds_base + off + (unsigned)(ul * total) * 16u;
+            for (int s0 = (wave - w0) * 64; s0 < total; s0 += nw * 64) {
+                const int sl = s0 + lane;
+                if (sl < total && TRS_FRAME_ABLATE != 4) {
+                    const int pix = ul * upix + (sl >> p.cgs), q = sl & (p.cg - 1);   // (the swizzle follows the pixel's index in the GROUP, as the readers compute it)
+                    const int src = min(base + (sl - q) + (q ^ frame_swz(pix, p.cgs)), last_gran);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.in + src),
+                                                     (__attribute__((address_space(3))) void*)(uintptr_t)(dst + s0 * 16), 16, 0, 0);
+                }
             }
         }
-        float* lb = reinterpret_cast<float*>(psmem + (((size_t)(p.F * upix) << p.cgs) * 16));
-        for (int i = tid; i < p.COUT_PAD; i += blockDim.x) lb[i] = p.bias[i];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const u4v* lin = reinterpret_cast<const u4v*>(psmem);
-    const float4* lbias = reinterpret_cast<const float4*>(psmem + (((size_t)(p.F * upix) << p.cgs) * 16));   // staged behind the activations
-    int m_wg = nu * uout;                                                   // output pixel slots of this workgroup
-    if (p.F == 1 && p.bands > 1) {                                          // one unit: a short last band has no tiles for the rows below the frame
-        const int band = u0 % p.bands;
-        m_wg = min(p.ohb, p.OH - band * p.ohb) * p.OW;
-    }
-    const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = p.COUT_PAD / (NB * 32);
+    };
+    float* lb = reinterpret_cast<float*>(psmem + 2 * (size_t)buf_bytes);    // the bias behind the two buffers
+    const float4* lbias = reinterpret_cast<const float4*>(lb);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(p.w), 0, 9 * p.cg * p.COUT_PAD * 16, 0x00020000);   // [9 taps x cg granules][COUT_PAD] granules
+#if TRS_FRAME_STAMPS
+    long long fs_t0 = (long long)__builtin_amdgcn_s_memtime(), fs_st = 0, fs_k = 0, fs_w = 0;
+#endif
+    int g = blockIdx.x;
+    if (g < n_groups) stage(g, 0u, 0, nwaves);                              // the first group: all waves
+    for (int i = tid; i < p.COUT_PAD; i += BLOCK) lb[i] = p.bias[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#if TRS_FRAME_STAMPS
+    { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); fs_st += t_ - fs_t0; fs_t0 = t_; }
+#endif
     constexpr int ksteps = 9 * HALF;                                        // k-steps (16 input channels of one tap each) of a 3x3 kernel
-    for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
-        const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
-        const int cbase = cgrp * NB * 32;
-        int lbase[NT];                                                      // linear LDS pixel index of each of this lane's windows
-        long long obase[NT];                                                // output pixel index in the layer's activation, -1 = no such pixel
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-            const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
-            const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
-            lbase[nt] = (ul * p.ihb + oyl) * p.IW + ox;
-            obase[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
-        }
-        const u4v* wl = p.w + cbase + r;                                    // + (granule) * COUT_PAD + nb * 32
-        u4v ring[R][NB];
-#pragma unroll
-        for (int d = 0; d < R; ++d)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * p.COUT_PAD + nb * 32];
-        const u4v* wnext = wl + (size_t)(2 * R + h) * p.COUT_PAD;
-        [[maybe_unused]] h16x8 xkeep[NT];
-        f32x16 acc[NT][NB];
-        acc_from_bias<NT, NB>(acc, lbias, cbase, h);
-        // All ksteps k-steps are unrolled (3 x 12 or 9 x 8 ...): ONE basic block, no back edge — the compiler counts the weight
-        // loads in flight exactly (vmcnt(N) per k-step) instead of draining the queue at a loop head or behind a branch.  The pixel
-        // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
-        // that keeps "MFMAs of k, then the refill of k's ring slot" in place would otherwise also pin each k-step's LDS reads
-        // right in front of its own MFMAs: one LDS latency per 4 MFMAs).
-        // (Round 4: a second sched_barrier between those reads and the MFMAs — hipcc sinks the reads behind three of a k-step's four MFMAs — was
-        // measured in the frame kernels, the chain and frame5: all slower, chain 46.2 -> 48.4 us, conv7 96.1 -> 100.5: the address arithmetic then runs
-        // as a burst with no MFMA beside it.)
-        auto pixels = [&](int k, h16x8 (&x)[NT]) {                        // k is a compile-time constant after unrolling
-            const int tap = k / HALF, g = 2 * (k % HALF) + h;
-            const int tap_off = (tap / 3) * p.IW + tap % 3;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int pix = lbase[nt] + tap_off;
-#if TRS_FRAME_ABLATE == 2
-                if (k == 0) xkeep[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
-                x[nt] = xkeep[nt];
-#else
-                x[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (g ^ frame_swz(pix, p.cgs))]);
-#endif
+    const int n_cgrp = p.COUT_PAD / (NB * 32);
+    for (int it = 0; g < n_groups; ++it, g += gridDim.x) {
+        const unsigned cur = (it & 1) ? buf_bytes : 0u;
+        if (wave >= COMPUTE) {                                              // loaders: the next group into the other buffer
+            if (g + (int)gridDim.x < n_groups) stage(g + (int)gridDim.x, buf_bytes - cur, COMPUTE, LOADERS);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const u4v* lin = reinterpret_cast<const u4v*>(psmem + cur);
+            const int u0 = g * p.F, nu = min(p.F, n_units - u0);
+            int m_wg = nu * uout;                                           // output pixel slots of this group
+            if (p.F == 1 && p.bands > 1) {                                  // one unit: a short last band has no tiles for the rows below the frame
+                const int band = u0 % p.bands;
+                m_wg = min(p.ohb, p.OH - band * p.ohb) * p.OW;
             }
-        };
-        h16x8 xa[NT], xb[NT];
-        pixels(0, xa);
+            const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32);
+            for (int item = wave; item < n_tiles * n_cgrp; item += COMPUTE) {
+                const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
+                const int cbase = cgrp * NB * 32;
+                int lbase[NT];                                              // linear LDS pixel index of each of this lane's windows
+                long long obase[NT];                                        // output pixel index in the layer's activation, -1 = no such pixel
 #pragma unroll
-        for (int k = 0; k < ksteps; ++k) {
-            const int d = k % R;
-            h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
-            h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
-            if (k + 1 < ksteps) pixels(k + 1, xn);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
-            if (k + R < ksteps && TRS_FRAME_ABLATE != 1) {                  // (compile-time) refill the slot with the k-step R ahead:
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];   // a running pointer — one live address, not one per k-step
-                wnext += 2 * p.COUT_PAD;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // epilogue: register quad q of block nb = channels cbase + nb*32 + 8q + 4h .. +3 of pixel r.  The two lanes of a pixel
-        // (h = 0, 1) hold the two halves of every 8-channel group: they swap half of their quads (one cross-half shuffle per
-        // dword) so that each lane ends with whole 16-byte groups — lane h = 0 stores groups q = 0, 1, lane h = 1 groups 2, 3
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            unsigned short* o = p.out + (size_t)(obase[nt] < 0 ? 0 : obase[nt]) * p.COUT + cbase;
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                uint2 w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
-                    w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
+                    const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
+                    const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
+                    lbase[nt] = (ul * p.ihb + oyl) * p.IW + ox;
+                    obase[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
                 }
-                u4v g0, g1;
-                quad_groups(w, g0, g1);                                   // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
+                // weight granule (2 k + h, cout cbase + nb*32 + r) by buffer load: one lane offset + a scalar per (k-step, block)
+                const int wvoff = (h * p.COUT_PAD + cbase + r) * 16;
+                auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (2 * k * p.COUT_PAD + nb * 32) * 16, 0)); };
+                u4v ring[R][NB];
+#pragma unroll
+                for (int d = 0; d < R; ++d)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
+                f32x16 acc[NT][NB];
+                acc_from_bias<NT, NB>(acc, lbias, cbase, h);
+                // All ksteps k-steps are unrolled (3 x 12 or 9 x 8 ...): ONE basic block, no back edge — the compiler counts the weight
+                // loads in flight exactly (vmcnt(N) per k-step) instead of draining the queue at a loop head or behind a branch.  The pixel
+                // fragments are software-pipelined by hand: k-step k + 1's ds_reads are issued BEFORE k-step k's MFMAs (the sched_barrier
+                // that keeps "MFMAs of k, then the refill of k's ring slot" in place would otherwise also pin each k-step's LDS reads
+                // right in front of its own MFMAs: one LDS latency per 4 MFMAs).
+                // (Round 4: a second sched_barrier between those reads and the MFMAs — hipcc sinks the reads behind three of a k-step's four MFMAs — was
+                // measured in the frame kernels, the chain and frame5: all slower, chain 46.2 -> 48.4 us, conv7 96.1 -> 100.5: the address arithmetic then runs
+                // as a burst with no MFMA beside it.)
+                auto pixels = [&](int k, h16x8 (&x)[NT]) {                  // k is a compile-time constant after unrolling
+                    const int tap = k / HALF, gq = 2 * (k % HALF) + h;
+                    const int tap_off = (tap / 3) * p.IW + tap % 3;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int pix = lbase[nt] + tap_off;
+                        x[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (gq ^ frame_swz(pix, p.cgs))]);
+                    }
+                };
+                h16x8 xa[NT], xb[NT];
+                pixels(0, xa);
+#pragma unroll
+                for (int k = 0; k < ksteps; ++k) {
+                    const int d = k % R;
+                    h16x8 (&xc)[NT] = (k & 1) ? xb : xa;
+                    h16x8 (&xn)[NT] = (k & 1) ? xa : xb;
+                    if (k + 1 < ksteps) pixels(k + 1, xn);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
+                    if (k + R < ksteps && TRS_FRAME_ABLATE != 1) {          // (compile-time) refill the slot with the k-step R ahead
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // epilogue: register quad q of block nb = channels cbase + nb*32 + 8q + 4h .. +3 of pixel r.  The two lanes of a pixel
+                // (h = 0, 1) hold the two halves of every 8-channel group: they swap half of their quads (v_permlane32_swap_b32) so that
+                // each lane ends with whole 16-byte groups — lane h = 0 stores groups q = 0, 1, lane h = 1 groups 2, 3
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    unsigned short* o = p.out + (size_t)(obase[nt] < 0 ? 0 : obase[nt]) * p.COUT + cbase;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        uint2 w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0 = acc[nt][nb][4 * q], v1 = acc[nt][nb][4 * q + 1], v2 = acc[nt][nb][4 * q + 2], v3 = acc[nt][nb][4 * q + 3];
+                            w[q] = p.relu ? relu_pack4(v0, v1, v2, v3) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
+                        }
+                        u4v g0, g1;
+                        quad_groups(w, g0, g1);                           // lane h = 0: channel groups 0, 1 of this block, lane h = 1: groups 2, 3 (whole 16-byte groups)
 #if TRS_FRAME_ABLATE == 3
-                asm volatile("" :: "v"(g0), "v"(g1)); (void)o;
+                        asm volatile("" :: "v"(g0), "v"(g1)); (void)o;
 #else
-                if (obase[nt] >= 0) {
-                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;       // channels nb*32 + 16h .. + 7
-                    *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;   // ... + 8 .. + 15
-                }
+                        if (obase[nt] >= 0) {
+                            *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h) = g0;       // channels nb*32 + 16h .. + 7
+                            *reinterpret_cast<u4v*>(o + nb * 32 + 16 * h + 8) = g1;   // ... + 8 .. + 15
+                        }
 #endif
+                    }
+                }
             }
         }
+#if TRS_FRAME_STAMPS
+        { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); fs_k += t_ - fs_t0; fs_t0 = t_; }
+#endif
+        __syncthreads();                                                    // the next group is in LDS, this one has been read
+#if TRS_FRAME_STAMPS
+        { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); fs_w += t_ - fs_t0; fs_t0 = t_; }
+#endif
     }
+#if TRS_FRAME_STAMPS
+    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == COMPUTE - 1 || wave == COMPUTE))
+        printf("frame kernel (cg %d, COUT %d, bands %d, F %d, %d groups), workgroup 7, wave %d [ticks]: first staging %lld | groups: work %lld, wait at the barrier %lld\n",
+               p.cg, p.COUT, p.bands, p.F, n_groups, wave, fs_st, fs_k, fs_w);
+#endif
 }
 
 // ---- conv4 .. conv7 in ONE launch: a frame's activations never leave LDS (round 2) ---------------------------------------------
@@ -1632,18 +1680,15 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.COUT = l.COUT; q.COUT_PAD = l.COUT_PAD; q.KH = l.KH; q.KW = l.KW;
         q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
         q.bands = l.frame_bands; q.ohb = l.frame_ohb; q.ihb = l.frame_ohb + l.KH - 1;
-        const int grid = (n_img * q.bands + q.F - 1) / q.F;
+        const int groups = (n_img * q.bands + q.F - 1) / q.F, grid = std::min(groups, cu_count);   // one persistent workgroup per CU
 #define LAUNCH_FRAME(NT_, HALF_)                                                                                              \
     do {                                                                                                                      \
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<NT_, 2, HALF_, 4, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((trs_conv_frame_kernel<NT_, 2, HALF_, 4, 512>), dim3(grid), dim3(512), l.frame_lds, s, q);        \
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame_kernel<NT_, 2, HALF_, TRS_FRAME_R, 8, TRS_FRAME_LOADERS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((trs_conv_frame_kernel<NT_, 2, HALF_, TRS_FRAME_R, 8, TRS_FRAME_LOADERS>), dim3(grid), dim3(64 * (8 + TRS_FRAME_LOADERS)), l.frame_lds, s, q);   \
     } while (0)
-        // 32-pixel tiles per wave item: 2, or 3 where that leaves the busiest SIMD no more MFMAs (3 streams a third less weights through L1)
-        const int px = std::min(q.F, n_img * q.bands) * q.ohb * q.OW, cgrps = q.COUT_PAD / 64;
-        auto busiest = [&](int nt) { const int items = ((px + 32 * nt - 1) / (32 * nt)) * cgrps; return ((items + 3) / 4) * nt; };
-        const int nt = busiest(3) <= busiest(2) ? 3 : 2;
-        if (q.cg == 8) { if (nt == 3) LAUNCH_FRAME(3, 4); else LAUNCH_FRAME(2, 4); }
-        else { if (nt == 3) LAUNCH_FRAME(3, 8); else LAUNCH_FRAME(2, 8); }
+        // (wave items of 2 x 32 pixels x 64 channels: the host cuts the frames into bands so that a group has about 8 of them — items of 3 tiles need
+        // more than the 168 registers that 12 waves leave each)
+        if (q.cg == 8) LAUNCH_FRAME(2, 4); else LAUNCH_FRAME(2, 8);
 #undef LAUNCH_FRAME
         HIPCHK(hipGetLastError());
         return TRS_OK;
@@ -1945,17 +1990,29 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             const int cg = l.CIN / 8;
             const bool shape_ok = l.S == 1 && l.KH == 3 && l.KW == 3 && (cg == 8 || cg == 16) && l.COUT_PAD % 64 == 0 && l.COUT == l.COUT_PAD && run_pad == l.KW * cg;
             if (((mask >> i) & 1) && shape_ok) {
-                // a frame larger than ~110 KB is cut into row bands (conv7 at 240x320: 21 x 31 x 128 = 167 KB -> 2 bands of 10 / 9 rows)
-                int bands = 1;
-                while (bands < l.OH && (size_t)((l.OH + bands - 1) / bands + l.KH - 1) * l.IW * l.CIN * 2 > 110 * 1024) ++bands;
+                // Two LDS buffers (the group being computed and the next one), F units each, a unit = a frame or one of `bands` row bands of it (240x320:
+                // conv4 128 KB, conv6 97 KB, conv7 167 KB per frame).  Among the (bands, F) that fit, take the one with the fewest MFMA rounds: a group is
+                // ceil(tiles / 2) x (COUT / 64) wave items for 8 compute waves; bands re-stage KH - 1 rows each (a small penalty), every CU should get
+                // at least two groups (one to compute, one on its way).
+                int bands = 1, f = 1; double best = 1e30;
+                for (int bnd = 1; bnd <= l.OH && bnd <= 8; ++bnd) {
+                    const int ohb_ = (l.OH + bnd - 1) / bnd;
+                    const size_t unit_ = (size_t)(ohb_ + l.KH - 1) * l.IW * l.CIN * 2;
+                    for (int f_ = 1; f_ <= 8; ++f_) {
+                        if (2 * unit_ * f_ + l.COUT_PAD * 4 > 158 * 1024) break;
+                        const long groups = ((long)c->n_cap * bnd + f_ - 1) / f_;
+                        if (f_ > 1 && groups < 2 * c->cu_count) break;
+                        const int tiles = (f_ * ohb_ * l.OW + 31) / 32, items = ((tiles + 1) / 2) * (l.COUT_PAD / 64);
+                        const double rounds = (double)((items + 7) / 8), per_cu = std::ceil((double)groups / c->cu_count);
+                        const double cost = per_cu * (rounds + 0.15) * (1.0 + 0.1 * (double)(bnd - 1) * (l.KH - 1) / l.OH);   // + a barrier and a hand-over per group
+                        if (cost < best - 1e-9) { best = cost; bands = bnd; f = f_; }
+                    }
+                }
                 const int ohb = (l.OH + bands - 1) / bands;
                 const int ihb = ohb + l.KH - 1;
                 const size_t unit_bytes = (size_t)ihb * l.IW * l.CIN * 2;
-                // units per workgroup: as many as fit ~100 KB (a short ring leaves room for 8 waves) while the grid keeps one workgroup per CU
-                int f = (int)std::max<size_t>(1, std::min<size_t>(8, (104 * 1024) / unit_bytes));
-                while (f > 1 && (c->n_cap * bands + f - 1) / f < c->cu_count) --f;
-                l.frame = unit_bytes * f + l.COUT_PAD * 4 <= 158 * 1024;
-                l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(f * unit_bytes) + l.COUT_PAD * 4;
+                l.frame = best < 1e29;
+                l.frame_f = f; l.frame_bands = bands; l.frame_ohb = ohb; l.frame_lds = (int)(2 * f * unit_bytes) + l.COUT_PAD * 4;
             }
         }
         if (i == 2) {            // conv3: frames in LDS when two fit (120x160: 2 x 64 KB); TRS_PILOT_FRAME5 = 0: the span kernel
@@ -2113,7 +2170,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             bool ok = true;
             for (int i = first; i < 7; ++i) {
                 const ConvLayer& l = c->L[i];
-                ok = ok && l.frame && l.frame_bands == 1 && l.COUT == l.COUT_PAD && l.CIN == (i == 6 ? 128 : 64) && (l.COUT == 64 || l.COUT == 128);
+                ok = ok && l.frame && l.COUT == l.COUT_PAD && l.CIN == (i == 6 ? 128 : 64) && (l.COUT == 64 || l.COUT == 128);
             }
             if (!ok) continue;
             auto out_bytes = [&](int i) { return (size_t)c->L[i].OH * c->L[i].OW * c->L[i].COUT * 2; };
