@@ -4,8 +4,8 @@
 // trs_conv_chain_kernel / trs_conv_frame_kernel, trs_pilot_dense_kernel).  The kernels here serve what those do not:
 //   trs_conv_u8_kernel    conv1 as its own layer (trs_pilot_tuning.no_fuse, a frame shape whose band does not fit LDS, and the activation the
 //                         fused head never writes: trs_pilot_debug_layer(0), trs_pilot_range_check)
-//   trs_conv_span_kernel  the stride-2 5x5 layers from per-row input spans staged in LDS: conv3 at 240x320 (its 281 KB frames do not fit LDS: a
-//                         DEFAULT path), conv2 unfused
+//   trs_conv_span_kernel  the stride-2 5x5 layers from per-row input spans staged in LDS: conv2 unfused, conv3 where trs_conv_frame5_kernel does not apply
+//                         (trs_pilot_tuning.frame5 = 0; until round 4 conv3's default at 240x320 — row bands on the frame5 kernel are faster now)
 //   trs_conv_lt_kernel    every other (layer, shape): quad-coalesced pixel loads + LDS transpose — the one generic fallback
 // Round 4 removed the chunked kernel (trs_conv_mfma_kernel: rounds 1-2's dense1 and last-resort fallback) and the direct form of the fused head
 // (trs_conv12_kernel), which no default shape reached.
