@@ -70,6 +70,7 @@ struct ConvParams {
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
+typedef const __attribute__((address_space(3))) u4v* lds_u4vp;   // an LDS address held as an integer: no "+ psmem" per access
 
 __device__ __forceinline__ unsigned short f2h(float f)
 {   // round to nearest even; beyond binary16's range: 65504 (the activations saturate, they never become infinite)
@@ -383,6 +384,8 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = L.COUT / (NB * 32);
     const float4* lbias = reinterpret_cast<const float4*>(lbias_f);
     constexpr int ksteps = 9 * HALF;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(L.w), 0, 9 * L.cg * L.COUT * 16, 0x00020000);   // [9 taps x cg granules][COUT] granules
+    const unsigned lin_b = (unsigned)(uintptr_t)lin;                                // LDS byte address of the layer's input image
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
         const int cgrp = item / n_tiles, tile = item - cgrp * n_tiles;
         const int cbase = cgrp * NB * 32;
@@ -394,27 +397,36 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             lbase[nt] = (ul * L.IH + oy) * L.IW + ox;
             mo[nt] = m < m_wg ? m : -1;
         }
-        const u4v* wl = L.w + cbase + r;
+        // (round 4, profiles/r04_mfma_issue.txt: inside a wave every vector-ALU instruction between two MFMAs ADDS ~6 ticks to the MFMA's 32, and two waves
+        // per SIMD hide only part of each other's — a K loop is priced by its non-MFMA instructions per MFMA.  So: weights by buffer load (one lane offset
+        // + a scalar per k-step instead of a 64-bit running pointer), and the XOR-swizzled LDS address of a tap's fragment computed ONCE per tap: the
+        // granule of k-step j of the tap is 2 j + h, and (2 j + h) ^ swizzle = (h ^ swizzle) ^ 2 j — the tap's byte address ^ 32 j, one v_xor per k-step.)
+        const int wvoff = (h * L.COUT + cbase + r) * 16;
+        auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + nb * 512, 2 * k * L.COUT * 16, 0)); };
         u4v ring[R][NB];
 #pragma unroll
         for (int d = 0; d < R; ++d)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wl[(size_t)(2 * d + h) * L.COUT + nb * 32];
-        const u4v* wnext = wl + (size_t)(2 * R + h) * L.COUT;
+            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
         f32x16 acc[NT][NB];
         acc_from_bias<NT, NB>(acc, lbias, cbase, h);
         [[maybe_unused]] h16x8 xkeep[NT];
+        unsigned tapb[NT];                                                  // LDS byte address of this lane's granule h ^ swizzle of the current tap's pixel
         auto pixels = [&](int k, h16x8 (&x)[NT]) {
-            const int tap = k / HALF, g = 2 * (k % HALF) + h;
+            const int tap = k / HALF, j = k % HALF;
             const int tap_off = (tap / 3) * L.IW + tap % 3;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int pix = lbase[nt] + tap_off;
+                if (j == 0) {
+                    const int pix = lbase[nt] + tap_off;
+                    tapb[nt] = lin_b + (unsigned)(((pix << L.cgs) + (h ^ frame_swz(pix, L.cgs))) << 4);
+                }
+                const h16x8 v = __builtin_bit_cast(h16x8, *(lds_u4vp)(uintptr_t)(tapb[nt] ^ (unsigned)(32 * j)));
 #if TRS_CHAIN_ABLATE == 2
-                if (k == 0) xkeep[nt] = __builtin_bit_cast(h16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+                if (k == 0) xkeep[nt] = v;
                 x[nt] = xkeep[nt];
 #else
-                x[nt] = __builtin_bit_cast(h16x8, lin[(pix << L.cgs) + (g ^ frame_swz(pix, L.cgs))]);
+                x[nt] = v;
 #endif
             }
         };
@@ -438,8 +450,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 }
             if (k + R < ksteps && TRS_CHAIN_ABLATE != 1) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wnext[nb * 32];
-                wnext += 2 * L.COUT;
+                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
