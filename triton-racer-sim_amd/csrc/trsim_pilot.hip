@@ -238,7 +238,6 @@ __global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_ke
             if (g + (int)gridDim.x < n_groups) stage(g + (int)gridDim.x, buf_bytes - cur, COMPUTE, LOADERS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            const u4v* lin = reinterpret_cast<const u4v*>(psmem + cur);
             const int u0 = g * p.F, nu = min(p.F, n_units - u0);
             int m_wg = nu * uout;                                           // output pixel slots of this group
             if (p.F == 1 && p.bands > 1) {                                  // one unit: a short last band has no tiles for the rows below the frame
@@ -260,13 +259,19 @@ __global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_ke
                     obase[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
                 }
                 // weight granule (2 k + h, cout cbase + nb*32 + r) by buffer load: one lane offset + a scalar per (k-step, block)
+                // (the k-step part of the offset is ONE scalar that runs with the loads — a constant per (k-step, block), 144 of them at 128 input channels, was hoisted
+                // out of the item loop and spilled to vector-register lanes: a v_readlane + wait states in front of every load; the block is the immediate offset)
                 const int wvoff = (h * p.COUT_PAD + cbase + r) * 16;
-                auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (2 * k * p.COUT_PAD + nb * 32) * 16, 0)); };
+                int wso = 0;
+                auto wload = [&](int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + nb * 512, wso, 0)); };
+                auto wnext = [&]() { wso += 2 * p.COUT_PAD * 16; asm volatile("" : "+s"(wso)); };   // the loads are issued in k order
                 u4v ring[R][NB];
 #pragma unroll
-                for (int d = 0; d < R; ++d)
+                for (int d = 0; d < R; ++d) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
+                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+                    wnext();
+                }
                 f32x16 acc[NT][NB];
                 acc_from_bias<NT, NB>(acc, lbias, cbase, h);
                 // All ksteps k-steps are unrolled (3 x 12 or 9 x 8 ...): ONE basic block, no back edge — the compiler counts the weight
@@ -277,13 +282,20 @@ __global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_ke
                 // (Round 4: a second sched_barrier between those reads and the MFMAs — hipcc sinks the reads behind three of a k-step's four MFMAs — was
                 // measured in the frame kernels, the chain and frame5: all slower, chain 46.2 -> 48.4 us, conv7 96.1 -> 100.5: the address arithmetic then runs
                 // as a burst with no MFMA beside it.)
+                // the XOR-swizzled LDS address of a tap's fragment once per tap: granule 2 j + h of k-step j, and (2 j + h) ^ swizzle = (h ^ swizzle) ^ 2 j — the
+                // tap's byte address ^ 32 j, one v_xor per k-step and tile (a K loop is priced by its non-MFMA instructions: profiles/r04_mfma_issue.txt)
+                constexpr int CGS = HALF == 4 ? 3 : 4;                      // (8 granules per input pixel <-> 4 k-steps per tap, 16 <-> 8)
+                unsigned tapb[NT];
                 auto pixels = [&](int k, h16x8 (&x)[NT]) {                  // k is a compile-time constant after unrolling
-                    const int tap = k / HALF, gq = 2 * (k % HALF) + h;
+                    const int tap = k / HALF, j = k % HALF;
                     const int tap_off = (tap / 3) * p.IW + tap % 3;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int pix = lbase[nt] + tap_off;
-                        x[nt] = __builtin_bit_cast(h16x8, lin[(pix << p.cgs) + (gq ^ frame_swz(pix, p.cgs))]);
+                        if (j == 0) {
+                            const int pix = lbase[nt] + tap_off;
+                            tapb[nt] = lds_base + cur + (unsigned)(((pix << CGS) + (h ^ frame_swz(pix, CGS))) << 4);
+                        }
+                        x[nt] = __builtin_bit_cast(h16x8, *(lds_u4vp)(uintptr_t)(tapb[nt] ^ (unsigned)(32 * j)));
                     }
                 };
                 h16x8 xa[NT], xb[NT];
@@ -300,7 +312,8 @@ __global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_ke
                         for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
                     if (k + R < ksteps && TRS_FRAME_ABLATE != 1) {          // (compile-time) refill the slot with the k-step R ahead
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
+                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+                        wnext();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -383,7 +396,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
     const int uout = L.OH * L.OW, m_wg = nu * uout;
     const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = L.COUT / (NB * 32);
     const float4* lbias = reinterpret_cast<const float4*>(lbias_f);
-    constexpr int ksteps = 9 * HALF;
+    constexpr int ksteps = 9 * HALF, CGS = HALF == 4 ? 3 : 4;              // (8 granules per input pixel <-> 4 k-steps per tap, 16 <-> 8: the host builds the layers so)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u4v*>(L.w), 0, 9 * L.cg * L.COUT * 16, 0x00020000);   // [9 taps x cg granules][COUT] granules
     const unsigned lin_b = (unsigned)(uintptr_t)lin;                                // LDS byte address of the layer's input image
     for (int item = wave; item < n_tiles * n_cgrp; item += nwaves) {
@@ -402,12 +415,16 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
         // + a scalar per k-step instead of a 64-bit running pointer), and the XOR-swizzled LDS address of a tap's fragment computed ONCE per tap: the
         // granule of k-step j of the tap is 2 j + h, and (2 j + h) ^ swizzle = (h ^ swizzle) ^ 2 j — the tap's byte address ^ 32 j, one v_xor per k-step.)
         const int wvoff = (h * L.COUT + cbase + r) * 16;
-        auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + nb * 512, 2 * k * L.COUT * 16, 0)); };
+        int wso = 0;                                                        // the k-step part of the offset: one scalar that runs with the loads (issued in k order)
+        auto wload = [&](int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + nb * 512, wso, 0)); };
+        auto wnext = [&]() { wso += 2 * L.COUT * 16; asm volatile("" : "+s"(wso)); };
         u4v ring[R][NB];
 #pragma unroll
-        for (int d = 0; d < R; ++d)
+        for (int d = 0; d < R; ++d) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
+            for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+            wnext();
+        }
         f32x16 acc[NT][NB];
         acc_from_bias<NT, NB>(acc, lbias, cbase, h);
         [[maybe_unused]] h16x8 xkeep[NT];
@@ -419,7 +436,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
             for (int nt = 0; nt < NT; ++nt) {
                 if (j == 0) {
                     const int pix = lbase[nt] + tap_off;
-                    tapb[nt] = lin_b + (unsigned)(((pix << L.cgs) + (h ^ frame_swz(pix, L.cgs))) << 4);
+                    tapb[nt] = lin_b + (unsigned)(((pix << CGS) + (h ^ frame_swz(pix, CGS))) << 4);
                 }
                 const h16x8 v = __builtin_bit_cast(h16x8, *(lds_u4vp)(uintptr_t)(tapb[nt] ^ (unsigned)(32 * j)));
 #if TRS_CHAIN_ABLATE == 2
@@ -450,7 +467,8 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
                 }
             if (k + R < ksteps && TRS_CHAIN_ABLATE != 1) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
+                for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+                wnext();
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -641,7 +659,6 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
             if (u + (int)gridDim.x < n_units) stage(u + (int)gridDim.x, buf_bytes - cur, kCompute, nwaves - kCompute);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            const u4v* lin = reinterpret_cast<const u4v*>(psmem + cur);
             const int f = u / p.bands, band = u - f * p.bands;
             const int m_wg = min(p.ohb, p.OH - band * p.ohb) * p.OW;         // a short last band has no tiles for the rows below the frame
             const int n_tiles = (m_wg + NT * 32 - 1) / (NT * 32), n_cgrp = COUT / (NB * 32);
@@ -660,21 +677,30 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
                 // weight granule (2 k + h, cout nb*32 + r) by buffer load: ONE lane offset + a scalar per (k-step, block) — a 64-bit address per load
                 // (or a running pointer per ring slot) cost this kernel ~80 registers, and with them a ring deep enough to cover an L2 hit
                 u4v ring[R][NB];
-                auto wload = [&](int k, int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, (2 * k * COUT + cbase + nb * 32) * 16, 0)); };
+                int wso = cbase * 16;                                       // the k-step part of the offset: one scalar that runs with the loads (see trs_conv_frame_kernel)
+                auto wload = [&](int nb) { return __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff + nb * 512, wso, 0)); };
+                auto wnext = [&]() { wso += 2 * COUT * 16; asm volatile("" : "+s"(wso)); };
 #pragma unroll
-                for (int d = 0; d < R; ++d)
+                for (int d = 0; d < R; ++d) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(d, nb);
+                    for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+                    wnext();
+                }
                 f32x16 acc[NT][NB];
                 acc_from_bias<NT, NB>(acc, lbias, cbase, h);
+                // (the swizzled address once per tap, ^ 32 for its second k-step: see trs_conv_frame_kernel)
+                unsigned tapb[NT];
                 auto pixels = [&](int k, h16x8 (&x)[NT]) {                  // k is a compile-time constant after unrolling
-                    const int tap = k / 2, g = 2 * (k % 2) + h;
+                    const int tap = k / 2, j = k % 2;
                     const int kh = tap / KW, kw = tap % KW;
                     const int tap_off = kh * p.IW + ((kw & 1) ? p.ev : 0) + (kw >> 1);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int pix = lbase[nt] + tap_off;
-                        x[nt] = __builtin_bit_cast(h16x8, lin[pix * 4 + (g ^ ((pix >> 2) & 3))]);
+                        if (j == 0) {
+                            const int pix = lbase[nt] + tap_off;
+                            tapb[nt] = lds_base + cur + (unsigned)((pix * 4 + (h ^ ((pix >> 2) & 3))) << 4);
+                        }
+                        x[nt] = __builtin_bit_cast(h16x8, *(lds_u4vp)(uintptr_t)(tapb[nt] ^ (unsigned)(32 * j)));
                     }
                 };
                 h16x8 xa[NT], xb[NT];
@@ -691,7 +717,8 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
                         for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[d][nb]), xc[nt], acc[nt][nb], 0, 0, 0);
                     if (k + R < ksteps) {
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(k + R, nb);
+                        for (int nb = 0; nb < NB; ++nb) ring[d][nb] = wload(nb);
+                        wnext();
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
