@@ -156,9 +156,8 @@ struct FrameConvParams {
     int relu;                  // (neighbouring bands re-stage KH - 1 rows); bands == 1: ohb = OH, ihb = IH
 };
 // weight prefetch: a register ring of R k-steps (R x NB granules per lane), refilled slot by slot right behind the MFMAs that
-// consumed the slot: R x NT x NB x 32 MFMA clocks of lead time (>= 1,000) against an L2 round trip of 500-800.  The unrolled
-// group of R k-steps is a whole number of taps: 12 = one kernel row of 3 taps at 64 input channels (4 k-steps per tap), 8 = one
-// tap at 128 input channels.
+// consumed the slot: R x NT x NB x 32 MFMA clocks of lead time against an L2 round trip of 500-800 (R = 4: one tap at 64 input
+// channels, half a tap at 128; rings of 6 and 8 measured no faster).
 
 #ifndef TRS_FRAME_STAMPS
 #define TRS_FRAME_STAMPS 0   /* diagnostic build, never shipped: workgroup 7 prints the s_memtime ticks of its staging, work and waits */
@@ -610,8 +609,7 @@ template <int NT, int NB, int R, int BLOCK, int COMPUTE>
 __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5Params p)
 {
     constexpr int KW = 5, ksteps = 50, kCompute = COMPUTE;                  // waves 0 .. COMPUTE - 1 compute, the others stage
-    const int COUT = p.COUT;                                                // 64; a run-time value on purpose: with a constant the compiler folds the ring's running
-                                                                            // pointer into 46 precomputed addresses (92 live registers, spills)
+    const int COUT = p.COUT;                                                // 64 (the host checks)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nwaves = BLOCK / 64;
     static_assert(nwaves > kCompute, "loader waves");
