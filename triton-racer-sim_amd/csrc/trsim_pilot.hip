@@ -769,9 +769,6 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
 #ifndef TRS_FUSE_ABLATE
 #define TRS_FUSE_ABLATE 0
 #endif
-#ifndef TRS_C1_ABLATE
-#define TRS_C1_ABLATE 0   /* timing-only builds of the head's conv1 phase: 1 = fragments read for a wave's first tile only, 2 = no tile writes, 3 = no MFMA */
-#endif
 #ifndef TRS_C2_ABLATE
 #define TRS_C2_ABLATE 0
 #endif
@@ -791,11 +788,6 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
 #define BAND_STAMP(i) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); st_[i] += t_ - t0_; t0_ = t_; } while (0)
 #else
 #define BAND_STAMP(i) do { } while (0)
-#endif
-#if TRS_BAND_STAMPS == 2   /* also inside the conv1 tile loop (perturbs it: every stamp drains the wave's LDS queue) */
-#define BAND_STAMP2(i) BAND_STAMP(i)
-#else
-#define BAND_STAMP2(i) do { } while (0)
 #endif
 struct Fuse12Params {
     const uint8_t* frames; int frames_bytes;
@@ -966,8 +958,23 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
 #pragma unroll
     for (int i = 12; i < 16; ++i) bias16[i] = 0.0f;
     asm volatile("" : "+v"(bias16));
+    // the rolling bands of whole-width frames share one conv1 geometry (2 R2 new rows of OW1 pixels: at most two tiles per wave): this lane's
+    // window address in the band image, its column's offset in a ring row, and (pixel index | row << 16) for the tiles wave and wave + 16
+    struct C1Slot { unsigned ra, pk; };                                     // pk = pixel index (10 bits) | row (4 bits) | column offset in a ring row (the rest)
+    C1Slot c1s[2];
+    const bool c1_fast = !SPLIT && q.roll && (2 * q.R2 * q.OW1 + 31) / 32 <= 2 * nwaves && 2 * q.R2 < 16 && 2 * nwaves * 32 <= 1024;
+    if (c1_fast) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pp = (wave_u + i * nwaves) * 32 + r;
+            const int yl = (int)__umulhi((unsigned)pp, magic1), x = pp - yl * q.OW1;
+            c1s[i].ra = (unsigned)q.off_band + 16u * h + (unsigned)(__mul24(2 * yl, row_in) + __mul24(x, 6)) * 2u;   // (past the band's last pixel: still inside the image
+                                                                                                                  // buffer, which is sized for a frame's first band; never stored)
+            c1s[i].pk = (unsigned)pp | ((unsigned)yl << 10) | ((unsigned)(((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)) << 14);
+        }
+    }
 #if TRS_BAND_STAMPS
-    long long st_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = (long long)__builtin_amdgcn_s_memtime();
+    long long st_[5] = {0, 0, 0, 0, 0}, t0_ = (long long)__builtin_amdgcn_s_memtime();
 #endif
     while (wt < total) {
         const int nxt = wt + 1;                                             // uniform per workgroup
@@ -978,10 +985,46 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         // ---- phase 1: the band's conv1 rows that are not in the tile yet (all of them, or all but the first 3), from the fp16 image ----
         const int rows1 = r1 - skip, npx1 = rows1 * w1, ntile1 = (npx1 + 31) >> 5;
 #if TRS_FUSE_ABLATE != 1
-        {
-            // A lane walks its pixels p = 32 t1 + r, t1 = wave, wave + 16, ... incrementally: (row yl, column x), the LDS address of its window in
-            // the band image and its ring slot in the tile advance by wave-uniform steps with one wrap (the phase is bound by its vector instructions
-            // — ~70 per tile until round 4, a third of them this address arithmetic and the bias FMAs — not by its 5 MFMAs).
+        // one conv1 tile: five fragments from the band image (kernel rows 0..4 of this lane's window, half h), five MFMAs (the bias is the first one's C
+        // operand), ReLU + fp16, three 8-byte writes into the ring (couts 8 qd + 4 h .. + 3, qd = 0..2: 24 channels)
+        // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel (v_permlane32_swap_b32)
+        // to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and its selects cost more than the conflict.
+        // Requesting the next tile's fragments right behind this tile's MFMAs was measured too: the oldest wave of a SIMD finishes 5 % earlier, the phase —
+        // which ends with the youngest — not at all: head 76.0 us against 75.9.)
+        auto conv1_tile = [&](unsigned rd, bool mine, unsigned dst_off) {
+            u4v xv[5];                                                      // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
+#pragma unroll
+            for (int s6 = 0; s6 < 5; ++s6) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(psmem + (rd + (unsigned)(s6 * bpitch * 2)));
+                xv[s6] = u4v{src[0], src[1], src[2], src[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);                              // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[0]), __builtin_bit_cast(h16x8, xv[0]), bias16, 0, 0, 0);
+#pragma unroll
+            for (int s6 = 1; s6 < 5; ++s6)                                  // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
+            if (mine) {
+                uint2* dst = reinterpret_cast<uint2*>(tile1 + dst_off);
+#pragma unroll
+                for (int qd = 0; qd < 3; ++qd) dst[2 * qd + h] = relu_pack4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+            }
+        };
+        if (c1_fast && skip == 3) {
+            // a band after the first of its frame (rolling): 2 R2 new rows, the same geometry for every such band — this lane's windows and columns were
+            // worked out once (c1s), only the ring slot of its row moves with the band
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (wave_u + i * nwaves < ntile1) {                         // (wave-uniform)
+                    const int ppi = (int)(c1s[i].pk & 1023u), yli = (int)((c1s[i].pk >> 10) & 15u);
+                    int slot1 = s0 + 3 + yli;                                // (< 2 NR)
+                    slot1 = slot1 >= NR ? slot1 - NR : slot1;
+                    conv1_tile(c1s[i].ra, ppi < npx1, (unsigned)__mul24(slot1, tile_pitch) + (c1s[i].pk >> 14));
+                }
+            }
+        } else {
+            // the general walk (a frame's first band, bands cut in width, one band per item): a lane walks its pixels p = 32 t1 + r, t1 = wave, wave + 16, ...
+            // incrementally: (row yl, column x), the LDS address of its window in the band image and its ring slot in the tile advance by wave-uniform steps
+            // with one wrap
             const int step = nwaves * 32;
             const int adv_y = (int)__umulhi((unsigned)step, magic), adv_x = step - adv_y * w1;          // step = adv_y rows + adv_x columns
             const int adv_slot = adv_y % NR;
@@ -993,58 +1036,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             const unsigned ra_step = (unsigned)(adv_y * 2 * bpitch + adv_x * 6) * 2u, ra_wrap = (unsigned)(2 * bpitch - w1 * 6) * 2u;
             int slot1 = s0 + skip + yl;                                      // (< 2 NR)
             slot1 = slot1 >= NR ? slot1 - NR : slot1;
-            // (Requesting the next tile's fragments right behind this tile's MFMAs, so that they land during its epilogue, was measured in round 4: the
-            // oldest wave of a SIMD finishes 5 % earlier, the phase — which ends with the youngest — not at all: head 76.0 us against 75.9.)
             for (int t1 = wave_u; t1 < ntile1; t1 += nwaves) {
-                BAND_STAMP2(5);                                             // (stamps level 2) loop overhead since the last tile's writes
-                const unsigned rd = min(ra, ra_last);
-                u4v xv[5];                                                  // every fragment of the tile first: one LDS round trip, then the MFMAs back to back
-#if TRS_C1_ABLATE == 1
-                if (t1 == wave_u)
-#endif
-#pragma unroll
-                for (int s6 = 0; s6 < 5; ++s6) {
-                    const unsigned* src = reinterpret_cast<const unsigned*>(psmem + (rd + (unsigned)(s6 * bpitch * 2)));
-                    xv[s6] = u4v{src[0], src[1], src[2], src[3]};
-                }
-#if TRS_C1_ABLATE == 1
-                else {
-#pragma unroll
-                    for (int s6 = 0; s6 < 5; ++s6) { xv[s6] = u4v{rd, rd, rd, rd}; asm volatile("" : "+v"(xv[s6])); }
-                }
-#endif
-                __builtin_amdgcn_sched_barrier(0);                          // (left alone, hipcc interleaves the reads with the MFMAs two deep to save registers)
-                BAND_STAMP2(6);                                             // address + the ten reads issued (the stamp waits for them)
-#if TRS_C1_ABLATE == 3
-                f32x16 acc = bias16;
-#pragma unroll
-                for (int s6 = 0; s6 < 5; ++s6) asm volatile("" : "+v"(acc) : "v"(xv[s6]), "v"(wv[s6]));
-#else
-                f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[0]), __builtin_bit_cast(h16x8, xv[0]), bias16, 0, 0, 0);
-#pragma unroll
-                for (int s6 = 1; s6 < 5; ++s6)                              // (the sixth k-step of the padded weight layout is all zeros: skipped, + 0 changes nothing)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
-#endif
-#if TRS_BAND_STAMPS == 2
-                { const int done_ = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0])); asm volatile("" :: "s"(done_)); }
-#endif
-                BAND_STAMP2(7);                                             // the five MFMAs complete
-                if (pp < npx1) {                                            // this lane's pixel: couts 8 qd + 4 h .. + 3, qd = 0..2 (24 channels)
-                    // (8-byte writes: the two column planes share bank groups, a 2-way conflict.  Swapping halves between the two lanes of a pixel
-                    // (v_permlane32_swap_b32) to write whole 16-byte granules was measured: head 100.7 -> 103.5 us on one box — the exchange and
-                    // its selects cost more than the conflict)
-                    uint2* dst = reinterpret_cast<uint2*>(tile1 + (unsigned)(__mul24(slot1, tile_pitch) + ((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)));
-#pragma unroll
-                    for (int qd = 0; qd < 3; ++qd) {
-                        const uint2 v = relu_pack4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
-#if TRS_C1_ABLATE == 2
-                        asm volatile("" :: "v"(v), "v"(dst));
-#else
-                        dst[2 * qd + h] = v;
-#endif
-                    }
-                }
-                BAND_STAMP2(8);                                             // epilogue + the writes issued (the stamp waits for them)
+                conv1_tile(min(ra, ra_last), pp < npx1, (unsigned)(__mul24(slot1, tile_pitch) + ((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)));
                 pp += step; x += adv_x; slot1 += adv_slot; ra += ra_step;
                 if (x >= w1) { x -= w1; slot1 += 1; ra += ra_wrap; }
                 slot1 = slot1 >= NR ? slot1 - NR : slot1;
@@ -1184,11 +1177,6 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3 || wave == 8))
         printf("band head, workgroup 7, wave %d, %d items [clocks]: conv1 tiles %lld | barrier %lld | conv2 K loop %lld | conv2 stores (loaders: phase 2) %lld | barrier %lld\n",
                wave, total, st_[0], st_[1], st_[2], st_[3], st_[4]);
-#if TRS_BAND_STAMPS == 2
-    if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3 || wave == 8 || wave == 12))
-        printf("  conv1 tile loop, wave %d: loop overhead %lld | address + reads %lld | MFMAs %lld | epilogue + writes %lld | (rest, in 'conv1 tiles' above) %lld\n",
-               wave, st_[5], st_[6], st_[7], st_[8], st_[0]);
-#endif
 #endif
 }
 
