@@ -322,6 +322,33 @@ def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
         assert np.max(np.abs(fused_out - plain_out)) <= 2e-3
 
 
+def test_fused_head_conv1_beyond_the_fp16_range(make_env):
+    """The fused head's conv1 epilogue skips the saturation step when |bias| + sum |w| < 65504 for every channel (checked when the weights are
+    loaded: its inputs are pixels / 256 <= 1).  With conv1's kernel scaled by 3e5 that bound fails: the saturating epilogue runs, conv1's
+    activation sits at 65504 where the sums overflow — and the fused head still agrees with the two separate layers (which always saturate);
+    everything stays finite."""
+    h, w, n = 120, 160, 5
+    ws = make_weights(h, w, seed=29)
+    ws[0] = ws[0] * np.float32(3e5)
+    ws[2] = ws[2] * np.float32(1e-5)                                     # conv2 brings the signal back into range
+    rng = np.random.default_rng(31)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    oh1, ow1 = (h - 5) // 2 + 1, (w - 5) // 2 + 1
+    oh2, ow2 = (oh1 - 5) // 2 + 1, (ow1 - 5) // 2 + 1
+    res = {}
+    for no_fuse in (0, 1):
+        env = make_env("hip", n_envs=n, img_h=h, img_w=w, auto_reset=True)
+        env.pilot_tuning(no_fuse=no_fuse)
+        env.pilot_load(ws)
+        out = env.pilot_forward_host(frames)
+        res[no_fuse] = (out, env.pilot_layer(1, (n, oh2, ow2, 32)), env.pilot_layer(0, (n, oh1, ow1, 24)))
+    assert np.isfinite(res[0][0]).all() and np.isfinite(res[0][1]).all()
+    assert res[1][2].max() == 65504.0                                    # conv1 saturates with these weights
+    diff = np.abs(res[0][1] - res[1][1])
+    assert (diff <= 2.0 ** -9 * np.abs(res[1][1]) + 1e-2).all(), float(diff.max())
+    assert np.abs(res[1][1]).max() > 0.1
+
+
 @pytest.mark.parametrize("size,n", [((120, 160), 300), ((240, 320), 150), ((130, 300), 131)])
 def test_fused_head_rolling_bands_are_bit_identical_to_one_band_per_item(make_env, size, n):
     """Round 3: with a (frame, part) stream per CU or more, a workgroup of the band-form head walks a frame's bands top to bottom and keeps

@@ -108,6 +108,14 @@ __device__ __forceinline__ uint2 relu_pack4(float v0, float v1, float v2, float 
 {
     return make_uint2(relu_h16x2(pack_h16x2(v0, v1)), relu_h16x2(pack_h16x2(v2, v3)));
 }
+// ... without the saturation, for sums that provably stay inside binary16 (conv1 of the fused head: |bias| + sum |w| < 65504 is checked when the weights
+// are loaded — its inputs are pixels / 256 <= 1)
+__device__ __forceinline__ uint2 relu_pack4_bounded(float v0, float v1, float v2, float v3)
+{
+    const s16x2 z = {0, 0};
+    return make_uint2(__builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_h16x2(v0, v1)), z)),
+                      __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_h16x2(v2, v3)), z)));
+}
 
 // The epilogues' half exchange.  Register quad q of a 32x32 accumulator block holds channels 8q + 4h .. + 3 of pixel r in lane (r, h): the two lanes of a
 // pixel hold the two halves of every 8-channel group.  So that each lane stores whole 16-byte groups — lane h = 0 groups 0 and 1, lane h = 1 groups 2
@@ -800,6 +808,7 @@ struct Fuse12Params {
     int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as fp16 [rows][IW * 3]
     int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
     int roll;                                               // band kernel: a workgroup walks the bands of a (frame, part) top to bottom and keeps the 3 shared conv1 rows (see the kernel)
+    int c1_bounded;                                         // conv1's sums provably stay inside binary16 (|bias| + sum |w| < 65504, pixels / 256 <= 1): its epilogue skips the saturation
     unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
 };
 
@@ -1005,8 +1014,13 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, wv[s6]), __builtin_bit_cast(h16x8, xv[s6]), acc, 0, 0, 0);
             if (mine) {
                 uint2* dst = reinterpret_cast<uint2*>(tile1 + dst_off);
+                if (q.c1_bounded) {                                         // (wave-uniform: conv1 cannot leave binary16's range with these weights — no saturation step)
 #pragma unroll
-                for (int qd = 0; qd < 3; ++qd) dst[2 * qd + h] = relu_pack4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+                    for (int qd = 0; qd < 3; ++qd) dst[2 * qd + h] = relu_pack4_bounded(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+                } else {
+#pragma unroll
+                    for (int qd = 0; qd < 3; ++qd) dst[2 * qd + h] = relu_pack4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+                }
             }
         };
         if (c1_fast && skip == 3) {
@@ -2127,6 +2141,17 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         q.c2 = ConvParams{};
         q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1; q.c2.oscale = 1.0f;
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
+        {   // can conv1 leave binary16's range?  Its inputs are pixels / 256 <= 1, so |output| <= |bias| + sum |w| (x 256 / 255 and the binary16 rounding of the
+            // weights: 1.01 covers both).  Below 65504 for every output channel the fused head's conv1 epilogue needs no saturation step.
+            const float* K0 = arr[0]; const float* B0 = arr[1];
+            double worst = 0.0;
+            for (int co = 0; co < l0.COUT; ++co) {
+                double sum = std::fabs((double)B0[co]);
+                for (int k = 0; k < l0.KH * l0.KW * l0.CIN; ++k) sum += std::fabs((double)K0[(size_t)k * l0.COUT + co]) * 1.01;
+                worst = std::max(worst, sum);
+            }
+            q.c1_bounded = (worst == worst && worst < 60000.0) ? 1 : 0;      // (NaN weights: not bounded)
+        }
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.COUT == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
         c->fuse12 = false; c->no_fuse = T.no_fuse != 0;
