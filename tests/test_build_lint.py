@@ -22,7 +22,7 @@ KNOWN_PACKED = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_pk_mov_b32"}
 # 16-bit packed forms keep both halves in ONE 32-bit register: in place is half-for-half unless op_sel / op_sel_hi swap the halves
 KNOWN_PACKED_16 = {"v_pk_max_i16", "v_pk_min_i16", "v_pk_sub_i16",     # (v_pk_sub_i16: the Canny suppression compares two magnitudes per instruction; v_pk_min_i16: the fp16 activations saturate at 65504)
                    "v_pk_add_u16", "v_pk_add_i16", "v_pk_lshlrev_b16", "v_pk_ashrrev_i16", "v_pk_mad_i16", "v_pk_mad_u16", "v_pk_mul_lo_u16",    # the Canny Sobel on packed int16 (round 3)
-                   "v_pk_mul_f16"}   # the fused head stages its pixels as x / 256: one packed multiply per pair in the loader waves (round 4)
+                   "v_pk_mul_f16", "v_pk_add_f16", "v_pk_min_u16"}   # the fused head stages its pixels as x / 256: a byte permute into the mantissas of (4.0, 4.0) and one packed subtract per pair (round 4)
 
 
 def swapped_halves_in_place_16(line):

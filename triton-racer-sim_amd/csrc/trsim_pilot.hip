@@ -848,6 +848,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(q.frames), 0, q.frames_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout2 = __builtin_amdgcn_make_buffer_rsrc(static_cast<unsigned char*>(q.c2.out), 0, q.c2.M * 64, 0x00020000);   // conv2's activation: 32 couts
     const float inv_ow2 = 1.0f / (float)q.OW2;
+    constexpr bool kC2NtIsOne = TRS_C2_NT == 1;
     const int row_in = q.IW * 3;                                            // bytes per frame row
     const int bpitch = SPLIT ? q.cpr * 16 : row_in;                         // values per row of the band image
     auto divmod = [](int v, int d, float inv, int& qt, int& rm) {
@@ -921,11 +922,16 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         for (int j = 0; j < 2 * kBandPf; ++j) {
             const int hc = (tid - 512) + j * 512;
             if (hc * 16 + 16 > q.band_bytes) continue;
-            auto pair = [](unsigned w, int k) -> unsigned {                  // two pixels as x / 256 in binary16 (exact: 0, 2^-8 .. 255 x 2^-8)
-                const float f0 = (float)((w >> (8 * k)) & 255u), f1 = (float)((w >> (8 * k + 8)) & 255u);
+            // two pixels as x / 256 in binary16 (exact: 0, 2^-8 .. 255 x 2^-8) in TWO instructions: binary16's 4.0 (0x4400) has an ulp of 2^-8, so
+            // 0x4400 | x IS 4 + x / 256; a byte permute drops the two bytes into the mantissas of (4.0, 4.0) and one packed subtract takes the 4.0 away
+            // (until round 4: v_cvt_f32_ubyte x 2, v_cvt_pkrtz, v_pk_mul_f16 — the loader waves share their SIMDs with the conv2 waves, and every
+            // vector instruction there is time the MFMAs do not get, profiles/r04_mfma_issue.txt)
+            auto pair = [](unsigned w, int k) -> unsigned {
                 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-                const h16x2 scale = {(_Float16)kConv1Scale, (_Float16)kConv1Scale};
-                return __builtin_bit_cast(unsigned, __builtin_bit_cast(h16x2, u8pair_h16(f0, f1)) * scale);   // one v_pk_mul_f16 per pair
+                const unsigned sel = k == 0 ? 0x05010500u : 0x05030502u;     // result bytes, low to high: w.byte[k], 0x44, w.byte[k + 1], 0x44 (sources 0..3 = w, 4..7 = the magic)
+                const unsigned m = __builtin_amdgcn_perm(0x44004400u, w, sel);   // = the halves 0x4400 | w.byte[k], 0x4400 | w.byte[k + 1]
+                const h16x2 four = {(_Float16)4.0f, (_Float16)4.0f};
+                return __builtin_bit_cast(unsigned, __builtin_bit_cast(h16x2, m) - four);
             };
             *reinterpret_cast<u4v*>(band + (size_t)hc * 16) = u4v{pair(raw[j].x, 0), pair(raw[j].x, 2), pair(raw[j].y, 0), pair(raw[j].y, 2)};
         }
@@ -969,6 +975,18 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     asm volatile("" : "+v"(bias16));
     // the rolling bands of whole-width frames share one conv1 geometry (2 R2 new rows of OW1 pixels: at most two tiles per wave): this lane's
     // window address in the band image, its column's offset in a ring row, and (pixel index | row << 16) for the tiles wave and wave + 16
+    // ... and so do their conv2 tiles (one per wave, kC2Nt = 1): the tile pixel's column address in a ring row, and (row << 24 | byte offset of its 32 output
+    // bytes relative to the band's first output pixel); a lane past a full band's last pixel takes that pixel (never stored)
+    const bool c2_fast = !SPLIT && kC2NtIsOne && (q.R2 * q.OW2 + 31) / 32 <= 8 && q.R2 * q.OW2 * 64 < (1 << 24);
+    unsigned c2s_abase = 0, c2s_rel = 0;
+    if (c2_fast) {
+        const int mm = min(wave_u * 32 + r, q.R2 * q.OW2 - 1);
+        const int yl2 = (int)(((float)mm + 0.5f) * inv_ow2);
+        int yq = yl2, x2 = mm - yl2 * q.OW2;
+        if (x2 < 0) { --yq; x2 += q.OW2; } else if (x2 >= q.OW2) { ++yq; x2 -= q.OW2; }
+        c2s_abase = (unsigned)q.off_tile + (unsigned)__mul24(x2, 48);
+        c2s_rel = ((unsigned)yq << 24) | (unsigned)((__mul24(yq, q.OW2) + x2) * 64 + 32 * h);
+    }
     struct C1Slot { unsigned ra, pk; };                                     // pk = pixel index (10 bits) | row (4 bits) | column offset in a ring row (the rest)
     C1Slot c1s[2];
     const bool c1_fast = !SPLIT && q.roll && (2 * q.R2 * q.OW1 + 31) / 32 <= 2 * nwaves && 2 * q.R2 < 16 && 2 * nwaves * 32 <= 1024;
@@ -1104,12 +1122,19 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
                 unsigned abase[kC2Nt]; int trow[kC2Nt], moff[kC2Nt];
 #pragma unroll
                 for (int j = 0; j < kC2Nt; ++j) {
-                    const int px = (kC2Nt * tp + j) * 32 + r, mm = min(px, npx2 - 1);   // (lanes past the band's last pixel compute it again: never stored)
-                    int yl2, x2;
-                    divmod(mm, w2, inv_w2, yl2, x2);
-                    abase[j] = (unsigned)q.off_tile + (unsigned)__mul24(x2, 48);   // even plane, pixel x2
-                    trow[j] = s0 + 2 * yl2;                                  // ring slot of conv1 row 2 yl2 + kh: trow + kh (mod NR)
-                    moff[j] = px < npx2 ? ((m0 + __mul24(yl2, q.OW2) + x2) * 32 + 16 * h) * 2 : -1;   // this lane's 32 bytes of the pixel in conv2's activation
+                    const int px = (kC2Nt * tp + j) * 32 + r;
+                    if (c2_fast) {                                           // (uniform) whole-width band, one tile per wave: this lane's (row, column) were worked out once
+                        abase[j] = c2s_abase;
+                        trow[j] = s0 + 2 * (int)(c2s_rel >> 24);
+                        moff[j] = px < npx2 ? m0 * 64 + (int)(c2s_rel & 0xFFFFFFu) : -1;
+                    } else {
+                        const int mm = min(px, npx2 - 1);                    // (lanes past the band's last pixel compute it again: never stored)
+                        int yl2, x2;
+                        divmod(mm, w2, inv_w2, yl2, x2);
+                        abase[j] = (unsigned)q.off_tile + (unsigned)__mul24(x2, 48);   // even plane, pixel x2
+                        trow[j] = s0 + 2 * yl2;                              // ring slot of conv1 row 2 yl2 + kh: trow + kh (mod NR)
+                        moff[j] = px < npx2 ? ((m0 + __mul24(yl2, q.OW2) + x2) * 32 + 16 * h) * 2 : -1;   // this lane's 32 bytes of the pixel in conv2's activation
+                    }
                 }
                 // the accumulators start at conv2's bias: register 4 qd + j = cout 8 qd + 4 h + j (read once per item, under the first fragments' latency)
                 f32x16 acc2[kC2Nt];
