@@ -162,6 +162,7 @@ struct FrameConvParams {
     int F, cg, cgs;            // units (frames, or row bands of frames) per workgroup; granules per pixel (8 / 16) and log2 of it
     int bands, ohb, ihb;       // a frame whose activation does not fit LDS is cut into `bands` bands of ohb output rows = ohb + KH - 1 input rows
     int relu;                  // (neighbouring bands re-stage KH - 1 rows); bands == 1: ohb = OH, ihb = IH
+    unsigned magic_uout, magic_ow, magic_bands;   // floor(p / d) = umulhi(p, ceil(2^32 / d)), exact for p < 2^32 / d: d = ohb x OW, OW, bands (an item's set-up without divisions)
 };
 // weight prefetch: a register ring of R k-steps (R x NB granules per lane), refilled slot by slot right behind the MFMAs that
 // consumed the slot: R x NT x NB x 32 MFMA clocks of lead time against an L2 round trip of 500-800 (R = 4: one tap at 64 input
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(64 * (COMPUTE + LOADERS), 1) void trs_conv_frame_ke
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-                    const int ul = mc / uout, rem = mc - ul * uout, oyl = rem / p.OW, ox = rem - oyl * p.OW;
-                    const int u = u0 + ul, f = u / p.bands, oy = (u - f * p.bands) * p.ohb + oyl;
+                    const int ul = (int)__umulhi((unsigned)mc, p.magic_uout), rem = mc - ul * uout, oyl = (int)__umulhi((unsigned)rem, p.magic_ow), ox = rem - oyl * p.OW;
+                    const int u = u0 + ul, f = p.magic_bands ? (int)__umulhi((unsigned)u, p.magic_bands) : u, oy = (u - f * p.bands) * p.ohb + oyl;   // (magic 0: one band per frame)
                     lbase[nt] = (ul * p.ihb + oyl) * p.IW + ox;
                     obase[nt] = (m < m_wg && oy < p.OH) ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
                 }
@@ -381,6 +382,8 @@ struct ChainLayer {
     const u4v* w; const float* bias;
     int IH, IW, OH, OW, COUT, cg, cgs;     // COUT == COUT_PAD (64 / 128); cg = input granules per pixel (8 / 16), cgs = log2
     int nt, nb;                            // a wave item = nt x 32 pixels x nb x 32 channels (nt 2 / 3, nb 1 / 2): the choice that leaves the busiest SIMD the fewest MFMAs
+    unsigned magic_uout, magic_ow;         // floor(p / (OH x OW)) = umulhi(p, magic_uout), floor(p / OW) = umulhi(p, magic_ow) for p < 65536 (an item's set-up: four divisions
+                                           // per tile cost ~100 vector instructions per item — a K loop is 36 k-steps of ~25)
 };
 struct ChainParams {
     const u4v* in;             // the first layer's input activation, fp16 NHWC
@@ -413,7 +416,7 @@ __device__ __forceinline__ void chain_layer(const ChainLayer& L, const u4v* lin,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int m = tile * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-            const int ul = mc / uout, rem = mc - ul * uout, oy = rem / L.OW, ox = rem - oy * L.OW;
+            const int ul = (int)__umulhi((unsigned)mc, L.magic_uout), rem = mc - ul * uout, oy = (int)__umulhi((unsigned)rem, L.magic_ow), ox = rem - oy * L.OW;
             lbase[nt] = (ul * L.IH + oy) * L.IW + ox;
             mo[nt] = m < m_wg ? m : -1;
         }
@@ -600,6 +603,7 @@ struct Frame5Params {
     unsigned short* out;       // fp16 NHWC [N][OH][OW][64]
     int N, IH, IW, OH, OW, F, ev, COUT;   // ev = even columns per row = (IW + 1) / 2
     int bands, ohb, ihb;                  // a frame that does not fit LDS is cut into `bands` bands of ohb output rows = ihb = 2 ohb + 3 input rows (bands == 1: ohb = OH, ihb = IH)
+    unsigned magic_ow;                    // floor(p / OW) = umulhi(p, magic_ow)
 };
 
 // Round 4: the workgroup is persistent and double-buffered.  Until then a 4-wave workgroup took ONE unit (two workgroups per CU, "one stages
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int m = item * NT * 32 + nt * 32 + r, mc = min(m, m_wg - 1);
-                    const int oyl = mc / p.OW, ox = mc - oyl * p.OW;
+                    const int oyl = (int)__umulhi((unsigned)mc, p.magic_ow), ox = mc - oyl * p.OW;
                     const int oy = band * p.ohb + oyl;
                     lbase[nt] = 2 * oyl * p.IW + ox;                        // slot of input pixel (2 oyl, 2 ox) of the unit: even plane, position ox
                     mo[nt] = m < m_wg ? ((long long)f * p.OH + oy) * p.OW + ox : -1;
@@ -1732,6 +1736,7 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.in = static_cast<const u4v*>(in); q.w = l.w; q.bias = l.bias; q.out = static_cast<unsigned short*>(out);
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.F = 1; q.ev = (l.IW + 1) / 2; q.COUT = l.COUT;
         q.bands = l.frame5_bands; q.ohb = l.frame5_ohb; q.ihb = l.frame5_bands == 1 ? l.IH : 2 * l.frame5_ohb + 3;
+        q.magic_ow = (unsigned)((0x100000000ull + (unsigned)l.OW - 1u) / (unsigned)l.OW);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_frame5_kernel<2, TRS_F5_NB, TRS_F5_R, 64 * (TRS_F5_COMPUTE + 4), TRS_F5_COMPUTE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((trs_conv_frame5_kernel<2, TRS_F5_NB, TRS_F5_R, 64 * (TRS_F5_COMPUTE + 4), TRS_F5_COMPUTE>), dim3(std::min(n_img * q.bands, cu_count)), dim3(64 * (TRS_F5_COMPUTE + 4)), l.frame5_lds, s, q);
         HIPCHK(hipGetLastError());
@@ -1743,6 +1748,8 @@ int launch_conv(const ConvLayer& l, const void* in, size_t in_bytes, void* out, 
         q.N = n_img; q.IH = l.IH; q.IW = l.IW; q.OH = l.OH; q.OW = l.OW; q.COUT = l.COUT; q.COUT_PAD = l.COUT_PAD; q.KH = l.KH; q.KW = l.KW;
         q.F = l.frame_f; q.cg = l.CIN / 8; q.cgs = q.cg == 8 ? 3 : 4; q.relu = l.relu;
         q.bands = l.frame_bands; q.ohb = l.frame_ohb; q.ihb = l.frame_ohb + l.KH - 1;
+        { auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d); };
+          q.magic_uout = magic(q.ohb * q.OW); q.magic_ow = magic(q.OW); q.magic_bands = q.bands == 1 ? 0u : magic(q.bands); }
         const int groups = (n_img * q.bands + q.F - 1) / q.F, grid = std::min(groups, cu_count);   // one persistent workgroup per CU
 #define LAUNCH_FRAME(NT_, HALF_)                                                                                              \
     do {                                                                                                                      \
@@ -2287,7 +2294,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                         const int m = busiest(cnt, 2, wv);
                         if (m < best || (m == best && wv > best_waves)) { best = m; best_waves = wv; nt = cnt; }
                     }
-                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, 2};
+                    auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d); };
+                    q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, 2, magic(l.OH * l.OW), magic(l.OW)};
                 }
                 c->chain_first = first; c->chain_lds = (int)total;
             }
