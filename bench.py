@@ -42,6 +42,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 PREWARM_S = 0.08               # untimed steps of the same workload before the W warm-up steps: GPU clocks at their loaded level
 
 
+# What v_mfma_f32_32x32x16_f16 delivers on this chip when all 1,024 SIMDs stream it from registers (scripts/mfma_issue.hip, profiles/r04_mfma_issue.txt:
+# 32 clocks per MFMA at the ~1.65 GHz the chip sustains under that load).  The roofline's `peak` stays the data sheet's 2.5 PFLOP/s; this is reported beside it.
+MEASURED_MFMA_TFLOPS = 1729.0
+
 def algorithmic_bytes(h, w, render, depth=False):
     # H*W*3 image bytes written once (+ H*W*4 of fp32 depth) + 88 B of state / control / telemetry per env-step
     return (h * w * 3 if render else 0) + (h * w * 4 if render and depth else 0) + 88
@@ -541,7 +545,7 @@ def main():
             ms_p = env.event_elapsed_ms(2, 3)
             ptf = 2.0 * pmacs * n * psteps / (ms_p * 1e-3) / 1e12
             pilot_leg = {"env_steps_per_s": round(n * psteps / (ms_p * 1e-3), 1), "us_per_step": round(ms_p * 1e3 / psteps, 3), "tflops_fp16": round(ptf, 1),
-                         "frac_of_mfma_peak": round(ptf / 2500.0, 5),
+                         "frac_of_mfma_peak": round(ptf / 2500.0, 5), "frac_of_measured_mfma_ceiling": round(ptf / MEASURED_MFMA_TFLOPS, 5),
                          "note": "trs_step_pilot: env step + cnn_2d_speed_control forward (fp16 MFMA convolutions, fp32 accumulate, fp32 tail) + KerasPilot.step per step, random-init weights; "
                                  "device time by HIP events; `python bench.py --pilot` reports this loop as the main line"}
         except Exception as exc:                                    # the leg is informational: never lose the main line to it
@@ -563,7 +567,7 @@ def main():
                 ms5 = env5.event_elapsed_ms(0, 1)
                 tf5 = 2.0 * macs5 * 512 * 60 / (ms5 * 1e-3) / 1e12
                 pilot5_leg = {"env_steps_per_s": round(512 * 60 / (ms5 * 1e-3), 1), "us_per_step": round(ms5 * 1e3 / 60, 3), "tflops_fp16": round(tf5, 1),
-                              "frac_of_mfma_peak": round(tf5 / 2500.0, 5),
+                              "frac_of_mfma_peak": round(tf5 / 2500.0, 5), "frac_of_measured_mfma_ceiling": round(tf5 / MEASURED_MFMA_TFLOPS, 5),
                               "note": "512 envs x 240x320 RGB + fp32 depth + cnn_2d_speed_control in the loop = one GPU's share of BASELINE configs[4]; device time by HIP events"}
                 env5.close()
             except Exception as exc:
@@ -701,7 +705,8 @@ def main():
             line["config"]["workload"] += " + cnn_2d_speed_control inference in the loop (random-init weights, closed loop)"
             line["dtype"] += " / fp16 MFMA convolutions, f32 accumulate"
             line["roofline"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 5),
-                                "traffic": None, "kernel": "per step: trs_step_kernel + trs_conv12_band_kernel (conv1 + conv2 fused) + trs_conv_frame5_kernel (conv3) + trs_conv_chain_kernel (conv4..7 in one launch) + trs_pilot_dense_kernel (dense1) + trs_pilot_tail_kernel at 120x160; frames too large for LDS: trs_conv_span_kernel (conv3) and one trs_conv_frame_kernel launch per 3x3 layer",
+                                "measured_ceiling": MEASURED_MFMA_TFLOPS, "frac_of_measured_ceiling": round(tf / MEASURED_MFMA_TFLOPS, 5),
+                                "traffic": None, "kernel": "per step: trs_step_kernel + trs_conv12_band_kernel (conv1 + conv2 fused) + trs_conv_frame5_kernel (conv3) + trs_conv_chain_kernel (conv4..7 in one launch) + trs_pilot_dense_kernel (dense1) + trs_pilot_tail_kernel at 120x160; frames too large for LDS: trs_conv_frame5_kernel on row bands (conv3) and one trs_conv_frame_kernel launch per 3x3 layer",
                                 "flops_per_frame": pilot_flops, "avg_step_us": round(kernel_ms * 1e3 / args.steps, 3),
                                 "note": "whole closed-loop step by HIP events; per-layer times in profiles/r04_pilot_layers.txt"}
         line["config"]["launcher"] = launcher          # "self": python bench.py --gpus N started the ranks (launch_ranks); "torch.distributed.run"; "external"
