@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-layer kernel times of the pilot loop (rocprofv3 kernel trace); extra args go to bench.py; env TRS_PILOT_WAVES tunes waves/CU
+# per-layer kernel times of the pilot loop (rocprofv3 kernel trace); extra args go to bench.py; TRS_HIP_LIB picks another build of the library, PL_TAG names the output
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 tag=${PL_TAG:-run}

@@ -11,7 +11,7 @@ if [ "$1" = prepare ]; then
 fi
 C=triton-racer-sim_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -ffp-contract=off -fno-fast-math"
-/opt/rocm/bin/hipcc $FLAGS -I. -o /tmp/libtrsim_new.so $C/trsim_hip.hip $C/trsim_pilot.hip $C/trsim_tables.cpp 2>/dev/null &
+/opt/rocm/bin/hipcc $FLAGS -I. -o /tmp/libtrsim_new.so $C/trsim_hip.hip $C/trsim_resident.hip $C/trsim_comm.hip $C/trsim_pilot.hip $C/trsim_tables.cpp -ldl -Iinclude 2>/dev/null &
 ( cd scripts/ab_old && /opt/rocm/bin/hipcc $FLAGS -o /tmp/libtrsim_old.so trsim_hip.hip trsim_pilot.hip trsim_tables.cpp 2>/dev/null ) &
 wait
 run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']/1e6,2), 'M', d['ms_per_step']*1e3, 'us', d['roofline']['frac'])"; }
