@@ -283,7 +283,7 @@ def test_closed_loop_is_unaffected_by_another_stream(make_env):
 @pytest.mark.parametrize("size,wsplit", [((120, 160), None), ((240, 320), None), ((240, 320), 1), ((100, 132), None), ((130, 300), None)])
 def test_fused_head_equals_the_two_layers(make_env, size, wsplit):
     """conv1 -> conv2 fused (conv1's activation stays in LDS; trs_conv12_band_kernel) against the two separate kernels (trs_pilot_tuning.no_fuse).
-    The band form (120x160; 240x320 and 130x300 cut in two parts of conv2 columns, the last part narrower) keeps the conv1 tile
+    The band form (120x160; 240x320 and 130x300 cut in two parts of conv2 columns of equal width, the last one overlapping its neighbour) keeps the conv1 tile
     split by column parity and takes conv2's k dimension in that order (even columns, then odd): the same products in another
     summation order, so an output can land on the neighbouring fp16 value — at most one ulp (2^-10 relative), on a small fraction
     of the elements.  240x320 with fuse_wsplit_max = 1 (a band may not be cut in width, and a whole-width band does not fit LDS): the
@@ -354,7 +354,7 @@ def test_fused_head_rolling_bands_are_bit_identical_to_one_band_per_item(make_en
     """Round 3: with a (frame, part) stream per CU or more, a workgroup of the band-form head walks a frame's bands top to bottom and keeps
     the three conv1 rows two neighbouring bands share in a ring (trs_pilot_tuning.fuse_roll, the default) instead of computing them
     twice.  Same values into the same MFMAs: conv2's activation and the model's outputs must equal the one-band-per-item order bit for
-    bit — whole streams per workgroup and a ragged last round (n not a multiple of the CU count), the width-split form, a narrow last part."""
+    bit — whole streams per workgroup and a ragged last round (n not a multiple of the CU count), the width-split form (equal parts since round 4: the last one overlaps its neighbour)."""
     h, w = size
     ws = make_weights(h, w, seed=5)
     rng = np.random.default_rng(12)

@@ -813,7 +813,7 @@ struct Fuse12Params {
     int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
     int roll;                                               // band kernel: a workgroup walks the bands of a (frame, part) top to bottom and keeps the 3 shared conv1 rows (see the kernel)
     int c1_bounded;                                         // conv1's sums provably stay inside binary16 (|bias| + sum |w| < 65504, pixels / 256 <= 1): its epilogue skips the saturation
-    unsigned magic_full, magic_last, magic_cpr;             // floor(p / w1) = umulhi(p, magic) for a full part's / the last part's conv1 width; the same for / cpr
+    unsigned magic_full, magic_cpr;                         // floor(p / w1) = umulhi(p, magic_full) for a part's conv1 width 2 w2p + 3; the same for / cpr
 };
 
 // The fused head with conv1's input staged once per band.  (Rounds 1-2 had a direct form whose conv1 tiles fetched their windows
@@ -891,7 +891,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             skip = 0;
         }
         y2_0 = b * q.R2;
-        if constexpr (SPLIT) { x2_0 = part * q.w2p; w2 = min(q.w2p, q.OW2 - x2_0); w1 = 2 * w2 + 3; }
+        if constexpr (SPLIT) { x2_0 = min(part * q.w2p, q.OW2 - q.w2p); w2 = q.w2p; w1 = 2 * w2 + 3; }   // every part w2p columns wide: the last one starts where it ends at the frame's edge and
+                                                                                                       // recomputes the column(s) it shares with its neighbour (the same values to the same bytes)
         else { x2_0 = 0; w2 = q.OW2; w1 = q.OW1; }
         r2 = min(q.R2, q.OH2 - y2_0); r1 = 2 * (r2 - 1) + 5;
     };
@@ -981,25 +982,26 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
     // window address in the band image, its column's offset in a ring row, and (pixel index | row << 16) for the tiles wave and wave + 16
     // ... and so do their conv2 tiles (one per wave, kC2Nt = 1): the tile pixel's column address in a ring row, and (row << 24 | byte offset of its 32 output
     // bytes relative to the band's first output pixel); a lane past a full band's last pixel takes that pixel (never stored)
-    const bool c2_fast = !SPLIT && kC2NtIsOne && (q.R2 * q.OW2 + 31) / 32 <= 8 && q.R2 * q.OW2 * 64 < (1 << 24);
+    const int w2c = SPLIT ? q.w2p : q.OW2, w1c = SPLIT ? 2 * q.w2p + 3 : q.OW1;      // conv2 / conv1 columns of an item (the same for every item)
+    const bool c2_fast = kC2NtIsOne && (q.R2 * w2c + 31) / 32 <= 8 && q.R2 * q.OW2 * 64 < (1 << 24);
     unsigned c2s_abase = 0, c2s_rel = 0;
     if (c2_fast) {
-        const int mm = min(wave_u * 32 + r, q.R2 * q.OW2 - 1);
-        const int yl2 = (int)(((float)mm + 0.5f) * inv_ow2);
-        int yq = yl2, x2 = mm - yl2 * q.OW2;
-        if (x2 < 0) { --yq; x2 += q.OW2; } else if (x2 >= q.OW2) { ++yq; x2 -= q.OW2; }
+        const int mm = min(wave_u * 32 + r, q.R2 * w2c - 1);
+        const int yl2 = (int)(((float)mm + 0.5f) * (SPLIT ? 1.0f / (float)w2c : inv_ow2));
+        int yq = yl2, x2 = mm - yl2 * w2c;
+        if (x2 < 0) { --yq; x2 += w2c; } else if (x2 >= w2c) { ++yq; x2 -= w2c; }
         c2s_abase = (unsigned)q.off_tile + (unsigned)__mul24(x2, 48);
         c2s_rel = ((unsigned)yq << 24) | (unsigned)((__mul24(yq, q.OW2) + x2) * 64 + 32 * h);
     }
     struct C1Slot { unsigned ra, pk; };                                     // pk = pixel index (10 bits) | row (4 bits) | column offset in a ring row (the rest)
     C1Slot c1s[2];
-    const bool c1_fast = !SPLIT && q.roll && (2 * q.R2 * q.OW1 + 31) / 32 <= 2 * nwaves && 2 * q.R2 < 16 && 2 * nwaves * 32 <= 1024;
+    const bool c1_fast = q.roll && (2 * q.R2 * w1c + 31) / 32 <= 2 * nwaves && 2 * q.R2 < 16 && 2 * nwaves * 32 <= 1024;
     if (c1_fast) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int pp = (wave_u + i * nwaves) * 32 + r;
-            const int yl = (int)__umulhi((unsigned)pp, magic1), x = pp - yl * q.OW1;
-            c1s[i].ra = (unsigned)q.off_band + 16u * h + (unsigned)(__mul24(2 * yl, row_in) + __mul24(x, 6)) * 2u;   // (past the band's last pixel: still inside the image
+            const int yl = (int)__umulhi((unsigned)pp, SPLIT ? q.magic_full : magic1), x = pp - yl * w1c;
+            c1s[i].ra = (unsigned)q.off_band + 16u * h + (unsigned)(__mul24(2 * yl, bpitch) + __mul24(x, 6)) * 2u;   // (past the band's last pixel: still inside the image
                                                                                                                   // buffer, which is sized for a frame's first band; never stored)
             c1s[i].pk = (unsigned)pp | ((unsigned)yl << 10) | ((unsigned)(((x & 1) ? plane_bytes : 0) + __mul24(x >> 1, 48)) << 14);
         }
@@ -1011,7 +1013,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         const int nxt = wt + 1;                                             // uniform per workgroup
         int n, y2_0, r2, r1, x2_0, w2, w1, skip;
         geometry(wt, n, y2_0, r2, r1, x2_0, w2, w1, skip);
-        const unsigned magic = SPLIT ? (w2 == q.w2p ? q.magic_full : q.magic_last) : magic1;
+        const unsigned magic = SPLIT ? q.magic_full : magic1;
         const int s0 = q.roll ? (2 * y2_0) % NR : 0;                        // ring slot of the band's first conv1 row
         // ---- phase 1: the band's conv1 rows that are not in the tile yet (all of them, or all but the first 3), from the fp16 image ----
         const int rows1 = r1 - skip, npx1 = rows1 * w1, ntile1 = (npx1 + 31) >> 5;
@@ -2207,8 +2209,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         // staged frame-row segments (a part re-stages 2 x 3 + 3 input columns and recomputes 3 conv1 columns of its neighbour)
         const int max_split = T.fuse_wsplit_max;                          // 4; 1 = never cut in width
         for (int ws = 2; shape_ok && !c->fuse12 && band_r2 > 0 && ws <= max_split; ++ws) {
-            const int w2p = (l1.OW + ws - 1) / ws, w2_last = l1.OW - (ws - 1) * w2p, w1m = 2 * w2p + 3, w1_last = 2 * w2_last + 3;
-            if (w2_last < 15 || w1m * 19 >= 65536) continue;
+            const int w2p = (l1.OW + ws - 1) / ws, w1m = 2 * w2p + 3;          // every part w2p conv2 columns wide (the last one overlaps its neighbour)
+            if (w2p < 15 || w2p > l1.OW || w1m * 19 >= 65536) continue;
             const int cpr = ((2 * w1m + 3) * 3 + 15) / 16;
             for (int r2 = std::min(band_r2, l1.OH); r2 >= std::min(4, l1.OH); --r2) {
                 const int rows_in = 2 * (2 * r2 + 3) + 3;
@@ -2224,7 +2226,6 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2;
                 q.wsplit = ws; q.w2p = w2p; q.cpr = cpr;
                 q.magic_full = (unsigned)((0x100000000ull + (unsigned)w1m - 1u) / (unsigned)w1m);
-                q.magic_last = (unsigned)((0x100000000ull + (unsigned)w1_last - 1u) / (unsigned)w1_last);
                 q.magic_cpr = (unsigned)((0x100000000ull + (unsigned)cpr - 1u) / (unsigned)cpr);
                 break;
             }
