@@ -64,7 +64,8 @@ struct FParams {                        // ImgPreprocessing with dynamic brightn
                                         // in-range tests per component value, range_byte_entry) | sel — staged into LDS once per launch (round 4: the
                                         // resident worker's raster waves then issue NO loads in their steady state)
 };
-constexpr int kDynTabWords = 512 + 768 + 4;
+constexpr int kDynTabWords = 512 + 768 + 4 + 256;   // ... | cnt[256]: the class counts of a row's 4-pixel pack (n0 | n1 << 8 | n2 << 16 | n3 << 24; round 4, see raster_dyn_batch phase A)
+constexpr int kDynCntAt = 512 + 768 + 4;
 
 }  // namespace trsim
 
@@ -87,6 +88,7 @@ using trsim::PParams;
 using trsim::RParams;
 using trsim::FParams;
 using trsim::kDynTabWords;
+using trsim::kDynCntAt;
 
 // ---------------------------------------------------------------------------------------------
 // device pieces of the spec
@@ -583,13 +585,23 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, const un
 #define TRS_DYN_ABLATE 0   /* timing-only diagnostic builds (scripts/r04_dyn_ablate.sh), never shipped: 1 no classification in phase A, 2 no filter arithmetic in phase B, 3 no stores in phase C */
 #endif
 constexpr int kDynBatch = 4;
-__host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128 + ((kDynTabWords * 4 + 15) & ~15); }
+__host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128 + ((kDynTabWords * 4 + 15) & ~15) + H * 16; }   // ... + rowch[H]: the raw palette by channel
 // the tables behind the batch's palettes and sums (staged by dyn_stage_tables before the launch's first barrier)
 __device__ __forceinline__ unsigned* dyn_tabs_lds(unsigned char* lds_base, const FParams& f, int H) { return reinterpret_cast<unsigned*>(lds_base + f.lds_off + kDynBatch * H * 16 + 128); }
-__device__ __forceinline__ void dyn_stage_tables(unsigned char* lds_base, const FParams& f, int H, int tid, int nthreads)
+// rowch[v] = the RAW palette of row v by channel: {R of classes 0..3, G of classes 0..3, B of classes 0..3, 0} as packed bytes (behind the tables)
+__device__ __forceinline__ unsigned dyn_rowch_lds(const FParams& f, int H) { return (unsigned)f.lds_off + (unsigned)(kDynBatch * H * 16 + 128 + ((kDynTabWords * 4 + 15) & ~15)); }
+__device__ __forceinline__ void dyn_stage_tables(unsigned char* lds_base, const FParams& f, int H, int tid, int nthreads, const uint32_t* pal_global)
 {
     unsigned* const dst = dyn_tabs_lds(lds_base, f, H);
     for (int i = tid; i < kDynTabWords; i += nthreads) dst[i] = f.tabs[i];
+    uint32_t* const rowch = reinterpret_cast<uint32_t*>(lds_base + dyn_rowch_lds(f, H));
+    for (int v = tid; v < H; v += nthreads) {                              // (the palette itself is still on its way into LDS: read it from memory)
+        const uint32_t c0 = pal_global[4 * v], c1 = pal_global[4 * v + 1], c2 = pal_global[4 * v + 2], c3 = pal_global[4 * v + 3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            rowch[4 * v + ch] = ((c0 >> (8 * ch)) & 255u) | (((c1 >> (8 * ch)) & 255u) << 8) | (((c2 >> (8 * ch)) & 255u) << 16) | (((c3 >> (8 * ch)) & 255u) << 24);
+        rowch[4 * v + 3] = 0u;
+    }
 }
 
 // The team barrier of raster_dyn_batch: a BOUNDED spin.  Every 1024 polls (~30 us) it asks `bail(first)` whether to give up — the resident worker
@@ -639,14 +651,22 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
     };
     // (A) rows outside, envs inside: the (up to) four envs' lookups of one row are independent chains (row table -> map
     // -> palette are three dependent LDS round trips per row, and two waves per SIMD cannot hide them one env at a time)
-    unsigned srb[kDynBatch], sgs[kDynBatch];                          // R | B << 16 and G: <= 24 rows x 4 px x 255 per thread fits 16 bits
+    // The channel sums of a row: sum over the classes k of n_k x (raw colour of class k in this row).  The pack of four 2-bit classes indexes a
+    // 256-entry table of packed counts (n0 .. n3 as bytes), the row's raw palette sits in LDS by channel (rowch: four R bytes, four G bytes, four
+    // B bytes — one 16-byte read per row, shared by the batch's envs and independent of the classification), and one v_dot4_u32_u8 per
+    // channel adds n . colours.  (Until round 4: four dependent palette gathers and four masked adds per env and row — 28 of the ~64 vector
+    // instructions of a row of phase A, which is bound by exactly those.)  Exact integers either way.
+    unsigned ssr[kDynBatch], ssg[kDynBatch], ssb[kDynBatch];
 #pragma unroll
-    for (int bi = 0; bi < kDynBatch; ++bi) { srb[bi] = 0u; sgs[bi] = 0u; }
+    for (int bi = 0; bi < kDynBatch; ++bi) { ssr[bi] = 0u; ssg[bi] = 0u; ssb[bi] = 0u; }
+    const unsigned cnt_a = (unsigned)f.lds_off + (unsigned)(kDynBatch * p.H * 16 + 128 + kDynCntAt * 4);
+    const unsigned rowch_a = dyn_rowch_lds(f, p.H);
     {
         int slot = 0;
         for (int v = rth.vstart; v < f.w1; v += p.rows_per_pass) {
             if (v < f.w0) continue;
-            const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+            typedef unsigned lu4 __attribute__((ext_vector_type(4)));
+            const lu4 rc = *(const __attribute__((address_space(3))) lu4*)(uintptr_t)(rowch_a + ((unsigned)v << 4));
             const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
             unsigned packs[kDynBatch];
 #pragma unroll
@@ -659,11 +679,10 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             for (int bi = 0; bi < kDynBatch; ++bi) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) cbits[bi][k] |= word == (unsigned)k ? packs[bi] << sh : 0u;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t c = *(lds_u32p)(uintptr_t)(pal_a + (((packs[bi] >> (2 * k)) & 3u) << 2));
-                    srb[bi] += c & 0x00FF00FFu; sgs[bi] += (c >> 8) & 255u;
-                }
+                const unsigned cnt = *(lds_u32p)(uintptr_t)(cnt_a + (packs[bi] << 2));
+                ssr[bi] = __builtin_amdgcn_udot4(cnt, rc.x, ssr[bi], false);
+                ssg[bi] = __builtin_amdgcn_udot4(cnt, rc.y, ssg[bi], false);
+                ssb[bi] = __builtin_amdgcn_udot4(cnt, rc.z, ssb[bi], false);
             }
             ++slot;
         }
@@ -671,7 +690,7 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
 #pragma unroll
     for (int bi = 0; bi < kDynBatch; ++bi) {
         if (bi >= nb) continue;
-        unsigned sr = srb[bi] & 0xFFFFu, sb = srb[bi] >> 16, sg = sgs[bi];
+        unsigned sr = ssr[bi], sb = ssb[bi], sg = ssg[bi];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
         if (lane == 0) {

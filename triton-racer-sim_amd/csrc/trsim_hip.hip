@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0;   // esum[2][4][3], dbar
-        dyn_stage_tables(smem, sp.fp, p.H, tid, kBlock);                   // OpenCV's reciprocals + the in-range byte masks (behind the prologue's barrier)
+        dyn_stage_tables(smem, sp.fp, p.H, tid, kBlock, reinterpret_cast<const uint32_t*>(p.blob + p.off_pal));                   // OpenCV's reciprocals + the in-range byte masks (behind the prologue's barrier)
     }
     // ---- prologue: everything is staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves
     // 64 lanes x 16 B = 1 KB, lane-linear, no registers and no ds_write pass), all requests are in flight together and
@@ -1574,6 +1574,11 @@ int upload_dyn_tables(trs_env* e, const trs_pre_config& c)
     unsigned sel = 0;
     for (int i = 0; i < 768; ++i) t[512 + i] = range_byte_entry(lo, hi, dc, c.n_filters, i, &sel);
     t[512 + 768] = sel;
+    for (int i = 0; i < 256; ++i) {                                           // class counts of a 4-pixel pack: n0 | n1 << 8 | n2 << 16 | n3 << 24
+        unsigned cnt = 0;
+        for (int k = 0; k < 4; ++k) cnt += 1u << (8 * ((i >> (2 * k)) & 3));
+        t[trsim::kDynCntAt + i] = cnt;
+    }
     { int rq = quiesce(e); if (rq) return rq; HIPCHK(hipStreamSynchronize(e->sP)); }   // a running kernel may still be staging the old tables
     if (!e->dyn_tab) HIPCHK(hipMalloc((void**)&e->dyn_tab, kDynTabWords * sizeof(unsigned)));
     HIPCHK(hipMemcpy(e->dyn_tab, t.data(), kDynTabWords * sizeof(unsigned), hipMemcpyHostToDevice));

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0;   // channel sums, team-barrier counter
-        dyn_stage_tables(smem, wp.fp, p.H, tid, kBlock);                   // the filter's tables, once per launch: the raster waves' steady state issues no loads
+        dyn_stage_tables(smem, wp.fp, p.H, tid, kBlock, reinterpret_cast<const uint32_t*>(p.blob + p.off_pal));                   // the filter's tables, once per launch: the raster waves' steady state issues no loads
     }
     if (!raster_team)
         for (int j = pw; j < n_loc; j += kPhysWaves) {
