@@ -594,7 +594,7 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
 #define TRS_F5_COMPUTE 4   /* compute waves (+ 4 loader waves); 1 x 8 and 2 x 8 measured: see the kernel */
 #endif
 #ifndef TRS_F5_STAMPS
-#define TRS_F5_STAMPS 0   /* diagnostic build, never shipped: workgroups 7 and 700 print the shader clocks of their staging and K loops */
+#define TRS_F5_STAMPS 0   /* diagnostic build, never shipped: workgroup 7 prints the s_memtime ticks of its first staging, its work and its waits */
 #endif
 struct Frame5Params {
     const u4v* in;             // fp16 NHWC [N][IH][IW][32]
@@ -786,9 +786,6 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
 #endif
 #ifndef TRS_C2_NT
 #define TRS_C2_NT 1      /* conv2 tiles of the fused head per wave item (one weight fragment feeds that many MFMAs); 2 measured: see the kernel */
-#endif
-#ifndef TRS_LOADER_PRIO
-#define TRS_LOADER_PRIO 0   /* s_setprio 3 on the loader waves while they unpack: measured, see the kernel */
 #endif
 #ifndef TRS_C2_DEPTH
 #define TRS_C2_DEPTH 4   /* k-steps of fragments in flight */
@@ -1087,14 +1084,8 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
         BAND_STAMP(1);                                                      // wait at the barrier
         if (loader) {
             if (nxt < total) {
-#if TRS_LOADER_PRIO
-                __builtin_amdgcn_s_setprio(3);
-#endif
                 unpack(raw);                                                // the next item's band (requested an item ago)
                 if (nxt + 1 < total) request(nxt + 1, raw);
-#if TRS_LOADER_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
         } else {
             // ---- phase 2: conv2 rows from the tile (waves 0..7: at most a handful of tiles per band) ----
@@ -1112,7 +1103,7 @@ __global__ __launch_bounds__(1024) void trs_conv12_band_kernel(const Fuse12Param
             //     by hand): the pairs run on four waves, one per SIMD, and each needs 3.7 k clocks for its 80 MFMAs + 1.0 k for two epilogues — 95.7 us
             //     on the same box.  (Round 2 measured the same split with compiler-scheduled reads: 107 -> 130 us; conv2's 40 weight fragments in
             //     registers on eight waves of 256 registers 100 -> 117 us, the same with K split over two waves 100 -> 125 us, r02_pilot_head_reg.txt.)
-            //   * TRS_LOADER_PRIO = 1 (s_setprio 3 while the loader waves unpack: they finish in 1.0 k instead of 3.0 k clocks, but the conv2 waves
+            //   * s_setprio 3 while the loader waves unpack (measured, removed: they finish in 1.0 k instead of 3.0 k clocks, but the conv2 waves
             //     they displace are the critical path): 90.0 us.  Deeper fragment rings (6, 8 k-steps): no change.
             //   * The odd k-steps' weight fragments straight from global memory (buffer loads, three in flight = six k-steps of lead; the LDS then delivers
             //     1.5 KB per MFMA and the L1 the rest): K loop 2.5 k -> 3.5 k clocks per band, head 76.3 -> 81 us (240x320: 162 -> 191) — the frames the
