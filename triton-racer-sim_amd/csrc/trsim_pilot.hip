@@ -2279,7 +2279,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                     };
                     // the better tile height (2 or 3 tiles of 32 pixels) for items of 64 output channels (items of 32 channels — twice the ring depth,
                     // two waves on every SIMD — were measured in round 3: the kernel 105 k against 107 k clocks, the closed loop equal; removed in round 4, and measured once
-                    // more for conv7 alone, whose 64-channel items are 6 for 8 waves or 4 lone waves: chain 46.3 -> 47.5 us, for every layer 49.5)
+                    // more for conv7 alone, whose 64-channel items are 6 for 8 waves or 4 lone waves: chain 46.3 -> 47.5 us, for every layer 49.5; conv7 on ten single-tile
+                    // items of 64 channels (three per busy SIMD instead of four lone waves): 43.4 -> 46.5 us — twice the weight stream per MFMA)
                     int nt = 2, best = 1 << 30, best_waves = 0;
                     for (int cnt = 3; cnt >= 2; --cnt) {
                         int wv = 0;
