@@ -649,6 +649,39 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         };
         return cls_of(rth.ufa) | (cls_of(rth.ufb) << 2) | (cls_of(rth.ufc) << 4) | (cls_of(rth.ufd) << 6);
     };
+    // The same classes for TWO envs of one row, in stages: eight map addresses, eight reads in flight, eight extractions.  The scheduling fences keep
+    // the stages apart: left alone (and short of registers in this kernel) hipcc issued one read, waited for it, issued the next - sixteen
+    // dependent LDS round trips per row of the batch where this takes two.
+    auto classify_pair = [&](const f2v rt, const float4& cam0, const float4& cam1, unsigned& pack0, unsigned& pack1) {
+        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
+        const f2v uf[4] = {rth.ufa, rth.ufb, rth.ufc, rth.ufd};
+        unsigned wa[8], sh[8];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const float4& cam = e2 ? cam1 : cam0;
+            const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
+            const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
+            const f2v d = ray_step(kk2, cns);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f2v g = __builtin_elementwise_fma(uf[q], d, a);
+                const unsigned ix = min(cvt_u32_sat(g.x), rth.gwm1);
+                const unsigned iz = min(cvt_u32_sat(g.y), rth.ghm1);
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(wa[4 * e2 + q]) : "v"(iz), "s"(rth.pitch), "v"((ix >> 2) & ~3u));
+                sh[4 * e2 + q] = ix << 1;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = *(lds_u32p)(uintptr_t)wa[i];
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_ubfe(w[i], sh[i], 2);
+        pack0 = c[0] | (c[1] << 2) | (c[2] << 4) | (c[3] << 6);
+        pack1 = c[4] | (c[5] << 2) | (c[6] << 4) | (c[7] << 6);
+    };
     // (A) rows outside, envs inside: the (up to) four envs' lookups of one row are independent chains (row table -> map
     // -> palette are three dependent LDS round trips per row, and two waves per SIMD cannot hide them one env at a time)
     // The channel sums of a row: sum over the classes k of n_k x (raw colour of class k in this row).  The pack of four 2-bit classes indexes a
@@ -662,29 +695,54 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
     const unsigned cnt_a = (unsigned)f.lds_off + (unsigned)(kDynBatch * p.H * 16 + 128 + kDynCntAt * 4);
     const unsigned rowch_a = dyn_rowch_lds(f, p.H);
     {
-        int slot = 0;
-        for (int v = rth.vstart; v < f.w1; v += p.rows_per_pass) {
-            if (v < f.w0) continue;
-            typedef unsigned lu4 __attribute__((ext_vector_type(4)));
-            const lu4 rc = *(const __attribute__((address_space(3))) lu4*)(uintptr_t)(rowch_a + ((unsigned)v << 4));
-            const unsigned sh = (unsigned)(slot & 3) * 8u, word = (unsigned)slot >> 2;
+        // The window rows are taken from the LAST down: each row's pack is pushed into the low byte of the env's 128-bit register cbits (three
+        // v_alignbit + one v_lshl_or), so phase C, walking its rows upwards, finds the pack of its next window row in the low byte and shifts it
+        // out.  (Until late round 4: a slot counter, four compares and selects per env and row here, three selects and a variable shift in phase C.)
+        // Integer sums: the order of the rows does not matter.
+        float4 camx[kDynBatch];
+#pragma unroll
+        for (int bi = 0; bi < kDynBatch; ++bi) camx[bi] = bi < nb ? cams[bi] : cams[0];
+        int vl = -1;
+        if (f.w1 > rth.vstart) vl = rth.vstart + ((f.w1 - 1 - rth.vstart) / p.rows_per_pass) * p.rows_per_pass;
+        const int vstop = max(f.w0, rth.vstart);
+        typedef unsigned lu4 __attribute__((ext_vector_type(4)));
+        auto rowch_of = [&](int v) -> lu4 { return *(const __attribute__((address_space(3))) lu4*)(uintptr_t)(rowch_a + ((unsigned)v << 4)); };
+        lu4 rc = rowch_of(max(vl, 0));                                   // this row's palette and row-table entry were requested one row earlier
+        f2v rt = lrow[max(vl, 0)];
+        for (int v = vl; v >= vstop; v -= p.rows_per_pass) {
+            const int vn = max(v - p.rows_per_pass, 0);
+            const lu4 rcn = rowch_of(vn);
+            const f2v rtn = lrow[vn];
             unsigned packs[kDynBatch];
 #pragma unroll
-#if TRS_DYN_ABLATE == 1   /* timing-only: phase A without its classification */
             for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = 0u;
-#else
-            for (int bi = 0; bi < kDynBatch; ++bi) packs[bi] = (v >= p.uni_rows && bi < nb) ? classify4(v, cams[bi]) : 0u;
+#if TRS_DYN_ABLATE != 1   /* 1: timing-only, phase A without its classification */
+            // ONE branch for the row, all four envs inside it (an env past the batch's end classifies with the first env's camera and is never read):
+            // with a test of `bi < nb` per env hipcc gave every env its own exec-masked block, each with its own row-table read and its
+            // own counted waits - sixteen dependent LDS round trips per row instead of three
+            if (v >= p.uni_rows) {
+                classify_pair(rt, camx[0], camx[1], packs[0], packs[1]);
+                classify_pair(rt, camx[2], camx[3], packs[2], packs[3]);
+            }
 #endif
+            unsigned cnt[kDynBatch];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) cnt[bi] = *(lds_u32p)(uintptr_t)(cnt_a + (packs[bi] << 2));   // (the four reads together, the pushes underneath)
 #pragma unroll
             for (int bi = 0; bi < kDynBatch; ++bi) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cbits[bi][k] |= word == (unsigned)k ? packs[bi] << sh : 0u;
-                const unsigned cnt = *(lds_u32p)(uintptr_t)(cnt_a + (packs[bi] << 2));
-                ssr[bi] = __builtin_amdgcn_udot4(cnt, rc.x, ssr[bi], false);
-                ssg[bi] = __builtin_amdgcn_udot4(cnt, rc.y, ssg[bi], false);
-                ssb[bi] = __builtin_amdgcn_udot4(cnt, rc.z, ssb[bi], false);
+                cbits[bi][3] = __builtin_amdgcn_alignbit(cbits[bi][3], cbits[bi][2], 24);
+                cbits[bi][2] = __builtin_amdgcn_alignbit(cbits[bi][2], cbits[bi][1], 24);
+                cbits[bi][1] = __builtin_amdgcn_alignbit(cbits[bi][1], cbits[bi][0], 24);
+                cbits[bi][0] = (cbits[bi][0] << 8) | packs[bi];
             }
-            ++slot;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                ssr[bi] = __builtin_amdgcn_udot4(cnt[bi], rc.x, ssr[bi], false);
+                ssg[bi] = __builtin_amdgcn_udot4(cnt[bi], rc.y, ssg[bi], false);
+                ssb[bi] = __builtin_amdgcn_udot4(cnt[bi], rc.z, ssb[bi], false);
+            }
+            rc = rcn; rt = rtn;
         }
     }
 #pragma unroll
@@ -750,21 +808,19 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             img + (size_t)eb * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
         __amdgpu_buffer_rsrc_t drs = rsrc;
         if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)eb * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
-        int slot = 0;
         const unsigned penv_a = (unsigned)f.lds_off + (unsigned)(bi * p.H * 16);
         for (int v = rth.vstart; v < p.H; v += p.rows_per_pass) {
             const bool in_win = v >= f.w0 && v < f.w1;
             unsigned pack = 0;
-            if (v >= p.uni_rows) {
-                if (in_win) {
-                    const unsigned word = (unsigned)slot >> 2;
-                    const unsigned wv = word == 0 ? cbits[bi][0] : (word == 1 ? cbits[bi][1] : (word == 2 ? cbits[bi][2] : cbits[bi][3]));
-                    pack = (wv >> ((unsigned)(slot & 3) * 8u)) & 255u;
-                } else {
-                    pack = classify4(v, cams[bi]);
-                }
+            if (in_win) {                                                   // phase A's pack of this row (0 for a uniform row), then the next one moves down
+                pack = cbits[bi][0] & 255u;
+                cbits[bi][0] = __builtin_amdgcn_alignbit(cbits[bi][1], cbits[bi][0], 8);
+                cbits[bi][1] = __builtin_amdgcn_alignbit(cbits[bi][2], cbits[bi][1], 8);
+                cbits[bi][2] = __builtin_amdgcn_alignbit(cbits[bi][3], cbits[bi][2], 8);
+                cbits[bi][3] >>= 8;
+            } else if (v >= p.uni_rows) {
+                pack = classify4(v, cams[bi]);
             }
-            if (in_win) ++slot;
             const unsigned row_a = penv_a + ((unsigned)v << 4);
             const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
             const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
