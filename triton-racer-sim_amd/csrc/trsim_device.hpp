@@ -584,6 +584,11 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, const un
 #ifndef TRS_DYN_ABLATE
 #define TRS_DYN_ABLATE 0   /* timing-only diagnostic builds (scripts/r04_dyn_ablate.sh), never shipped: 1 no classification in phase A, 2 no filter arithmetic in phase B, 3 no stores in phase C */
 #endif
+#ifdef TRS_DYN_STAMPS   /* diagnostic build (scripts/dyn_stamps.sh), never shipped: s_memtime ticks (100 MHz) of workgroup 7's first raster thread per phase into stats[46..51] */
+#define DYN_STAMP(k) do { if (blockIdx.x == 7 && tid == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); atomicAdd(&p.stats[46 + (k)], tn - dyn_t0); dyn_t0 = tn; } } while (0)
+#else
+#define DYN_STAMP(k) do { } while (0)
+#endif
 constexpr int kDynBatch = 4;
 __host__ __device__ inline int dyn_lds_bytes(int H) { return kDynBatch * H * 16 + 128 + ((kDynTabWords * 4 + 15) & ~15) + H * 16; }   // ... + rowch[H]: the raw palette by channel
 // the tables behind the batch's palettes and sums (staged by dyn_stage_tables before the launch's first barrier)
@@ -622,6 +627,10 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
                                                  int nb, uint8_t* img, float* dep, int e, int it, int tid, int lane, Bail&& bail)
 {
     uint32_t* const penv = reinterpret_cast<uint32_t*>(lds_base + f.lds_off);                          // [kDynBatch][H][4]
+#ifdef TRS_DYN_STAMPS
+    unsigned long long dyn_t0 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 7 && tid == 0) atomicAdd(&p.stats[52], 1ull);
+#endif
     int* const esum = reinterpret_cast<int*>(lds_base + f.lds_off + kDynBatch * p.H * 16);           // [2][kDynBatch][3]
     int* const dbar = esum + 2 * kDynBatch * 3;
     const int par = it & 1;
@@ -689,6 +698,9 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
     // B bytes — one 16-byte read per row, shared by the batch's envs and independent of the classification), and one v_dot4_u32_u8 per
     // channel adds n . colours.  (Until round 4: four dependent palette gathers and four masked adds per env and row — 28 of the ~64 vector
     // instructions of a row of phase A, which is bound by exactly those.)  Exact integers either way.
+    float4 camx[kDynBatch];                                                  // an env past the batch's end runs with the first env's camera: classified, never read
+#pragma unroll
+    for (int bi = 0; bi < kDynBatch; ++bi) camx[bi] = bi < nb ? cams[bi] : cams[0];
     unsigned ssr[kDynBatch], ssg[kDynBatch], ssb[kDynBatch];
 #pragma unroll
     for (int bi = 0; bi < kDynBatch; ++bi) { ssr[bi] = 0u; ssg[bi] = 0u; ssb[bi] = 0u; }
@@ -699,9 +711,6 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         // v_alignbit + one v_lshl_or), so phase C, walking its rows upwards, finds the pack of its next window row in the low byte and shifts it
         // out.  (Until late round 4: a slot counter, four compares and selects per env and row here, three selects and a variable shift in phase C.)
         // Integer sums: the order of the rows does not matter.
-        float4 camx[kDynBatch];
-#pragma unroll
-        for (int bi = 0; bi < kDynBatch; ++bi) camx[bi] = bi < nb ? cams[bi] : cams[0];
         int vl = -1;
         if (f.w1 > rth.vstart) vl = rth.vstart + ((f.w1 - 1 - rth.vstart) / p.rows_per_pass) * p.rows_per_pass;
         const int vstop = max(f.w0, rth.vstart);
@@ -756,9 +765,11 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             atomicAdd(&es[0], (int)sr); atomicAdd(&es[1], (int)sg); atomicAdd(&es[2], (int)sb);
         }
     }
+    DYN_STAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!team_barrier_wait(dbar, nrw * (2 * it + 1), bail)) return false;
+    DYN_STAMP(1);
     // (B) delta exactly as ImgPreprocessing computes it (binary64; img_preprocessing.py:88-91), then the palette entries
     {
         const double cnt = (double)(f.w1 - f.w0) * (double)p.W;
@@ -796,47 +807,76 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         }
         if (tid < kDynBatch * 3) esum[(par ^ 1) * kDynBatch * 3 + tid] = 0;   // the next batch's sums start from zero (nobody reads that half now)
     }
+    DYN_STAMP(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!team_barrier_wait(dbar, nrw * (2 * it + 2), bail)) return false;
-    // (C)
+    DYN_STAMP(3);
+    // (C) rows outside, envs inside (as phase A): the four envs' palette gathers of a row are sixteen independent LDS reads in flight; one env at a
+    // time every row was its own round trip (6.9 of the step's 19 us by the stamps of scripts/dyn_stamps.sh, at 58 % of the vector-issue rate).
+    {
+        __amdgpu_buffer_rsrc_t rsrc[kDynBatch], drs[kDynBatch];
 #pragma unroll
-    for (int bi = 0; bi < kDynBatch; ++bi) {
-        const int eb = e + bi;
-        if (bi >= nb) continue;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            img + (size_t)eb * ((size_t)p.gpe * 12), 0, (int)((size_t)p.gpe * 12), 0x00020000);
-        __amdgpu_buffer_rsrc_t drs = rsrc;
-        if constexpr (DEPTH) drs = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)eb * ((size_t)p.gpe * 4), 0, (int)((size_t)p.gpe * 16), 0x00020000);
-        const unsigned penv_a = (unsigned)f.lds_off + (unsigned)(bi * p.H * 16);
+        for (int bi = 0; bi < kDynBatch; ++bi) {
+            const int eb = e + min(bi, nb - 1);                               // an env past the batch's end: a descriptor of ZERO bytes - the hardware's bounds check drops its stores
+            rsrc[bi] = __builtin_amdgcn_make_buffer_rsrc(img + (size_t)eb * ((size_t)p.gpe * 12), 0, bi < nb ? (int)((size_t)p.gpe * 12) : 0, 0x00020000);
+            drs[bi] = rsrc[bi];
+            if constexpr (DEPTH) drs[bi] = __builtin_amdgcn_make_buffer_rsrc(dep + (size_t)eb * ((size_t)p.gpe * 4), 0, bi < nb ? (int)((size_t)p.gpe * 16) : 0, 0x00020000);
+        }
+        const unsigned env_pitch = (unsigned)(p.H * 16);
         for (int v = rth.vstart; v < p.H; v += p.rows_per_pass) {
             const bool in_win = v >= f.w0 && v < f.w1;
-            unsigned pack = 0;
-            if (in_win) {                                                   // phase A's pack of this row (0 for a uniform row), then the next one moves down
-                pack = cbits[bi][0] & 255u;
-                cbits[bi][0] = __builtin_amdgcn_alignbit(cbits[bi][1], cbits[bi][0], 8);
-                cbits[bi][1] = __builtin_amdgcn_alignbit(cbits[bi][2], cbits[bi][1], 8);
-                cbits[bi][2] = __builtin_amdgcn_alignbit(cbits[bi][3], cbits[bi][2], 8);
-                cbits[bi][3] >>= 8;
+            unsigned pack[kDynBatch];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) pack[bi] = 0u;
+            if (in_win) {                                                   // phase A's packs of this row (0 for a uniform row), then the next row's move down
+#pragma unroll
+                for (int bi = 0; bi < kDynBatch; ++bi) {
+                    pack[bi] = cbits[bi][0];                                // (only the low byte is read below)
+                    cbits[bi][0] = __builtin_amdgcn_alignbit(cbits[bi][1], cbits[bi][0], 8);
+                    cbits[bi][1] = __builtin_amdgcn_alignbit(cbits[bi][2], cbits[bi][1], 8);
+                    cbits[bi][2] = __builtin_amdgcn_alignbit(cbits[bi][3], cbits[bi][2], 8);
+                    cbits[bi][3] >>= 8;
+                }
             } else if (v >= p.uni_rows) {
-                pack = classify4(v, cams[bi]);
+                const f2v rt = lrow[v];
+                classify_pair(rt, camx[0], camx[1], pack[0], pack[1]);
+                classify_pair(rt, camx[2], camx[3], pack[2], pack[3]);
             }
-            const unsigned row_a = penv_a + ((unsigned)v << 4);
-            const uint32_t c0p = *(lds_u32p)(uintptr_t)(row_a + ((pack & 3u) << 2)), c1p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 2) & 3u) << 2));
-            const uint32_t c2p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 4) & 3u) << 2)), c3p = *(lds_u32p)(uintptr_t)(row_a + (((pack >> 6) & 3u) << 2));
-            const u3v px3 = {__builtin_amdgcn_perm(c1p, c0p, 0x04020100u), __builtin_amdgcn_perm(c2p, c1p, 0x05040201u), __builtin_amdgcn_perm(c3p, c2p, 0x06050402u)};
+            const unsigned row_a = (unsigned)f.lds_off + ((unsigned)v << 4);
+            unsigned ga[kDynBatch][4];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned cls = __builtin_amdgcn_ubfe(pack[bi], 2 * q, 2);
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ga[bi][q]) : "v"(cls), "v"(row_a + (unsigned)bi * env_pitch));
+                }
+            uint32_t cp[kDynBatch][4];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cp[bi][q] = *(lds_u32p)(uintptr_t)ga[bi][q];
+            const unsigned soff = rth.col_off + v * rth.row_bytes;
+            unsigned dz = 0; (void)dz;
+            if constexpr (DEPTH) dz = __float_as_uint(rth.lrowdepth[v]);
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                const u3v px3 = {__builtin_amdgcn_perm(cp[bi][1], cp[bi][0], 0x04020100u), __builtin_amdgcn_perm(cp[bi][2], cp[bi][1], 0x05040201u),
+                                 __builtin_amdgcn_perm(cp[bi][3], cp[bi][2], 0x06050402u)};
 #if TRS_DYN_ABLATE == 3   /* timing-only: phase C without its stores */
-            asm volatile("" :: "v"(px3.x), "v"(px3.y), "v"(px3.z)); (void)rsrc; (void)drs;
+                asm volatile("" :: "v"(px3.x), "v"(px3.y), "v"(px3.z)); (void)soff;
 #else
-            __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc, rth.col_off + v * rth.row_bytes, 0, TRS_STORE_AUX);
-            if constexpr (DEPTH) {
-                const unsigned dz = __float_as_uint(rth.lrowdepth[v]);
-                const u4v d4 = {dz, dz, dz, dz};
-                __builtin_amdgcn_raw_buffer_store_b128(d4, drs, (rth.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
-            }
+                __builtin_amdgcn_raw_buffer_store_b96(px3, rsrc[bi], soff, 0, TRS_STORE_AUX);
+                if constexpr (DEPTH) {
+                    const u4v d4 = {dz, dz, dz, dz};
+                    __builtin_amdgcn_raw_buffer_store_b128(d4, drs[bi], (rth.cg + v * p.gpr) * 16, 0, TRS_STORE_AUX);
+                }
 #endif
+            }
         }
     }
+    DYN_STAMP(4);
     return true;
 }
 
