@@ -22,7 +22,7 @@ names = ["A (classify + sums)", "barrier 1", "B (palettes)", "barrier 2", "C (sh
 print(f"{dt / 2000 * 1e6:.2f} us per step by wall clock; batches of workgroup 7 seen: {int(nb)}")
 tot = 0.0
 for k, nm in enumerate(names):
-    us = d[46 + k] / nb * 0.01
+    us = d[46 + k] / nb / 2100.0   # s_memtime counts shader clocks here (~2.1 GHz under this load), not 100 MHz
     tot += us
     print(f"  {nm:24s} {us:6.2f} us per batch")
 print(f"  inside raster_dyn_batch  {tot:6.2f} us per batch (one batch of 4 envs per step and workgroup at 1024 envs)")

@@ -137,6 +137,18 @@ __device__ __forceinline__ void wave_argmin(double& d, int& i)
     argmin_dpp_step<0x143, 0xc>(d, i);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
 }
 
+// wave64 sum of an unsigned per lane by the same DPP steps (lanes without a source add 0); the total ends in lane 63
+__device__ __forceinline__ unsigned wave_sum_dpp(unsigned x)
+{
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 __device__ __forceinline__ unsigned cvt_u32_sat(float x)
 {
     // v_cvt_u32_f32: truncate toward zero, saturate (negative / NaN -> 0).  For the rasteriser's
@@ -757,10 +769,8 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
 #pragma unroll
     for (int bi = 0; bi < kDynBatch; ++bi) {
         if (bi >= nb) continue;
-        unsigned sr = ssr[bi], sb = ssb[bi], sg = ssg[bi];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-        if (lane == 0) {
+        const unsigned sr = wave_sum_dpp(ssr[bi]), sg = wave_sum_dpp(ssg[bi]), sb = wave_sum_dpp(ssb[bi]);   // (DPP: 6 vector instructions per sum; the ds_bpermute shuffles were 6 LDS round trips)
+        if (lane == 63) {
             int* const es = esum + (par * kDynBatch + bi) * 3;
             atomicAdd(&es[0], (int)sr); atomicAdd(&es[1], (int)sg); atomicAdd(&es[2], (int)sb);
         }
@@ -790,20 +800,28 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         // ground row's four entries are four items.  1,332 items instead of 1,920 entries per batch of four 120-row frames.
         const unsigned* const ltabs = dyn_tabs_lds(lds_base, f, p.H);
         const int items_env = p.uni_rows + 4 * (p.H - p.uni_rows);
-        for (int t = tid; t < kDynBatch * items_env; t += kRasterThreads) {
-            const int bi = t / items_env, it_e = t - bi * items_env;
-            if (bi >= nb) break;
-            const float deltaf = bi == 0 ? dlt[0] : (bi == 1 ? dlt[1] : (bi == 2 ? dlt[2] : dlt[3]));
+        // A thread takes one palette entry for ALL envs of the batch: one read of the raw colour, four independent filter chains (each is ~65 vector
+        // instructions behind four dependent table lookups) - until late round 4 an item was (env, entry), found by an integer division, one chain at a time.
+        // (An env past the batch's end is filtered with delta 0 into its own, unused, palette.)
+        for (int it_e = tid; it_e < items_env; it_e += kRasterThreads) {
             const bool uni = it_e < p.uni_rows;
             const int ent = uni ? 4 * it_e : it_e + 3 * p.uni_rows;          // palette entry (row * 4 + class) of this item
+            const uint32_t raw = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2));
+            uint32_t c[kDynBatch];
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
 #if TRS_DYN_ABLATE == 2   /* timing-only: phase B without the filter arithmetic */
-            const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)) + (unsigned)deltaf;
+                c[bi] = raw + (unsigned)dlt[bi];
 #else
-            const uint32_t c = filter_colour_dev(f, ltabs, *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)ent << 2)), deltaf);
+                c[bi] = filter_colour_dev(f, ltabs, raw, dlt[bi]);
 #endif
-            uint32_t* const dst = penv + bi * per_env + ent;
-            dst[0] = c;
-            if (uni) { dst[1] = c; dst[2] = c; dst[3] = c; }
+            }
+#pragma unroll
+            for (int bi = 0; bi < kDynBatch; ++bi) {
+                uint32_t* const dst = penv + bi * per_env + ent;
+                dst[0] = c[bi];
+                if (uni) { dst[1] = c[bi]; dst[2] = c[bi]; dst[3] = c[bi]; }
+            }
         }
         if (tid < kDynBatch * 3) esum[(par ^ 1) * kDynBatch * 3 + tid] = 0;   // the next batch's sums start from zero (nobody reads that half now)
     }
