@@ -25,7 +25,7 @@ cp("r04f_pilot_layers.txt", "r04_pilot_layers.txt", "# round 4: per-kernel times
 cp("r04f_pilot_pmc.txt", "r04_pilot_pmc.txt", "# round 4: hardware counters per kernel of one closed-loop step (scripts/pilot_pmc.sh: separate --pmc passes, no tracing domains)\n")
 cp("r04f_pilot_precision.txt", "r04_pilot_precision.txt")
 cp("r04f_image_path.txt", "r04_image_path.txt", "# round 4: image path (scripts/preprocess_bench.py); the Canny layer was not changed this round\n")
-cp("r04f_fused_filter.txt", "r04_fused_filter.txt", "# round 4: cam/processed_img per step (scripts/filter_bench.py): the dynamic-brightness filter with its tables in LDS, uniform rows filtered once (26.3-26.9 -> 23.1-23.6 us resident),\n# and phase A's channel sums by a class-count table + the raw palette by channel + one v_dot4_u32_u8 per channel (-> 21.3-21.4 us; launch mode 27.9 -> 25.9)\n")
+cp("r04f_fused_filter.txt", "r04_fused_filter.txt", "# round 4: cam/processed_img per step (scripts/filter_bench.py): the dynamic-brightness filter with its tables in LDS, uniform rows filtered once (26.3-26.9 -> 23.1-23.6 us resident),\n# and phase A's channel sums by a class-count table + the raw palette by channel + one v_dot4_u32_u8 per channel (-> 21.3-21.4 us; launch mode 27.9 -> 25.9),\n# then the phases' LDS reads in flight together, class bits in a shift register, DPP sums (-> 15.5 us; launch mode 22.9; profiles/r04_dyn_stamps.txt)\n")
 cp("r04f_config1.txt", "r04_config1.txt")
 Q = os.path.join(O, "prof_r04f_resident")
 if os.path.exists(os.path.join(Q, "summary.txt")):
