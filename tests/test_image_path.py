@@ -243,7 +243,7 @@ def test_gpu_fused_frame_filter_equals_oracle(make_env, cfg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", DYNAMIC)
-@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (64, 64, 300, False)])
+@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (64, 64, 300, False), (120, 160, 7, False)])   # (7: a last batch of three envs)
 def test_gpu_fused_dynamic_brightness_equals_oracle(make_env, cfg, shape):
     """Dynamic brightness inside the step kernel (class histogram of rows 40..118 -> per-env palette) against the
     oracle's render-then-filter, bit for bit; env counts that leave the last workgroup partly filled; single-step calls,
@@ -274,7 +274,7 @@ def test_gpu_fused_dynamic_brightness_equals_oracle(make_env, cfg, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", DYNAMIC)
-@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (120, 160, 1024, False), (64, 64, 300, False)])
+@pytest.mark.parametrize("shape", [(120, 160, 101, False), (240, 320, 37, True), (120, 160, 1024, False), (64, 64, 300, False), (120, 160, 6, True)])   # (6: a last batch of two envs, with depth)
 def test_gpu_dynamic_brightness_in_resident_mode_equals_oracle(make_env, cfg, shape):
     """Round 3: the dynamic-brightness frame filter has its own instantiation of the resident worker (until round 2 resident-mode
     calls silently fell back to launches, include/trsim.h).  Every step posted on its own, lock-step calls, a step sequence, a filter
