@@ -485,14 +485,15 @@ def main():
         # the way Car.start drives GymInterface.step (core/car.py:45-53)
         one_steer = (torch.rand(n, device="cuda") * 2 - 1) * 0.3
         one_thr = torch.rand(n, device="cuda") * 0.6 + 0.2
+        p_steer, p_thr = one_steer.data_ptr(), one_thr.data_ptr()          # the consumer holds its control tensors: their addresses are taken once
         torch.cuda.synchronize()
         for _ in range(min(50, args.steps)):
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
         env.sync()
         t1 = time.perf_counter()
         env.event_record(6)
         for _ in range(args.steps):
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
         env.event_record(7)
         ms_one = env.event_elapsed_ms(6, 7)
         wall_one = time.perf_counter() - t1
@@ -500,33 +501,33 @@ def main():
         env.sync()
         t4 = time.perf_counter()
         for _ in range(lock_steps):                               # lock-step with launches: step, wait for the frame (stream synchronisation), step
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
             env.sync()
         wall_lock_launch = time.perf_counter() - t4
         # ... the same loop in resident mode: every call only posts its control pointers to the worker kernel
         env.set_step_mode(True)
         for _ in range(min(50, args.steps)):
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
         env.sync()
         t2 = time.perf_counter()
         env.event_record(6)                                       # (asks the worker to leave: the timed span holds a whole worker launch)
         for _ in range(args.steps):
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
         env.event_record(7)
         ms_res = env.event_elapsed_ms(6, 7)
         wall_res = time.perf_counter() - t2
         # ... and lock-step: the consumer waits for every frame before it posts the next step (PCIe round trips included)
-        env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+        env.step_device(p_steer, p_thr)
         env.sync()
         t3 = time.perf_counter()
         for _ in range(lock_steps):
-            env.step_device(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device(p_steer, p_thr)
             env.sync()
         wall_lock = time.perf_counter() - t3
-        env.step_device_wait(one_steer.data_ptr(), one_thr.data_ptr())
+        env.step_device_wait(p_steer, p_thr)
         t3 = time.perf_counter()
         for _ in range(lock_steps):                                       # ... the same tick through trs_step_wait: one FFI crossing
-            env.step_device_wait(one_steer.data_ptr(), one_thr.data_ptr())
+            env.step_device_wait(p_steer, p_thr)
         wall_lock1 = time.perf_counter() - t3
         # ... and SURVEY 8(f-1): cnn_2d_speed_control inference on the device frame every step, actions fed back (closed loop, launch mode: the
         # pilot's kernels need the CUs' LDS, so the resident worker is asked to leave first)

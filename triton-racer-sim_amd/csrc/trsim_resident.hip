@@ -250,7 +250,7 @@ __device__ __forceinline__ void dispatcher_run(const WParams& wp, const WLds& l,
         const bool busy = (u64)lds_load64(l.fwd) < L.known;           // this workgroup has not finished everything published
         if (fresh || busy) L.t_last = now;
         const bool leave = (!fresh && (close_req || now - L.t_last > wp.idle_ticks)) || now - L.t_start > wp.life_ticks;
-        if (!leave) { if (!fresh) __builtin_amdgcn_s_sleep(16); continue; }
+        if (!leave) { if (!fresh) __builtin_amdgcn_s_sleep(4); continue; }      // (a poll is a PCIe round trip anyway; 16 until late round 4: ~0.25 us more until a post is seen)
         if (lane == 0) sys_store64(&wp.mb->exited, 1ull);
         drain_vmem();                                        // `exited` is in host memory before the last look at the ring
         (void)dispatcher_take(wp, l, L, lane, close_req);    // whatever was posted before that look is still served by this launch
@@ -286,15 +286,16 @@ __device__ __forceinline__ void forward_arrivals(const WParams& wp, const WLds& 
         lds_store32(&l.arrive[slot], 0);
         const int shard = (int)(blockIdx.x & 7u), nshards = min(8, wp.n_blocks);
         const unsigned members = (unsigned)((wp.n_blocks - shard + 7) / 8);
+        // The counters only ever count up (zeroed by trs_worker_init_kernel in front of every launch): step fwd is the uses-th use of its slot in
+        // this launch, so the last arrival of a shard sees members * uses - 1 and the last shard nshards * uses - 1 (modulo 2^32 like the counters).
+        // Until late round 4 the last arrival reset the counter and drained that store in front of the done flag: a device round trip on the
+        // consumer's critical path of every lock-step tick.
+        const unsigned uses = (unsigned)((fwd - wp.start) / (u64)kSlots) + 1u;
         unsigned* a = &wp.dc->arrive[slot][shard][0];
-        if (__hip_atomic_fetch_add(a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-            __hip_atomic_store(a, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members * uses - 1u) {
             unsigned* t = &wp.dc->top[slot][0];
-            if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nshards - 1u) {
-                __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                drain_vmem();                                // the counters are back at zero before the host can post step fwd + 8
+            if (__hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nshards * uses - 1u)
                 sys_store64(&wp.mb->done[slot], fwd + 1);
-            }
         }
     }
     fwd += 1;
