@@ -726,6 +726,7 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
         int vl = -1;
         if (f.w1 > rth.vstart) vl = rth.vstart + ((f.w1 - 1 - rth.vstart) / p.rows_per_pass) * p.rows_per_pass;
         const int vstop = max(f.w0, rth.vstart);
+        __builtin_amdgcn_s_setprio(2);                                   // phase A is vector-issue bound: the physics wave of this SIMD (the NEXT steps' integration) yields to it and runs in phases B / C
         typedef unsigned lu4 __attribute__((ext_vector_type(4)));
         auto rowch_of = [&](int v) -> lu4 { return *(const __attribute__((address_space(3))) lu4*)(uintptr_t)(rowch_a + ((unsigned)v << 4)); };
         lu4 rc = rowch_of(max(vl, 0));                                   // this row's palette and row-table entry were requested one row earlier
@@ -775,6 +776,7 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
             atomicAdd(&es[0], (int)sr); atomicAdd(&es[1], (int)sg); atomicAdd(&es[2], (int)sb);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     DYN_STAMP(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(dbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
