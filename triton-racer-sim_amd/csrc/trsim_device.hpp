@@ -653,24 +653,7 @@ __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams
     for (int bi = 0; bi < kDynBatch; ++bi)
 #pragma unroll
         for (int k = 0; k < 4; ++k) cbits[bi][k] = 0u;
-    auto classify4 = [&](int v, const float4& cam) -> unsigned {       // classes of this thread's 4 pixels of row v, 2 bits each
-        const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
-        const f2v rt = lrow[v];
-        const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
-        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);
-        const f2v d = ray_step(kk2, cns);
-        auto cls_of = [&](f2v uf) -> unsigned {
-            const f2v g = __builtin_elementwise_fma(uf, d, a);
-            const unsigned ix = min(cvt_u32_sat(g.x), rth.gwm1);
-            const unsigned iz = min(cvt_u32_sat(g.y), rth.ghm1);
-            unsigned waddr;
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(waddr) : "v"(iz), "s"(rth.pitch), "v"((ix >> 2) & ~3u));
-            const uint32_t w = *(lds_u32p)(uintptr_t)waddr;
-            return __builtin_amdgcn_ubfe(w, ix << 1, 2);
-        };
-        return cls_of(rth.ufa) | (cls_of(rth.ufb) << 2) | (cls_of(rth.ufc) << 4) | (cls_of(rth.ufd) << 6);
-    };
-    // The same classes for TWO envs of one row, in stages: eight map addresses, eight reads in flight, eight extractions.  The scheduling fences keep
+    // The classes of this thread's 4 pixels of a row (2 bits each) for TWO envs, in stages: eight map addresses, eight reads in flight, eight extractions.  The scheduling fences keep
     // the stages apart: left alone (and short of registers in this kernel) hipcc issued one read, waited for it, issued the next - sixteen
     // dependent LDS round trips per row of the batch where this takes two.
     auto classify_pair = [&](const f2v rt, const float4& cam0, const float4& cam1, unsigned& pack0, unsigned& pack1) {
