@@ -596,7 +596,7 @@ __device__ __forceinline__ uint32_t filter_colour_dev(const FParams& f, const un
 #ifndef TRS_DYN_ABLATE
 #define TRS_DYN_ABLATE 0   /* timing-only diagnostic builds (scripts/r04_dyn_ablate.sh), never shipped: 1 no classification in phase A, 2 no filter arithmetic in phase B, 3 no stores in phase C */
 #endif
-#ifdef TRS_DYN_STAMPS   /* diagnostic build (scripts/dyn_stamps.sh), never shipped: s_memtime ticks (100 MHz) of workgroup 7's first raster thread per phase into stats[46..51] */
+#ifdef TRS_DYN_STAMPS   /* diagnostic build (scripts/dyn_stamps.sh), never shipped: s_memtime counts (shader clocks on this part) of workgroup 7's first raster thread per phase into stats[46..50], batches seen into stats[52] */
 #define DYN_STAMP(k) do { if (blockIdx.x == 7 && tid == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); atomicAdd(&p.stats[46 + (k)], tn - dyn_t0); dyn_t0 = tn; } } while (0)
 #else
 #define DYN_STAMP(k) do { } while (0)
