@@ -404,7 +404,7 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
 #endif
 constexpr int kEdgeBlock = 1024;          // 16 waves per frame (512 until round 2: the phases are latency chains of LDS reads, twice the waves hide twice as much)
 constexpr int kEdgeGpt = 5;              // 4-pixel groups per thread held in registers between the two passes over a frame: 5120 groups = 20,480 pixels (120x160: 4800 groups)
-constexpr int kEdgeTables = 512 * 4 + 3 * (kEdgeBlock / 64) * 4 + 16 + 256 * 4 + 3 * 256 * 4;   // s_tab | s_part | s_delta | s_trim | s_rng
+constexpr int kEdgeTables = 512 * 4 + 3 * (kEdgeBlock / 64) * 4 + 16 + 2 * 256 * 4 + 3 * 256 * 4;   // s_tab | s_part | s_delta | s_trim[2] | s_rng
 
 __device__ __forceinline__ bool has_zero_byte(unsigned w) { return ((w - 0x01010101u) & ~w & 0x80808080u) != 0u; }
 
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     unsigned* const s_part = reinterpret_cast<unsigned*>(s_tab + 512);       // [2][3] channel sums of the brightness rows, by frame parity: the waves ADD their totals (LDS atomics;
                                                                              // round 4: the delta phase's 16-lane 64-bit shuffle reductions are gone; < 2^24 per channel)
     float* const s_delta = reinterpret_cast<float*>(s_part + 3 * (kEdgeBlock / 64));
-    unsigned* const s_trim = reinterpret_cast<unsigned*>(s_delta + 4);        // [256] this frame's trim of every byte value
-    unsigned* const s_rng = s_trim + 256;                                    // [3][256] byte ch = 0xFF: value x of component c (h, s, v) lies inside the range of the filter that owns channel ch's mask (mask_pixel)
+    unsigned* const s_trim2 = reinterpret_cast<unsigned*>(s_delta + 4);       // [2][256] the trim of every byte value, by frame parity (the next frame's table is made during this frame's output phase)
+    unsigned* const s_rng = s_trim2 + 512;                                   // [3][256] byte ch = 0xFF: value x of component c (h, s, v) lies inside the range of the filter that owns channel ch's mask (mask_pixel)
     const int tid = threadIdx.x, lane = tid & 63;
     // Every phase takes its thread index through `fresh`: an empty asm the compiler cannot see through, so that what a phase derives from
     // the index (row / column splits, addresses) is computed where it is used.  Left alone, hipcc hoisted those values of ALL phases in
@@ -523,6 +523,24 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
         if (lane == 0) { atomicAdd(&s_part[par * 3], sr); atomicAdd(&s_part[par * 3 + 1], sg); atomicAdd(&s_part[par * 3 + 2], sb); }
     };
+    auto make_trim_table = [&](int par_of_sums, unsigned* table) {           // one thread per byte value (tid < 256): delta from the frame's channel totals, then the trim
+        const int t = fresh(tid);
+        const double cnt = (double)(p.r1 - p.r0) * (double)W;
+        double cur = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const unsigned tot = s_part[par_of_sums * 3 + ch];               // (a uniform LDS read: exact integer totals, any order of the adds)
+            cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
+        }
+        cur = cur + 0.0;
+        const float deltaf = (float)((p.baseline - cur) / 3), off = p.offset, con = p.contrast;
+        float x = (float)t;
+        if (p.dynamic) x = x + deltaf;
+        x = x - off; x = x * con; x = x + off;
+        x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+        table[t] = (unsigned)(int)x;
+    };
+    bool table_ready = false;                                                 // uniform: s_trim2[par] already holds this frame's table (made during the previous frame's output phase)
     if (tid < 6) s_part[tid] = 0u;                                            // (behind the first barrier below before anyone adds)
     int par = 0;                                                              // parity of the current frame of this workgroup
     bool sums_ready = false;                                                  // uniform: s_part already holds this frame's sums
@@ -568,24 +586,12 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         // every thread of the table reads the three totals (the waves added theirs with LDS atomics: exact integers, any order) and evaluates the same
         // binary64 expression: no serial pass by one thread, no barrier for the delta, no reduction in this phase (round 3 reduced 16 partial sums per
         // channel here with 64-bit shuffles)
-        if (tid < 256) {                                                    // this frame's trim of every byte value, in numpy's operation order (:92-99)
-            if (tid < 3) s_part[(par ^ 1) * 3 + tid] = 0u;                   // the NEXT frame's sums start from zero (its adders are behind this phase's barrier)
-            const double cnt = (double)(p.r1 - p.r0) * (double)W;
-            double cur = 0.0;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const unsigned tot = s_part[par * 3 + ch];                  // (a uniform LDS read: exact integer totals, any order of the adds)
-                cur = cur + (cnt > 0 ? (double)tot / cnt : 0.0);
-            }
-            cur = cur + 0.0;
-            const float deltaf = (float)((p.baseline - cur) / 3), off = p.offset, con = p.contrast;
-            float x = (float)tid;
-            if (p.dynamic) x = x + deltaf;
-            x = x - off; x = x * con; x = x + off;
-            x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
-            s_trim[tid] = (unsigned)(int)x;
+        unsigned* const s_trim = s_trim2 + par * 256;
+        if (tid < 3) s_part[(par ^ 1) * 3 + tid] = 0u;                       // the NEXT frame's sums start from zero (their adders are behind the barriers below; that half was last read for the previous frame's table)
+        if (!table_ready) {
+            if (tid < 256) make_trim_table(par, s_trim);                     // this frame's trim of every byte value, in numpy's operation order (:92-99)
+            __syncthreads();
         }
-        __syncthreads();
         EDGE_STAMP(2);
         // ---- trimmed frame -> LDS ----
         for (int c = 0, t = fresh(tid); c < nchunks; ++c) {
@@ -731,6 +737,11 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         // ---- colour masks on the trimmed frame, merge, edge layer last (img_preprocessing.py:43-53) ----
         // (the switch p.color is tested once per group, not per pixel: four independent chains of dependent table lookups then
         // interleave instead of running one after the other)
+        // The NEXT frame's trim table, by the first four waves (one per SIMD), while the other twelve keep the SIMDs busy with this phase: its channel
+        // sums are complete (published in front of the suppression phase, three barriers ago).  Until late round 4 every frame began with this
+        // table and a barrier - 256 threads in a chain of binary64 divisions, 768 waiting: 6 % of the kernel by the phase stamps.
+        table_ready = sums_ready;
+        if (table_ready && tid < 256) make_trim_table(par ^ 1, s_trim2 + (par ^ 1) * 256);
         for (int g = fresh(tid); g < (TRS_EDGE_ABLATE == 4 ? 0 : p.gpe); g += kEdgeBlock) {
             const unsigned* sw = reinterpret_cast<const unsigned*>(simg + (size_t)g * 12);
             const unsigned w0 = sw[0], w1 = sw[1], w2 = sw[2];              // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3, trimmed
