@@ -491,6 +491,18 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
     auto fresh = [](int v) -> int { asm volatile("" : "+v"(v)); return v; };
     const int H = p.H, W = p.W, MP = W + 8, npx = H * W;
     const size_t frame_bytes = (size_t)p.gpe * 12;
+    const int chunk_groups = kEdgeBlock * kEdgeGpt, nchunks = (p.gpe + chunk_groups - 1) / chunk_groups;
+    const bool one_chunk = nchunks == 1;
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t& r, int c, u3v (&R)[kEdgeGpt]) {
+        const int t = fresh(tid);
+#pragma unroll
+        for (int k = 0; k < kEdgeGpt; ++k) R[k] = __builtin_amdgcn_raw_buffer_load_b96(r, (c * chunk_groups + k * kEdgeBlock + t) * 12, 0, 0);   // past the frame: zeros (buffer bounds)
+    };
+    u3v R[kEdgeGpt];                                                          // this thread's groups of the frame (see below)
+    if (one_chunk && (int)blockIdx.x < p.n_img) {                            // the workgroup's FIRST frame is requested before anything else: its memory latency runs under the table set-up below
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)blockIdx.x * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        fetch(r0, 0, R);
+    }
     for (int i = tid; i < 512; i += kEdgeBlock) s_tab[i] = p.hsv_tab[i];
     unsigned sel = 0;                                                        // the channels that carry a mask (a later filter on a channel replaces an earlier one, :57-63)
     for (int i = tid; i < 768; i += kEdgeBlock) s_rng[i] = range_byte_entry(p.lo, p.hi, p.dst_ch, p.n_filters, i, nullptr);
@@ -503,7 +515,6 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
 #else
 #define EDGE_STAMP(k) do { } while (0)
 #endif
-    u3v R[kEdgeGpt];                                                          // this thread's groups of the frame (see below)
     const int chunk_groups0 = kEdgeBlock * kEdgeGpt;
     auto chunk_sums = [&](const u3v (&R)[kEdgeGpt], int c, unsigned& sr, unsigned& sg, unsigned& sb) {   // this thread's groups of chunk c inside the brightness rows
         const int t = fresh(tid);
@@ -561,14 +572,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         // A frame of up to 1024 x kEdgeGpt groups (every frame whose work arrays fit LDS) is read from memory ONCE — both passes work
         // on the registers — and the next frame's loads are issued as soon as the registers are free, in front of the Sobel phase.
         // Larger frames take the passes in chunks of 1024 x kEdgeGpt groups (the second pass reads L2). ----
-        const int chunk_groups = kEdgeBlock * kEdgeGpt, nchunks = (p.gpe + chunk_groups - 1) / chunk_groups;
-        const bool one_chunk = nchunks == 1;
-        auto fetch = [&](const __amdgpu_buffer_rsrc_t& r, int c, u3v (&R)[kEdgeGpt]) {
-            const int t = fresh(tid);
-#pragma unroll
-            for (int k = 0; k < kEdgeGpt; ++k) R[k] = __builtin_amdgcn_raw_buffer_load_b96(r, (c * chunk_groups + k * kEdgeBlock + t) * 12, 0, 0);   // past the frame: zeros (buffer bounds)
-        };
-        if (!(one_chunk && img != (int)blockIdx.x)) fetch(rs, 0, R);        // (one-chunk frames after the first: prefetched during the previous frame)
+        if (!one_chunk) fetch(rs, 0, R);                                    // (one-chunk frames: the first was requested at the kernel's start, the others during the previous frame)
         // ---- channel sums over the brightness rows -> delta (as trs_preprocess_kernel) ----
         // (one-chunk frames after the first: the sums were taken from the prefetched registers in the middle of the previous frame, see below -
         // this phase and its barrier were 12 % of the kernel, most of it waves waiting for each other right after the previous frame's last phase)
@@ -653,6 +657,7 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
             sums_ready = true;
         }
         // ---- non-maximum suppression + double threshold: map <- 0 = weak / 1 = no / 2 = edge ----
+        int weak_here = 0;                                                   // this thread wrote a weak pixel (0) in the phase below
         // Branch-free, two pixels per instruction (hipcc turned the per-pixel choice of neighbours into divergent branches with LDS reads
         // inside them: 133 instructions per pixel).  A comparison a < b of two magnitudes (0 .. 2040) is the sign bit of the 16-bit
         // difference a - b; the magnitudes arrive packed two per dword, so v_pk_sub_i16 compares a PAIR of pixels with their
@@ -700,9 +705,11 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                     out4 |= ((h & 0xFFu) | ((h >> 8) & 0xFF00u)) << (16 * pr);
                 }
                 *reinterpret_cast<unsigned*>(map + (size_t)g * 4) = out4;
+                weak_here |= has_zero_byte(out4) ? 1 : 0;                    // (a group past the frame's end does not come here)
             }
         }
-        __syncthreads();
+        // the barrier behind the suppression phase is a vote: a frame without a single weak pixel (0) has no hysteresis to run - no sweep, no barrier of its own
+        const bool frame_has_weak = __syncthreads_or(weak_here) != 0;
         EDGE_STAMP(5);
         // ---- hysteresis: weak pixels 8-connected to an edge become edges.  A thread owns a contiguous run of pixels and walks it
         // forwards, then backwards: a chain along a row closes in one sweep instead of one pixel per sweep (the closure does not
@@ -720,15 +727,21 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
                 if (hit) map[px] = 2;
                 return hit ? 1 : 0;
             };
-            for (int iter = 0; iter < (TRS_EDGE_ABLATE == 3 ? 0 : npx); ++iter) {
+            for (int iter = 0; iter < (TRS_EDGE_ABLATE == 3 || !frame_has_weak ? 0 : npx); ++iter) {
                 int changed = 0;
-                for (int q = s0; q < s1; q += 4) {
-                    if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
-                    for (int k = 0; k < 4; ++k) if (map[q + k] == 0) changed |= visit(q + k);
-                }
-                for (int q = s1 - 4; q >= s0; q -= 4) {
-                    if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
-                    for (int k = 3; k >= 0; --k) if (map[q + k] == 0) changed |= visit(q + k);
+                // A strip without a weak pixel (almost every strip) has nothing to do in either direction: its words are read TOGETHER first (one LDS
+                // round trip) - the two walks below read them one after the other behind a branch each (ten dependent round trips per sweep).
+                bool any_weak = false;
+                for (int q = s0; q < s1; q += 4) any_weak |= has_zero_byte(*reinterpret_cast<const unsigned*>(map + q));
+                if (any_weak) {
+                    for (int q = s0; q < s1; q += 4) {
+                        if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
+                        for (int k = 0; k < 4; ++k) if (map[q + k] == 0) changed |= visit(q + k);
+                    }
+                    for (int q = s1 - 4; q >= s0; q -= 4) {
+                        if (!has_zero_byte(*reinterpret_cast<const unsigned*>(map + q))) continue;
+                        for (int k = 3; k >= 0; --k) if (map[q + k] == 0) changed |= visit(q + k);
+                    }
                 }
                 if (!__syncthreads_or(changed)) break;
             }
