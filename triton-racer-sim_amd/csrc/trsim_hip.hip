@@ -343,9 +343,8 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
             sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
             sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-        if (lane == 0) { s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb; }
+        sr = wave_sum_dpp(sr); sg = wave_sum_dpp(sg); sb = wave_sum_dpp(sb);   // (DPP: totals in lane 63)
+        if (lane == 63) { s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb; }
         __syncthreads();
         if (tid < 256) {                                                    // every thread of the table evaluates the same binary64 expression itself (exact integer
             const double cnt = (double)(p.r1 - p.r0) * (double)p.W;         // totals, any order): no serial pass by one thread, no barrier for the delta (round 3)
@@ -530,9 +529,8 @@ __global__ __launch_bounds__(kEdgeBlock) void trs_preprocess_edge_kernel(const P
         }
     };
     auto publish_sums = [&](unsigned sr, unsigned sg, unsigned sb, int par) {  // wave totals -> s_part[par] (read by the delta phase behind a barrier)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { sr += __shfl_down(sr, off, 64); sg += __shfl_down(sg, off, 64); sb += __shfl_down(sb, off, 64); }
-        if (lane == 0) { atomicAdd(&s_part[par * 3], sr); atomicAdd(&s_part[par * 3 + 1], sg); atomicAdd(&s_part[par * 3 + 2], sb); }
+        sr = wave_sum_dpp(sr); sg = wave_sum_dpp(sg); sb = wave_sum_dpp(sb);   // (DPP: the wave's totals end in lane 63; the ds_bpermute shuffles were six dependent LDS round trips per frame)
+        if (lane == 63) { atomicAdd(&s_part[par * 3], sr); atomicAdd(&s_part[par * 3 + 1], sg); atomicAdd(&s_part[par * 3 + 2], sb); }
     };
     auto make_trim_table = [&](int par_of_sums, unsigned* table) {           // one thread per byte value (tid < 256): delta from the frame's channel totals, then the trim
         const int t = fresh(tid);
