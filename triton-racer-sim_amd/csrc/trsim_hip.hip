@@ -300,6 +300,12 @@ __device__ __forceinline__ u3v pack_rgb4(unsigned P0, unsigned P1, unsigned P2, 
 
 __device__ __forceinline__ unsigned sum_bytes(unsigned w, unsigned mask, unsigned acc) { return __builtin_amdgcn_sad_u8(w & mask, 0u, acc); }
 
+constexpr int kPreGpt = 19;   // 4-pixel groups a thread of trs_preprocess_kernel can hold between its two passes (dynamic brightness): 4,800 groups on 256 threads, 19,200 on 1024
+
+// REGS: the instantiation that may hold a frame in registers between its two passes (dynamic brightness, see below and trs_preprocess's dispatch); the other
+// one keeps 42 registers per thread - the occupancy the single-pass variants and the mask arithmetic live on (with the frame in registers: trim 21.5 -> 22.4 us
+// per 1024 frames, trim + HSV masks 29.5 -> 30.2, and + 11 % on 1024-thread workgroups with masks; profiles/r04_image_path_regs.txt).
+template <bool REGS>
 __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)   // 256 threads per frame at 120x160, 1024 for frames of 8,192+ pixel groups
 {
     __shared__ int s_tab[512];
@@ -333,15 +339,37 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
     for (int img = blockIdx.x; img < p.n_img; img += gridDim.x) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.src) + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dst + (size_t)img * frame_bytes, 0, (int)frame_bytes, 0x00020000);
+        // Dynamic brightness needs the frame's own mean before its first pixel can be trimmed.  Where the frame fits the workgroup's registers (at most
+        // kPreGpt groups per thread: 120x160 on 256 threads, 240x320 on 1024) it is read from memory ONCE - every load in flight together - and both the
+        // channel sums and the second pass work on the registers (round 4, late: the sums pass used to read the brightness rows from memory and the
+        // second pass the whole frame again: 6 of this variant's 36 us per 1024 frames).  Larger frames keep the two passes over memory.
+        const bool in_regs = REGS && p.dynamic && (p.gpe + nthreads - 1) / nthreads <= kPreGpt;
+        u3v R[REGS ? kPreGpt : 1];
+        if constexpr (REGS) {
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < kPreGpt; ++k) R[k] = __builtin_amdgcn_raw_buffer_load_b96(rs, (tid + k * nthreads) * 12, 0, 0);   // past the frame: zeros (the descriptor's bounds)
+            }
+        }
         if (p.dynamic) {
         // ---- pass 1: channel sums over the brightness rows ----
         unsigned sr = 0, sg = 0, sb = 0;
-        for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += nthreads) {
-            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+        auto add_group = [&](const u3v w) {
             // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3
             sr = sum_bytes(w.x, 0xFF0000FFu, sr); sr = sum_bytes(w.y, 0x00FF0000u, sr); sr = sum_bytes(w.z, 0x0000FF00u, sr);
             sg = sum_bytes(w.x, 0x0000FF00u, sg); sg = sum_bytes(w.y, 0xFF0000FFu, sg); sg = sum_bytes(w.z, 0x00FF0000u, sg);
             sb = sum_bytes(w.x, 0x00FF0000u, sb); sb = sum_bytes(w.y, 0x0000FF00u, sb); sb = sum_bytes(w.z, 0xFF0000FFu, sb);
+        };
+        if (in_regs) {
+            if constexpr (REGS) {
+#pragma unroll
+                for (int k = 0; k < kPreGpt; ++k) {
+                    const int g = tid + k * nthreads;
+                    if (g >= p.r0 * p.gpr && g < p.r1 * p.gpr) add_group(R[k]);
+                }
+            }
+        } else {
+            for (int g = p.r0 * p.gpr + tid; g < p.r1 * p.gpr; g += nthreads) add_group(__builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0));
         }
         sr = wave_sum_dpp(sr); sg = wave_sum_dpp(sg); sb = wave_sum_dpp(sb);   // (DPP: totals in lane 63)
         if (lane == 63) { s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb; }
@@ -362,8 +390,7 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
         // ---- pass 2: trim, masks, merge ----
         // (p.color is tested once per 4-pixel group, not per pixel: the four pixels' chains of dependent table lookups — trim, OpenCV's
         // reciprocal tables, the range bits — then interleave instead of running one behind the other)
-        for (int g = tid; g < p.gpe; g += nthreads) {
-            const u3v w = __builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0);
+        auto out_group = [&](const u3v w, int g) {
             // bytes: w.x = R0 G0 B0 R1 | w.y = G1 B1 R2 G2 | w.z = B2 R3 G3 B3 -> four trimmed pixels (r, g, b, 0)
             auto tr = [&](unsigned word, int k) -> unsigned { return s_trim[(word >> (8 * k)) & 255u]; };
             const unsigned t00 = tr(w.x, 0), t01 = tr(w.x, 1), t02 = tr(w.x, 2), t10 = tr(w.x, 3), t11 = tr(w.y, 0), t12 = tr(w.y, 1);
@@ -377,7 +404,18 @@ __global__ __launch_bounds__(1024) void trs_preprocess_kernel(const PreParams p)
                 P2 = t20 | (t21 << 8) | (t22 << 16); P3 = t30 | (t31 << 8) | (t32 << 16);
             }
             const u3v out = pack_rgb4(P0, P1, P2, P3);
-            __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b96(out, rd, g * 12, 0, 0);                         // (a group past the frame: dropped by the descriptor's bounds)
+        };
+        if (in_regs) {
+            if constexpr (REGS) {
+#pragma unroll
+                for (int k = 0; k < kPreGpt; ++k) {
+                    const int g = tid + k * nthreads;
+                    if (g < p.gpe) out_group(R[k], g);
+                }
+            }
+        } else {
+            for (int g = tid; g < p.gpe; g += nthreads) out_group(__builtin_amdgcn_raw_buffer_load_b96(rs, g * 12, 0, 0), g);
         }
         if (p.dynamic) __syncthreads();   // s_part / s_trim are rewritten for the next frame of this workgroup
     }
@@ -1796,7 +1834,8 @@ TRS_EXPORT int trs_preprocess(trs_env* e, const trs_pre_config* c, const uint8_t
     }
     const int block = p.gpe >= 8192 ? 1024 : 256;                          // large frames: more waves per frame (one workgroup per frame cannot fill the chip otherwise)
     const int grid = std::min(n_images, e->cu_count * (block == 256 ? 8 : 2));
-    hipLaunchKernelGGL(trs_preprocess_kernel, dim3(grid), dim3(block), 0, e->sP, p);
+    if (p.dynamic && (!p.color || block == 256)) hipLaunchKernelGGL(trs_preprocess_kernel<true>, dim3(grid), dim3(block), 0, e->sP, p);   // the frame held in registers between the sums and the trim (with the masks' arithmetic only on 256-thread workgroups: on 1024 threads the registers cost more occupancy than the second read)
+    else hipLaunchKernelGGL(trs_preprocess_kernel<false>, dim3(grid), dim3(block), 0, e->sP, p);
     HIPCHK(hipGetLastError());
     return TRS_OK;
 }
