@@ -238,6 +238,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class phase:
+    """``with phase("name", seconds):`` — a phase of a multi-rank run that can only stall on ANOTHER rank (rendezvous, barrier, collective).  When it
+    takes longer than ``seconds`` the rank says which phase it is stuck in and exits with code 3 (the launcher then stops the other ranks): no silent
+    wait for torch.distributed's own timeout.  At world size 1 nothing can stall on a peer; the guard is the same code all the same."""
+    def __init__(self, name, seconds, rank=None):
+        self.name, self.seconds = name, float(seconds)
+        self.rank = os.environ.get("RANK", "0") if rank is None else rank
+
+    def _expired(self):
+        sys.stderr.write(f"bench.py: rank {self.rank} stalled in phase '{self.name}' for more than {self.seconds:.0f} s; giving up (exit 3)\n")
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        import threading
+        self.t = threading.Timer(self.seconds, self._expired)
+        self.t.daemon = True
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+PHASE_S = float(os.environ.get("TRS_BENCH_PHASE_S", "120"))     # how long a rendezvous / barrier / collective may take before the rank gives up
+
+
 def launch_ranks(n_ranks, argv):
     """Parent of a self-launched run: one child process per rank (= per GPU), each running THIS file with the environment
     torch.distributed.run would give it.  The parent imports neither torch nor the HIP library and never touches a GPU (a process that
@@ -254,7 +282,10 @@ def launch_ranks(n_ranks, argv):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), TRS_BENCH_LAUNCHER="self")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
+        # dmabuf IPC.  Source: this pool's environment notes (the image exports it; "the host driver only supports dmabuf IPC, and without it RCCL /
+        # device-tensor sharing across processes fails with hipIpcGetMemHandle: invalid argument") — NOT a run of ours: no N > 1 RCCL run has been
+        # possible on the one-GPU boxes this repo is built on.  setdefault: an environment that sets it otherwise is left alone.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
 
     def relay(proc):
@@ -353,13 +384,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.share_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            with phase("init_process_group(gloo)", PHASE_S):
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=PHASE_S + 30))
             host_group = dist.group.WORLD
         else:
             # device collectives (the one all-gather): nccl = RCCL over xGMI.  Barriers and the MAX over ranks: a gloo group, i.e. host
             # sockets — a barrier must not need CU resources while every CU holds a resident worker
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
-            host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+            with phase("init_process_group(nccl)", PHASE_S):
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=PHASE_S + 30))
+            with phase("new_group(gloo)", PHASE_S):
+                host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=PHASE_S + 30))
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"rank {rank}: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     if args.envs_per_gpu is not None and args.total_envs is not None:
         sys.exit("give --envs-per-gpu or --total-envs, not both")
@@ -392,11 +428,9 @@ def main():
         run = lambda k_: env.step_synthetic(k_, spl)
     # the pilot loop goes through launches (the pilot's kernels need the CUs' LDS); physics-only envs have their own resident worker since round 4
     resident = bool((args.resident or args.step_mode == "resident") and not args.pilot and spl == 1)
-    if args.share_gpu:
-        # Rehearsal with several ranks on ONE GPU: their resident workers cannot be on the GPU together (each needs a workgroup slot with ~126 KB of LDS
-        # on every CU).  Two workers that each hold a part of the CUs wait for the rest until the 2 s safety gives up ("resident worker gave up", seen in
-        # round 4).  The rehearsal is about the N > 1 code path of THIS file, so the ranks step by launches; one GPU per rank (the real run) is resident.
-        resident = False
+    # (--share-gpu: several ranks on ONE GPU.  Their resident workers cannot be on the GPU together; since round 5 the library arbitrates — a launch that does
+    # not get the whole GPU is called off and that rank steps by launches until its next try, workers leave every 50 ms — so the rehearsal runs the
+    # resident path like the real run; round 4 had to rehearse with launches: "resident worker gave up", gpurun_out/r04_full_2.log.)
     if resident:
         # idle_us: the worker leaves by itself after this long without a post.  The library's default (2 ms) suits an interactive loop; a
         # benchmark whose host thread can be descheduled for milliseconds (a tracer attached, the GIL) would see its worker leave and be
@@ -411,14 +445,19 @@ def main():
     # every rank (steady state: what a consumer that keeps posting sees).
     def host_barrier():
         if dist is not None:
-            dist.barrier(group=host_group)
+            with phase("host barrier (gloo)", PHASE_S):
+                dist.barrier(group=host_group)
 
     stream_sync = (lambda: torch.cuda.current_stream().synchronize()) if resident else torch.cuda.synchronize
 
     if dist is not None and not args.share_gpu:   # warm the communicator (RCCL: connection set-up over xGMI) before any worker is resident
-        warm = torch.zeros(n * world, device="cuda")
-        dist.all_gather_into_tensor(warm, torch.zeros(n, device="cuda"))
-        torch.cuda.synchronize()
+        with phase("warm-up all-gather (RCCL connection set-up)", PHASE_S):
+            warm = torch.zeros(n * world, device="cuda")
+            dist.all_gather_into_tensor(warm, torch.full((n,), float(rank + 1), device="cuda"))
+            torch.cuda.synchronize()
+        seen = sorted(set(warm.cpu().tolist()))
+        if seen != [float(r + 1) for r in range(world)]:
+            sys.exit(f"rank {rank}: the warm-up all-gather returned contributions {seen[:16]}, expected one per rank 1..{world}")
     # An idle MI355X takes ~25-40 ms of work to raise its clocks: the first 2,000 steps of a fresh process run 12-14 % slower than the
     # steady state (profiles/r03_steady_state.txt: 10.85 us per step, then 9.46-9.58).  The metric is a steady-state rate, and
     # the driver's --warmup 5 is 50 us, so the clocks are brought up first — with untimed steps of the same workload, for PREWARM_S
@@ -443,8 +482,12 @@ def main():
     # so it closes the job here, timed on its own, not inside the K timed steps (a resident worker is asked to leave first, outside the timing)
     gathered, allgather_s = None, None
     if dist is not None:
-        gathered, allgather_s = shard.allgather_timed("ep_return", host_barrier, torch.cuda.synchronize)
-        allgather_s = max_over_ranks(allgather_s, host_group)
+        with phase("all-gather of ep_return", PHASE_S):
+            gathered, allgather_s = shard.allgather_timed("ep_return", host_barrier, torch.cuda.synchronize)
+        with phase("MAX over ranks (gloo)", PHASE_S):
+            allgather_s = max_over_ranks(allgather_s, host_group)
+        if gathered.numel() != n * world:
+            sys.exit(f"rank {rank}: the all-gather returned {gathered.numel()} values, expected {n} x {world}")
         mine = torch.as_tensor(env.fetch("ep_return"))
         if not torch.equal(gathered.cpu()[shard.base:shard.base + n], mine):
             sys.exit(f"rank {rank}: the gathered returns do not hold this shard's values at [{shard.base}, {shard.base + n})")
@@ -458,6 +501,10 @@ def main():
         env.event_record(1)
         env.sync()
     kernel_ms = env.event_elapsed_ms(0, 1)
+    if dist is not None:
+        with phase("MAX of the event time over ranks (gloo)", PHASE_S):
+            kernel_ms = max_over_ranks(kernel_ms, host_group)        # (rank 0's own event time x world was not the job's)
+    mode_after = env.step_mode()
 
     # informational only (never part of `value`): the same workload with 8 steps per launch, timed separately
     also = None
@@ -717,13 +764,19 @@ def main():
             line["value_incl_worker_launch"] = round(n * world * args.steps / avg_launch_s, 1)
             line["roofline"]["covers"] = "one whole worker launch (start-up + K steps + exit) by HIP events; `value` and frac_by_wall_clock cover the K steps alone, worker resident"
         if gathered is not None:
-            line["allgather"] = {"us": round(allgather_s * 1e6, 1), "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+            line["allgather"] = {"us": round(allgather_s * 1e6, 1), "ranks": dist.get_world_size(), "values": int(gathered.numel()), "backend": dist.get_backend(),
                                  "floats_per_rank": n, "returns_mean": round(float(gathered.float().mean().item()), 4),
                                  "note": "ONE all-gather of ep_return closes the job (configs[3]: one per 1000 steps), timed on its own after the K steps: "
                                          "[worker asked to leave, host barrier] t0 - all_gather_into_tensor - device synchronisation t1, MAX over ranks; never inside `value`"}
             line["config"]["allgather_returns_mean"] = line["allgather"]["returns_mean"]
+        if resident:
+            line["config"]["step_mode_at_end"] = {"mode": mode_after[0], "fell_back_to_launches": mode_after[1]}   # (trs_get_step_mode: a rank that had to share its GPU says so)
+        if world > 1:
+            line["config"]["n_gt_1_status"] = ("REHEARSAL on one GPU" if args.share_gpu else "nccl + gloo groups, resident workers, one RCCL all-gather") + \
+                "; the N > 1 resident path had never run on N GPUs when this file was written (one-GPU boxes only): unmeasured on hardware until the driver's run"
         if args.share_gpu:
-            line["config"]["rehearsal"] = f"{world} ranks SHARING GPU 0 over gloo: a rehearsal of the N > 1 code path, not a measurement (the ranks step by launches: two resident workers cannot share a GPU)"
+            line["config"]["rehearsal"] = (f"{world} ranks SHARING GPU 0 over gloo: a rehearsal of the N > 1 code path, not a measurement (resident mode selected on every rank; "
+                                           "the library lets one worker at a time have the GPU: the ranks take turns of <= 50 ms or step by launches)")
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(min(n, 1024), args.img_h, args.img_w) if render else None
             if cb:

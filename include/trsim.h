@@ -163,12 +163,27 @@ int trs_step_sequence_host(trs_env* env, const float* h_steering, const float* h
  *     the same mailbox and completion flags; a tick costs a post instead of a launch).  Every frame filter of trs_set_frame_filter is rendered by the worker (the dynamic-brightness one by its own
  *     instantiation since round 3).
  *     Kernels of other streams that need more than ~35 KB of LDS per workgroup cannot start while the worker is resident.
- *     ONE resident worker per GPU at a time: a worker needs a workgroup slot with most of the LDS on every CU, so the workers of two handles (or of two
- *     processes) on the same GPU cannot be resident together — the second starts when the first has left (idle_us without a post, trs_quiesce), and
- *     two that are launched against each other while both keep receiving posts can each end up holding a part of the CUs: both then wait until the
- *     2 s safety gives up (TRS_ERR_DEVICE "resident worker gave up").  Sharded runs give every handle its own GPU. */
+ *     ONE resident worker per GPU at a time — a worker needs every workgroup of its grid on the GPU at once, one slot with most of the LDS per
+ *     CU — and the library arbitrates (round 5; the reference's independent GymInterface instances simply work side by side,
+ *     components/gyminterface.py:49-76):
+ *       - handles of ONE process (any threads): the handle whose step needs a worker takes the GPU over; the other handle's worker finishes what
+ *         was posted to it and leaves first.  Alternating handles cost a worker start per alternation (tens of microseconds), never idle_us and
+ *         never an error; results are those of each handle stepped alone.  The host side of resident mode is serialised per GPU by a lock.
+ *       - ANOTHER process's worker on the same GPU cannot be asked to leave.  A worker launch that does not get its whole grid onto the GPU
+ *         notices within 2-4 ms (every workgroup reports in before the first post is taken), consumes nothing and leaves; a launch that has not
+ *         started at all after 250 ms is cancelled.  In both cases the handle goes back to TRS_STEP_LAUNCH by itself: the posted steps run as
+ *         launches, the call returns TRS_OK, trs_last_error() carries a note and trs_get_step_mode reports it.  No 2 s stall, no broken handle.
+ *         Resident mode is tried again by itself 100 ms later (doubling up to 2 s while the GPU stays shared).  A worker leaves after 50 ms
+ *         whatever happens and is started again by the next post: the gap is where the other process's kernels (its launches, or its own
+ *         worker) get the CUs, so processes that keep a shared GPU busy take turns of 50 ms.
+ *       - physics-only handles: ceil(n_envs / 4) workgroups must fit the GPU at once (a few thousand envs); trs_set_step_mode returns
+ *         TRS_ERR_LIMIT with the capacity beyond that (use TRS_STEP_LAUNCH with several steps per launch for such shards). */
 enum { TRS_STEP_LAUNCH = 0, TRS_STEP_RESIDENT = 1 };
 int trs_set_step_mode(trs_env* env, int mode, int idle_us);
+/* The handle's step mode now (either pointer may be NULL).  *fell_back = 1: resident mode had been selected and the library went back to
+ * TRS_STEP_LAUNCH by itself because a worker launch was not co-resident (the GPU is shared with another process's worker, see above);
+ * the library tries resident mode again by itself (100 ms later, doubling up to 2 s), trs_set_step_mode(TRS_STEP_RESIDENT) does so at once. */
+int trs_get_step_mode(trs_env* env, int* mode, int* fell_back);
 /* Resident mode only (a no-op otherwise): the worker leaves the GPU now — every posted step is complete in memory when the call
  * returns — and the next posted step starts a new one.  For a caller about to run work of ANOTHER stream or library that needs
  * the CUs the worker occupies (one workgroup slot and most of the LDS on every CU): a collective, a large kernel.  The step mode
@@ -179,7 +194,7 @@ int trs_quiesce(trs_env* env);
 int trs_step_wait(trs_env* env, const float* d_steering, const float* d_throttle, const float* d_brake_or_null, const uint8_t* d_reset_or_null, int n_steps);
 /* ---- test hooks of the resident worker: UNSTABLE, not part of the drop-in surface (no reference interface stands behind them; they exist so
  * that tests/test_resident.py can force the worker's rare paths).  trs_resident_debug_lifetime: a worker leaves by itself after life_us
- * microseconds (default 500,000; <= 0 restores it) and the next post starts a new one — many worker generations under load.  Needs
+ * microseconds (default 50,000; <= 0 restores it) and the next post starts a new one — many worker generations under load.  Needs
  * trs_set_step_mode first.  trs_resident_debug_abort: sets the running worker's abort bit from outside, as a wave does whose bounded wait gave up:
  * every wave must leave within its next poll and the next call must fail with TRS_ERR_DEVICE ("resident worker gave up") instead of hanging. */
 int trs_resident_debug_lifetime(trs_env* env, int life_us);

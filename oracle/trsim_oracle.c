@@ -625,6 +625,7 @@ EXPORT int trso_stream_signal_external(trs_env* e, void* s) { (void)s; return e 
 EXPORT int trso_step_wait(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int n) { return trso_step(e, st, th, br, rs, n); }   /* synchronous anyway */
 EXPORT int trso_quiesce(trs_env* e) { return e ? TRS_OK : TRS_ERR_ARG; }   /* nothing is ever resident here */
 EXPORT int trso_set_step_mode(trs_env* e, int mode, int idle_us) { (void)idle_us; if (!e) return TRS_ERR_ARG; return (mode == 0 || mode == 1) ? TRS_OK : TRS_ERR_ARG; }
+EXPORT int trso_get_step_mode(trs_env* e, int* mode, int* fell_back) { if (!e) return TRS_ERR_ARG; if (mode) *mode = 0; if (fell_back) *fell_back = 0; return TRS_OK; }
 EXPORT int trso_event_record(trs_env* e, int slot) { (void)e; (void)slot; return TRS_OK; }
 EXPORT int trso_event_elapsed_ms(trs_env* e, int a, int b, float* ms) { (void)e; (void)a; (void)b; if (ms) *ms = 0.0f; return TRS_OK; }
 EXPORT int trso_device_count(int* out) { if (out) *out = 0; return TRS_OK; }

@@ -59,9 +59,10 @@ def test_bench_self_launch_on_the_gpu():
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal_sharing_the_gpu():
     """The N > 1 branch of bench.py end to end on the one GPU of this box: two self-launched ranks, each with its own shard, K steps between host
-    barriers, MAX over ranks, one all-gather timed on its own.  Both ranks share GPU 0, so the group is gloo (RCCL refuses two ranks on one device),
-    the ranks step by launches (two resident workers cannot be on one GPU together: each needs most of every CU's LDS — with both resident the
-    rehearsal failed one run in three with "resident worker gave up") and the value is not a measurement — the line says so."""
+    barriers, MAX over ranks, one all-gather timed on its own.  Both ranks share GPU 0, so the group is gloo (RCCL refuses two ranks on one device)
+    and the value is not a measurement — the line says so.  Both ranks select RESIDENT mode, as the real run does: the library lets one worker at a
+    time have the GPU (round 5: a launch that does not get the whole GPU is called off and that rank steps by launches until its next try; round 4
+    failed here with "resident worker gave up", gpurun_out/r04_full_2.log, and had to rehearse with launches)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5", "--total-envs", "512"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -73,6 +74,8 @@ def test_bench_two_ranks_rehearsal_sharing_the_gpu():
     ag = d["allgather"]
     assert ag["ranks"] == 2 and ag["floats_per_rank"] == 256 and ag["us"] > 0 and ag["backend"] == "gloo"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "cpu_baseline" not in d
+    assert ag["values"] == 512 and "unmeasured on hardware" in d["config"]["n_gt_1_status"]
+    assert d["config"]["step_mode"].startswith("resident") and d["config"]["step_mode_at_end"]["mode"] in ("resident", "launch")
 
 
 @pytest.mark.gpu

@@ -71,7 +71,7 @@ FIELDS = {
 # every symbol include/trsim.h declares (suffix after the prefix)
 SYMBOLS = [
     "default_config", "create", "destroy", "load_track", "reset", "step", "step_host", "step_synthetic", "step_sequence", "step_sequence_host",
-    "set_step_mode", "quiesce", "step_wait", "get_state", "copy_to_host", "fetch_outputs", "set_pose", "locate", "map_info_get", "sync", "event_record",
+    "set_step_mode", "get_step_mode", "quiesce", "step_wait", "get_state", "copy_to_host", "fetch_outputs", "set_pose", "locate", "map_info_get", "sync", "event_record",
     "event_elapsed_ms", "device_count", "last_error",
     "default_pre_config", "preprocess", "preprocess_host", "set_frame_filter", "normalize", "normalize_host",
     "driver_assist", "driver_assist_host",
@@ -144,6 +144,7 @@ class Api:
             "step_sequence": (i32, [vp, fp, fp, fp, u8p, i32, i32]),
             "step_sequence_host": (i32, [vp, fp, fp, fp, u8p, i32, i32]),
             "set_step_mode": (i32, [vp, i32, i32]),
+            "get_step_mode": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
             "quiesce": (i32, [vp]),
             "step_wait": (i32, [vp, fp, fp, fp, u8p, i32]),
             "get_state": (i32, [vp, C.POINTER(TrsStateView)]),

@@ -63,10 +63,15 @@ struct trs_env {
 // ---- trsim_resident.hip (the resident worker: one step per trs_step call without a launch per step) ----
 namespace trsim {
 bool resident_on(const trs_env* e);                       // resident mode selected for this handle
+void resident_retry(trs_env* e);                          // a handle that fell back to launches (GPU shared with another process) tries resident mode again when due
 // hand n steps to the worker; controls as in trs_step (device pointers, or host-pinned pointers the device can read);
 // stride: elements between consecutive steps' control arrays (0 = held), synth: controls from the spec's generator
-int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride);
-int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps);
+// Both return TRS_OK, an error (< 0) or kResidentFellBack (> 0, not an error): the worker's launch was found not co-resident (another process's
+// worker on the GPU), the handle is back in TRS_STEP_LAUNCH, the first *n_done steps of the call are on the stream as launches and the caller
+// launches the rest itself.
+constexpr int kResidentFellBack = 1;
+int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride, int* n_done);
+int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps, int* n_done);
 hipStream_t resident_copy_stream(trs_env* e);             // a stream that is not blocked by the worker (the handle's own when none runs)
 int resident_wait(trs_env* e);                            // every posted step complete (the worker stays resident)
 int resident_quiesce(trs_env* e);                         // ... and the worker has left the GPU: the stream is free again

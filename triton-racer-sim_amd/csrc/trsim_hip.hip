@@ -1359,7 +1359,14 @@ TRS_EXPORT int trs_step(trs_env* e, const float* d_st, const float* d_th, const 
     if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
-    if (resident_steps(e)) return trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, 0);
+    trsim::resident_retry(e);
+    if (resident_steps(e)) {
+        int done = 0;
+        const int rc = trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, 0, &done);
+        if (rc != trsim::kResidentFellBack || done == n_steps) return rc < 0 ? rc : TRS_OK;
+        n_steps -= done;                                     // the handle went back to launch mode (trs_last_error() says why): the rest of the call by launches
+        if (done) d_rs = nullptr;
+    }
     { int rq = quiesce(e); if (rq) return rq; }
     // held controls; the reset request applies to the first step only
     return e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, n_steps)
@@ -1372,7 +1379,14 @@ TRS_EXPORT int trs_step_host(trs_env* e, const float* h_st, const float* h_th, c
     if (n_steps < 1) return fail(TRS_ERR_ARG, "n_steps < 1");
     if (!h_st || !h_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
-    if (resident_steps(e)) return trsim::resident_post_host(e, h_st, h_th, h_br, h_rs, n_steps);
+    trsim::resident_retry(e);
+    if (resident_steps(e)) {
+        int done = 0;
+        const int rc = trsim::resident_post_host(e, h_st, h_th, h_br, h_rs, n_steps, &done);
+        if (rc != trsim::kResidentFellBack || done == n_steps) return rc < 0 ? rc : TRS_OK;
+        n_steps -= done;
+        if (done) h_rs = nullptr;
+    }
     { int rq = quiesce(e); if (rq) return rq; }
     const size_t n = (size_t)e->n;
     e->h2d_bytes += n * 8 + (h_br ? n * 4 : 0) + (h_rs ? n : 0);
@@ -1389,7 +1403,16 @@ TRS_EXPORT int trs_step_sequence(trs_env* e, const float* d_st, const float* d_t
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     if (!d_st || !d_th) return fail(TRS_ERR_ARG, "null controls");
     HIPCHK(hipSetDevice(e->device));
-    if (resident_steps(e)) return trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, (size_t)e->n);
+    trsim::resident_retry(e);
+    if (resident_steps(e)) {
+        int done = 0;
+        const int rc = trsim::resident_post(e, d_st, d_th, d_br, d_rs, 0, n_steps, (size_t)e->n, &done);
+        if (rc != trsim::kResidentFellBack || done == n_steps) return rc < 0 ? rc : TRS_OK;
+        const size_t co = (size_t)done * (size_t)e->n;
+        d_st += co; d_th += co; if (d_br) d_br += co;
+        n_steps -= done;
+        if (done) d_rs = nullptr;
+    }
     { int rq = quiesce(e); if (rq) return rq; }
     e->seq_stride = e->n;
     const int rc = e->cfg.render ? run_camera_steps(e, d_st, d_th, d_br, d_rs, 0, n_steps, steps_per_launch)
@@ -1425,7 +1448,13 @@ TRS_EXPORT int trs_step_synthetic(trs_env* e, int n_steps, int steps_per_launch)
     if (!e || !e->track_loaded) return fail(TRS_ERR_STATE, "no track loaded");
     if (n_steps < 1 || steps_per_launch < 1) return fail(TRS_ERR_ARG, "n_steps / steps_per_launch < 1");
     HIPCHK(hipSetDevice(e->device));
-    if (resident_steps(e)) return trsim::resident_post(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, 0);
+    trsim::resident_retry(e);
+    if (resident_steps(e)) {
+        int done = 0;
+        const int rc = trsim::resident_post(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, 0, &done);
+        if (rc != trsim::kResidentFellBack || done == n_steps) return rc < 0 ? rc : TRS_OK;
+        n_steps -= done;
+    }
     { int rq = quiesce(e); if (rq) return rq; }
     return e->cfg.render ? run_camera_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch)
                          : run_physics_steps(e, nullptr, nullptr, nullptr, nullptr, 1, n_steps, steps_per_launch);
@@ -2122,6 +2151,17 @@ int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, c
     if (!rc) trsim::resident_note_launch(e);               // resident mode selected: this step has no completion flag, trs_sync / the copies wait for the stream
     return rc;
 }
+int trs_internal_replay_launch(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, uint64_t step)
+{
+    if (e->cfg.render) return launch_step(e, st, th, br, rs, synth, 1, 0, 0, step);
+    PParams p = e->pp;
+    p.ctl_steer = st; p.ctl_thr = th; p.ctl_brk = br; p.ctl_reset = rs; p.ctl_stride = 0;
+    p.synth = synth; p.n_steps = 1; p.write_cam = 0; p.step_off = (uint32_t)step;
+    hipLaunchKernelGGL(trs_physics_kernel, dim3((e->n + kPhysBlock / 64 - 1) / (kPhysBlock / 64)), dim3(kPhysBlock), e->lds_p, e->sP, p);
+    HIPCHK(hipGetLastError());
+    return TRS_OK;
+}
+void trs_internal_note(const std::string& msg) { g_err = msg; }
 int trsim::sync_handle(trs_env* e) { return sync_all(e); }
 int trsim::quiesce_handle(trs_env* e) { return quiesce(e); }
 int trsim::check_fault(trs_env* e)

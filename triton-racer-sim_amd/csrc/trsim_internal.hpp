@@ -24,5 +24,9 @@ const trs_pilot_tuning* trs_internal_pilot_tuning(trs_env* e);   // what trs_pil
 void trs_internal_set_pilot_tuning(trs_env* e, const trs_pilot_tuning* t);
 int trs_internal_fail(int code, const std::string& msg);
 int trs_internal_step_launch(trs_env* e, const float* d_st, const float* d_th, const float* d_br);   // one env step by launch, whatever the step mode
+// one env step with index `step` by launch, on the handle's stream, WITHOUT moving the step counter: a step that was posted to a resident worker
+// (the counter moved at the post) and has to run as a launch after all (trsim_resident.hip, fall_back_to_launches)
+int trs_internal_replay_launch(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, uint64_t step);
+void trs_internal_note(const std::string& msg);            // what trs_last_error() returns, without failing the call
 void trs_internal_count(trs_env* e, uint64_t d2h_bytes, uint64_t h2d_bytes);   // trs_counters bookkeeping for copies made outside trsim_hip.hip
 void trs_pilot_free(void* ctx);       // defined in trsim_pilot.hip, called by trs_destroy

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/trsim.h"
@@ -65,9 +66,11 @@ static_assert(offsetof(WEntry, seq_lo) == 8 * kTagLo && offsetof(WEntry, seq) ==
 struct Mailbox {                // pinned host memory the device reads and writes over PCIe
     alignas(64) uint64_t close;             // host -> device: leave once everything posted is done
     uint64_t posted;                        // host bookkeeping: steps [0, posted) have been posted (the device reads the entries' tags)
-    alignas(64) uint64_t exited;            // device -> host: the dispatcher has decided to leave
+    alignas(64) uint64_t exited;            // device -> host: the dispatcher has decided to leave (kExitNormal), or it found the launch NOT co-resident
+                                            //   (kExitNotCoresident: another worker — of another process — holds part of the CUs; nothing was consumed)
     uint64_t consumed;                      //   ... and every step below this index is processed by the time the kernel ends
     uint64_t error;                         //   non-zero: a bounded wait gave up (code << 32 | block)
+    uint64_t started;                       //   1 = every workgroup of this launch has reported in: the launch is co-resident and serves posts
     alignas(64) uint64_t done[kSlots];      // device -> host: done[s % 8] = s + 1 when step s is complete in memory
     alignas(64) WEntry ring[kSlots];        // host -> device
 };
@@ -77,6 +80,8 @@ struct DevCtl {                 // device memory; touched only by sc1 accesses a
     alignas(64) WEntry ring[kSlots];
     alignas(64) unsigned arrive[kSlots][8][16];   // [slot][blockIdx % 8]: one 64-B line each
     alignas(64) unsigned top[kSlots][16];
+    alignas(64) unsigned checkin[16];       // workgroups of this launch that are on a CU with their tables staged (the dispatcher waits for n_blocks)
+    alignas(64) unsigned decision[16];      // 0 = open, kGo = the whole grid is on the GPU: posts are served, kNoGo = it is not: every workgroup leaves (set ONCE, by compare-and-swap)
 };
 
 struct WParams {
@@ -88,6 +93,7 @@ struct WParams {
     DevCtl* dc;
     unsigned long long start;                               // first step index this launch processes
     unsigned long long idle_ticks, life_ticks, safety_ticks;   // wall_clock64() ticks (100 MHz)
+    unsigned long long checkin_ticks;                       // how long the dispatcher waits for every workgroup of the launch to report in
     int lds_off_phys, lds_off_ctl, n_blocks;
     FParams fp;                                             // DYN instantiation: ImgPreprocessing with dynamic brightness behind the rasteriser (trs_set_frame_filter)
 };
@@ -95,6 +101,9 @@ struct WParams {
 #define TRS_RESIDENT_DIAG 0   /* timing-only diagnostic builds (-DTRS_RESIDENT_DIAG=bits), never shipped, like TRS_ABLATE: 1 = arrive without the counted wait (WRONG completion flags), 2 = no telemetry stores, 4 = clock probe of one raster wave into stats[40..44] */
 #endif
 constexpr int kDiag = TRS_RESIDENT_DIAG;
+
+constexpr unsigned kDefaultLifeUs = 50000;
+constexpr unsigned kRetryMs0 = 100;
 
 struct Resident {
     bool enabled = false, running = false;
@@ -107,11 +116,22 @@ struct Resident {
     uint64_t seen_done = 0;              // every step below this index has been observed complete
     bool launched = false;               // steps were LAUNCHED on the handle's stream since the last wait (trs_step_pilot in resident mode): no
                                          // completion flag will ever be written for them — the stream is what to wait for
+    bool fell_back = false;              // a launch of the worker was found not co-resident (another process's worker on the GPU): the handle went
+                                         // back to TRS_STEP_LAUNCH by itself (trs_last_error() says so); trs_set_step_mode selects resident mode again
+    std::chrono::steady_clock::time_point t_launch{};   // when the running worker was launched (the host gives up on a launch that never reports in)
+    std::chrono::steady_clock::time_point t_fallback{}; // when the handle went back to launches; resident mode is tried again retry_ms later
+    unsigned retry_ms = kRetryMs0;                      //   ... doubling up to 2 s while the GPU stays shared
     unsigned idle_us = 2000;
-    unsigned life_us = 500000;           // a worker leaves after this long whatever happens (trs_resident_debug_lifetime: tests force many generations)
+    unsigned life_us = kDefaultLifeUs;   // a worker leaves after this long whatever happens and the next post (or the one that raced) starts a new one
+                                         // (trs_resident_debug_lifetime: tests force many generations).  50 ms since round 5 (0.5 s before): the gap
+                                         // between two generations is where ANOTHER process's kernels get CUs — its launches, or its own worker,
+                                         // which then holds the GPU for its 50 ms: processes that share a GPU take turns at the reference's tick
+                                         // rate (20 Hz, car_templates/manage.py:38) or better, and a worker restart (~35 us) per 50 ms costs 0.1 %
     unsigned char* hctl = nullptr;       // pinned staging for host-array controls: [kSlots] x (3 float[n] + uint8[n])
     size_t hctl_slot = 0;
     int lds_bytes = 0, lds_off_ctl = 0, lds_off_dyn = 0;
+    long long pw_capacity_envs = 0;      // physics-only handles: envs whose workgroups the GPU holds at once (worker_fits)
+    int pw_capacity_lds = -1;            //   ... asked for this LDS need
 };
 
 }  // namespace trsim
@@ -122,6 +142,26 @@ using namespace trsim;
 using u64 = unsigned long long;
 
 constexpr u64 kExitBit = 1ull << 63, kAbortBit = 1ull << 62, kCountMask = kAbortBit - 1;
+constexpr u64 kExitNormal = 1ull, kExitNotCoresident = 2ull;     // Mailbox::exited
+constexpr u64 kCloseLeave = 1ull, kCloseCancel = 2ull;            // Mailbox::close: leave once everything posted is done / the host has given up on this launch
+constexpr int kFellBack = trsim::kResidentFellBack;               // internal return code (> 0: not an error): the handle has just gone back to launch mode
+
+// ---- one resident worker per GPU (per process) -----------------------------------------------------------------------
+// A worker needs EVERY workgroup of its grid on a CU at once (the completion flags count all of them, and a workgroup that is there never
+// leaves while it waits for posts), one slot with most of the LDS per CU.  Two workers on one GPU would each hold a part of the CUs and wait
+// for the rest (seen in round 4: gpurun_out/r04_full_2.log, both ranks "resident worker gave up" after the 2 s safety).  So the library keeps
+// one owner per device: worker_launch asks the other handle's worker to leave first (close -> it finishes what was posted and exits -> the
+// kernel has ended), which costs a worker start per alternation, never idle_us and never the safety.  The lock also makes the host side of a
+// handle's resident state safe against that eviction coming from another handle's thread.  What the lock cannot see is another PROCESS: that
+// case is caught on the device (dispatcher_checkin) and by the host's launch deadline (wait_done), and ends in launch mode, not in a hang.
+constexpr int kMaxDevices = 64;
+struct DeviceSlot { std::recursive_mutex mu; trs_env* owner = nullptr; };
+DeviceSlot g_dev[kMaxDevices];
+struct DevLock {
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit DevLock(const trs_env* e) : lk(g_dev[(unsigned)e->device % kMaxDevices].mu) {}
+};
+inline DeviceSlot& slot_of(const trs_env* e) { return g_dev[(unsigned)e->device % kMaxDevices]; }
 
 // ---- scoped accesses ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 sys_load64(const void* p) { return __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -236,8 +276,117 @@ __device__ __forceinline__ int dispatcher_take(const WParams& wp, const WLds& l,
 // The dispatcher's whole life.  It leaves — and with it, after the steps below the final count, every wave of the launch — when
 // the host asks (close), when nothing was posted for idle_us although everything published is rendered, or when the launch's
 // lifetime is spent (the host starts a new worker at its next post).
+// the EXIT bit goes out once, with the FINAL count: every workgroup finishes the steps below it and leaves
+__device__ __forceinline__ void dispatcher_publish_exit(const WParams& wp, const WLds& l, u64 count, int lane)
+{
+    if (lane == 0) {
+        const u64 w = count | kExitBit;
+        // EXIT (1 << 63) outranks ABORT (1 << 62) in a max: an abort that arrived just before is carried over by hand
+        const u64 old_g = __hip_atomic_fetch_max(&wp.dc->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old_g & kAbortBit) __hip_atomic_fetch_or(&wp.dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 old_l = __hip_atomic_fetch_max(l.word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((old_l | old_g) & kAbortBit) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    drain_vmem();
+}
+
+// a workgroup is on its CU with its tables staged (called once per workgroup, behind the prologue's barrier)
+__device__ __forceinline__ void worker_checkin(const WParams& wp)
+{
+    __hip_atomic_fetch_add(&wp.dc->checkin[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Before the first post is taken: is the WHOLE grid on the GPU?  A step completes when every workgroup has arrived for it, and the workgroups
+// that are on a CU stay there while they wait for posts — a launch of which only a part found room (the rest of the CUs' LDS is held by the
+// worker of another process: this process's own handles hand the GPU over in worker_launch) would never complete a step and never make room
+// for its own missing workgroups (round 4, gpurun_out/r04_full_2.log: two ranks on one GPU, both "gave up (waiting for a post)" after the 2 s
+// safety — in workgroups 212 and 38, whose dispatchers in workgroup 0 had found no CU at all: the XCDs place their shares of a grid
+// independently).  The workgroups of a launch that has the GPU to itself report in within microseconds of each other (dispatch + ~124 KB of
+// LDS-DMA).  One word decides, once, by compare-and-swap: the dispatcher sets kGo when all n_blocks have reported in; the dispatcher after
+// checkin_ticks (2 ms) — or ANY workgroup's leader after twice that, should workgroup 0 be among the missing — sets kNoGo.  On kNoGo nothing
+// has been consumed: the winner tells the host (consumed = start, exited = kExitNotCoresident) and every workgroup — those on the GPU now and
+// the ones that get a CU later — leaves without taking a step.  The host then runs the posted steps by launches (fall_back_to_launches).  The
+// dispatcher takes the same exit when the host has given up on the launch first (close = kCloseCancel: the kernel sat in the queue behind
+// another process's worker for 250 ms).
+constexpr unsigned kGo = 1u, kNoGo = 2u;
+
+__device__ __forceinline__ unsigned decision_load(const WParams& wp) { return __hip_atomic_load(&wp.dc->decision[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// try to close the decision with `want`; returns what the decision IS afterwards (wave-uniform: lane 0 swaps, the wave reads it back)
+__device__ __forceinline__ unsigned decision_close(const WParams& wp, unsigned want, int lane, bool& won)
+{
+    unsigned seen = 0u;
+    if (lane == 0) {
+        unsigned expected = 0u;
+        const bool ok = __hip_atomic_compare_exchange_strong(&wp.dc->decision[0], &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen = ok ? (want | 0x100u) : expected;
+    }
+    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+    won = (seen & 0x100u) != 0u;
+    return seen & 0xffu;
+}
+
+// the launch is not co-resident: tell the host (the winner of the decision only) and this workgroup
+__device__ __forceinline__ void leave_not_coresident(const WParams& wp, const WLds& l, int lane, bool won)
+{
+    if (won) {
+        if (lane == 0) sys_store64(&wp.mb->consumed, wp.start);
+        drain_vmem();                                        // `consumed` is in host memory before `exited` says the launch is over
+        if (lane == 0) sys_store64(&wp.mb->exited, kExitNotCoresident);
+    }
+    dispatcher_publish_exit(wp, l, wp.start, lane);          // EXIT | start: device word (leaders that are past their own check) and this workgroup's LDS word
+}
+
+// 1 = serve posts, 0 = leave.
+__device__ __forceinline__ int dispatcher_checkin(const WParams& wp, const WLds& l, int lane)
+{
+    const u64 t0 = (u64)wall_clock64();
+    bool cancel = sys_load64(&wp.mb->close) == kCloseCancel, won = false;
+    for (unsigned spins = 0; !cancel; ++spins) {
+        if (decision_load(wp) == kNoGo) { leave_not_coresident(wp, l, lane, false); return 0; }
+        if (__hip_atomic_load(&wp.dc->checkin[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)wp.n_blocks) {
+            if (decision_close(wp, kGo, lane, won) != kGo) { leave_not_coresident(wp, l, lane, false); return 0; }
+            if (lane == 0) sys_store64(&wp.mb->started, 1ull);
+            return 1;
+        }
+        if (agent_load64(&wp.dc->word) & kAbortBit) {        // a workgroup refused to run (LDS segment not at offset 0): its error word is set
+            if (lane == 0) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return 0;
+        }
+        if ((u64)wall_clock64() - t0 > wp.checkin_ticks) break;
+        if ((spins & 63u) == 63u) cancel = sys_load64(&wp.mb->close) == kCloseCancel;   // (a PCIe read: sparse)
+        __builtin_amdgcn_s_sleep(4);
+    }
+    const unsigned d = decision_close(wp, kNoGo, lane, won);
+    if (d == kGo) { if (lane == 0) sys_store64(&wp.mb->started, 1ull); return 1; }   // (cannot happen: only this wave sets kGo)
+    leave_not_coresident(wp, l, lane, won);
+    return 0;
+}
+
+// A leader (one wave per workgroup other than workgroup 0) waits for the decision before it serves its workgroup.  1 = go, 0 = leave.
+__device__ __forceinline__ int leader_wait_decision(const WParams& wp, const WLds& l, int lane)
+{
+    const u64 t0 = (u64)wall_clock64();
+    for (;;) {
+        unsigned d = decision_load(wp);
+        if (d == 0u && (u64)wall_clock64() - t0 > 2ull * wp.checkin_ticks) {
+            bool won = false;
+            d = decision_close(wp, kNoGo, lane, won);        // the dispatcher itself is missing
+            if (d == kNoGo) { leave_not_coresident(wp, l, lane, won); return 0; }
+        }
+        if (d == kGo) return 1;
+        if (d == kNoGo) { leave_not_coresident(wp, l, lane, false); return 0; }
+        if (agent_load64(&wp.dc->word) & kAbortBit) {
+            if (lane == 0) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 __device__ __forceinline__ void dispatcher_run(const WParams& wp, const WLds& l, int lane)
 {
+    if (!dispatcher_checkin(wp, l, lane)) return;
     Leader L{wp.start, (u64)wall_clock64(), (u64)wall_clock64()};
     for (;;) {
         if ((lds_load64(l.word) | agent_load64(&wp.dc->word)) & kAbortBit) {   // some wave gave up: this workgroup learns of it here
@@ -251,19 +400,11 @@ __device__ __forceinline__ void dispatcher_run(const WParams& wp, const WLds& l,
         if (fresh || busy) L.t_last = now;
         const bool leave = (!fresh && (close_req || now - L.t_last > wp.idle_ticks)) || now - L.t_start > wp.life_ticks;
         if (!leave) { if (!fresh) __builtin_amdgcn_s_sleep(4); continue; }      // (a poll is a PCIe round trip anyway; 16 until late round 4: ~0.25 us more until a post is seen)
-        if (lane == 0) sys_store64(&wp.mb->exited, 1ull);
+        if (lane == 0) sys_store64(&wp.mb->exited, kExitNormal);
         drain_vmem();                                        // `exited` is in host memory before the last look at the ring
         (void)dispatcher_take(wp, l, L, lane, close_req);    // whatever was posted before that look is still served by this launch
-        if (lane == 0) {
-            sys_store64(&wp.mb->consumed, L.known);
-            const u64 w = L.known | kExitBit;                // the EXIT bit goes out once, with the FINAL count
-            // EXIT (1 << 63) outranks ABORT (1 << 62) in a max: an abort that arrived just before is carried over by hand
-            const u64 old_g = __hip_atomic_fetch_max(&wp.dc->word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old_g & kAbortBit) __hip_atomic_fetch_or(&wp.dc->word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64 old_l = __hip_atomic_fetch_max(l.word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old_l | old_g) & kAbortBit) __hip_atomic_fetch_or(l.word, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        drain_vmem();
+        if (lane == 0) sys_store64(&wp.mb->consumed, L.known);
+        dispatcher_publish_exit(wp, l, L.known, lane);
         return;
     }
 }
@@ -392,6 +533,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
         }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tid == 0) worker_checkin(wp);
 
     if (!raster_team) {
         // ---- physics team: LDS in, LDS out.  It reads its controls (system-scope loads) and hands the new pose AND the step's
@@ -400,6 +542,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
         const int first = blockIdx.x == 0 ? 1 : 0, nphys = kPhysWaves - first;   // workgroup 0: wave 0 is the dispatcher, three waves share the envs
         if (pw < first) { dispatcher_run(wp, l, lane); return; }
         Duties D{blockIdx.x != 0 && pw == 0, pw == kPhysWaves - 1, wp.start};
+        if (D.leader && !leader_wait_decision(wp, l, lane)) return;   // (the other waves wait for a post: the LDS word says EXIT when the launch is called off)
         const unsigned char* const lphys = smem + wp.lds_off_phys;
         u64 s = wp.start;
         for (;; ++s) {
@@ -646,6 +789,7 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
     if (tid < kSlots) l.arrive[tid] = 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tid == 0) worker_checkin(wp);
 
     if (wave == kPwEnvs + 1) {                               // the dispatcher: workgroup 0 only
         if (blockIdx.x == 0) dispatcher_run(wp, l, lane);
@@ -653,6 +797,7 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
     }
     if (wave == kPwEnvs) {                                   // the service wave: leader + forwarder, until the launch's last step has been passed on
         Duties D{blockIdx.x != 0, true, wp.start, n_loc};
+        if (D.leader && !leader_wait_decision(wp, l, lane)) return;
         u64 s = wp.start;
         while (wait_posted(wp, l, D, s, lane)) ++s;          // returns at once for a step that is posted: s runs up to the published count, then the wait does the duties
         const u64 w = lds_load64(l.word);
@@ -798,6 +943,21 @@ int worker_fits(trs_env* e)
         R->lds_off_ctl = (e->lds_p + 15) & ~15;
         R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(kPwEnvs) + 16);
         if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "track image too large for the resident physics worker");
+        // The grid is ceil(n / 4) workgroups and ALL of them must be on the GPU at once (arrival counters, done flags: see the note on
+        // DeviceSlot).  What the GPU holds at once is what the occupancy query says for this block size and LDS need, per CU (ADVICE r04:
+        // beyond it the workgroups that found no room never arrive — a step would complete only when the others idle out).
+        if (R->pw_capacity_lds != R->lds_bytes) {            // (asked once per LDS need: this runs in front of every worker start)
+            int per_cu = 0;
+            RCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(trs_physics_worker_kernel), kPwBlock, (size_t)R->lds_bytes));
+            R->pw_capacity_envs = (long long)per_cu * (long long)std::max(e->cu_count, 1) * kPwEnvs;
+            R->pw_capacity_lds = R->lds_bytes;
+        }
+        const long long capacity = R->pw_capacity_envs / kPwEnvs;    // 0 = the runtime gave no answer: the device-side check-in decides
+        const long long grid = ((long long)e->n + kPwEnvs - 1) / kPwEnvs;
+        if (capacity > 0 && grid > capacity)
+            return trs_internal_fail(TRS_ERR_LIMIT, "resident mode: " + std::to_string(e->n) + " physics-only envs need " + std::to_string(grid) +
+                                                        " co-resident workgroups, this GPU holds " + std::to_string(capacity) + " (" + std::to_string(capacity * kPwEnvs) +
+                                                        " envs): use TRS_STEP_LAUNCH with several steps per launch for shards of this size");
         return TRS_OK;
     }
     R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables
@@ -807,13 +967,21 @@ int worker_fits(trs_env* e)
     return TRS_OK;
 }
 
+int evict(trs_env* other);
+
 int worker_launch(trs_env* e, uint64_t start)
 {
     Resident* R = e->res;
     Mailbox* mb = R->mb;
     { int rc = worker_fits(e); if (rc) return rc; }
+    {   // one worker per GPU: the worker of another handle of this process leaves first (the caller holds the device's lock)
+        DeviceSlot& D = slot_of(e);
+        trs_env* const other = D.owner;
+        if (other && other != e && other->res && other->res->running) (void)evict(other);   // (a worker that gave up is gone all the same: its handle reports it)
+        D.owner = e;
+    }
     host_store(&mb->exited, 0); host_store(&mb->consumed, start); host_store(&mb->error, 0);
-    host_store(&mb->close, 0);
+    host_store(&mb->close, 0); host_store(&mb->started, 0);
     WParams wp{};
     wp.ph = e->pp; wp.ph.synth = 0; wp.ph.write_cam = 0; wp.ph.n_steps = 0; wp.ph.step_off = 0; wp.ph.ctl_stride = 0;
     wp.ra = e->rp;
@@ -821,8 +989,9 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.mb = mb; wp.dc = R->dc;
     wp.start = start;
     wp.idle_ticks = (unsigned long long)R->idle_us * 100ull;
-    wp.life_ticks = (unsigned long long)R->life_us * 100ull;   // 0.5 s by default: then the dispatcher leaves and the host starts a new worker at its next post
+    wp.life_ticks = (unsigned long long)R->life_us * 100ull;   // 50 ms by default: then the dispatcher leaves and the host starts a new worker at its next post
     wp.safety_ticks = 200000000ull;                         // 2 s
+    wp.checkin_ticks = 200000ull;                           // 2 ms: every workgroup of a launch that has the GPU to itself reports in within tens of microseconds
     wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl;
     const int grid = e->cfg.render ? (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg : (e->n + kPwEnvs - 1) / kPwEnvs;
     wp.n_blocks = grid;
@@ -831,6 +1000,7 @@ int worker_launch(trs_env* e, uint64_t start)
         hipLaunchKernelGGL(trs_physics_worker_kernel, dim3(grid), dim3(kPwBlock), R->lds_bytes, e->sP, wp);
         RCHK(hipGetLastError());
         R->running = true;
+        R->t_launch = std::chrono::steady_clock::now();
         return TRS_OK;
     }
     const bool dyn = e->has_frame_filter && e->filter_dynamic;
@@ -853,6 +1023,7 @@ int worker_launch(trs_env* e, uint64_t start)
            else hipLaunchKernelGGL((trs_worker_kernel<false, false>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp); }
     RCHK(hipGetLastError());
     R->running = true;
+    R->t_launch = std::chrono::steady_clock::now();
     return TRS_OK;
 }
 
@@ -869,8 +1040,36 @@ int worker_error(trs_env* e)
                                                  std::to_string((unsigned)err));
 }
 
-// the worker has said it leaves: wait for the kernel, restart it if posts raced with its exit
-int handle_exit(trs_env* e)
+// The launch was not co-resident (dispatcher_checkin) or never reported in (wait_done's deadline): the GPU is shared with the worker of another
+// process.  The handle goes back to TRS_STEP_LAUNCH — launches need no co-residency, they make progress whenever CUs come free — and the steps
+// that were posted but not consumed run as launches now, with the control pointers of their posts (the ring is host memory; pinned staging
+// slots of trs_step_host are device-readable).  Returns kFellBack (> 0): not an error, the posted steps will complete on the handle's stream.
+int fall_back_to_launches(trs_env* e, uint64_t consumed, const char* why)
+{
+    Resident* R = e->res;
+    const uint64_t posted = host_load(&R->mb->posted);
+    R->enabled = false;
+    R->fell_back = true;
+    R->t_fallback = std::chrono::steady_clock::now();
+    if (consumed > R->seen_done) R->seen_done = consumed;
+    for (uint64_t s = consumed; s < posted; ++s) {
+        const WEntry& en = R->mb->ring[s & (kSlots - 1)];
+        if (en.seq != s + 1 || en.seq_lo != s + 1)
+            return trs_internal_fail(TRS_ERR_DEVICE, "resident worker: the post of step " + std::to_string(s) + " is no longer in the ring");
+        int rc = trs_internal_replay_launch(e, en.steer, en.thr, en.brk, en.reset, (int)en.synth, s);
+        if (rc) return rc;
+    }
+    R->launched = true;                                      // these steps have no completion flag: the stream is what to wait for
+    R->base = R->seen_done = e->step_count;
+    for (int k = 0; k < kSlots; ++k) { host_store(&R->mb->ring[k].seq, 0); host_store(&R->mb->ring[k].seq_lo, 0); host_store(&R->mb->done[k], 0); }
+    trs_internal_note(std::string("resident worker: ") + why + " - another process's worker holds CUs of this GPU; the handle has gone back to TRS_STEP_LAUNCH "
+                      "(resident mode is tried again by itself after " + std::to_string(R->retry_ms) + " ms; trs_get_step_mode tells)");
+    return kFellBack;
+}
+
+// the worker has said it leaves (or has been told to): wait for the kernel, restart it if posts raced with its exit.
+// relaunch = false (eviction by another handle): posts that raced stay in the ring, the handle's next call starts a worker from seen_done.
+int handle_exit(trs_env* e, bool relaunch = true)
 {
     Resident* R = e->res;
     RCHK(hipStreamSynchronize(e->sP));
@@ -878,9 +1077,37 @@ int handle_exit(trs_env* e)
     int rc = worker_error(e);
     if (rc) return rc;
     const uint64_t consumed = host_load(&R->mb->consumed), posted = host_load(&R->mb->posted);
+    if (host_load(&R->mb->exited) == kExitNotCoresident)
+        return fall_back_to_launches(e, consumed, "the launch did not get every CU within 2 ms");
     if (consumed > R->seen_done) R->seen_done = consumed;   // the kernel has ended: everything it consumed is complete
-    if (consumed < posted) return worker_launch(e, consumed);
+    if (host_load(&R->mb->started)) R->retry_ms = kRetryMs0;   // this launch had the GPU: the sharing that caused an earlier fallback is over
+    if (consumed < posted && relaunch) return worker_launch(e, consumed);
     return TRS_OK;
+}
+
+// another handle of this process wants the GPU for its worker: this one finishes what was posted and leaves
+int evict(trs_env* other)
+{
+    Resident* R = other->res;
+    int rc = TRS_OK;
+    if (R->running) {
+        host_store(&R->mb->close, kCloseLeave);
+        rc = handle_exit(other, false);                      // (kFellBack: it left for launch mode — the GPU is free of it just the same)
+    }
+    return rc < 0 ? rc : TRS_OK;
+}
+
+// the host has waited too long for a launch to report in: the kernel sits in the queue behind something that does not leave (another
+// process's worker).  Cancel it (the dispatcher leaves at its first look, or serves what it had already begun) and go back to launches.
+int give_up_on_launch(trs_env* e)
+{
+    Resident* R = e->res;
+    host_store(&R->mb->close, kCloseCancel);
+    RCHK(hipStreamSynchronize(e->sP));                       // bounded by the other worker's lifetime (50 ms) or idle time
+    R->running = false;
+    int rc = worker_error(e);
+    if (rc) return rc;
+    return fall_back_to_launches(e, host_load(&R->mb->consumed), "the launch had not started after 250 ms");
 }
 
 int wait_done(trs_env* e, uint64_t s)
@@ -889,15 +1116,27 @@ int wait_done(trs_env* e, uint64_t s)
     if (s < R->seen_done) return TRS_OK;
     Mailbox* mb = R->mb;
     const auto t0 = std::chrono::steady_clock::now();
+    auto fell_back = [&]() -> int {                           // the posted steps went onto the stream as launches: wait for the stream
+        RCHK(hipStreamSynchronize(e->sP));
+        R->launched = false;
+        R->base = R->seen_done = e->step_count;
+        return TRS_OK;
+    };
     for (unsigned spins = 0;; ++spins) {
         if (host_load(&mb->done[s & (kSlots - 1)]) >= s + 1) { R->seen_done = s + 1; return TRS_OK; }
         if ((spins & 63u) == 63u) {
             if (R->running && host_load(&mb->exited)) {
                 int rc = handle_exit(e);
+                if (rc == kFellBack) return fell_back();
                 if (rc) return rc;
                 if (s < R->seen_done) return TRS_OK;
             } else if (!R->running) {
                 if (host_load(&mb->posted) > R->seen_done) { int rc = worker_launch(e, R->seen_done); if (rc) return rc; }
+            } else if ((spins & 4095u) == 4095u && !host_load(&mb->started) &&
+                       std::chrono::steady_clock::now() - R->t_launch > std::chrono::milliseconds(250)) {
+                int rc = give_up_on_launch(e);
+                if (rc == kFellBack) return fell_back();
+                if (rc) return rc;
             }
             if (host_load(&mb->error)) { (void)handle_exit(e); return worker_error(e); }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
@@ -933,6 +1172,24 @@ int ensure_resident(trs_env* e)
 namespace trsim {
 
 bool resident_on(const trs_env* e) { return e && e->res && e->res->enabled; }
+
+// A handle that went back to launches because the GPU was shared with another process's worker tries resident mode again by itself:
+// called in front of every step call.  The step that follows starts a worker; if the GPU is still shared the launch is called off
+// again within milliseconds (dispatcher_checkin) and the interval doubles (100 ms .. 2 s).
+void resident_retry(trs_env* e)
+{
+    Resident* R = e ? e->res : nullptr;
+    if (!R || R->enabled || !R->fell_back || R->broken || !R->mb) return;
+    DevLock lock(e);
+    if (std::chrono::steady_clock::now() - R->t_fallback < std::chrono::milliseconds(R->retry_ms)) return;
+    if (worker_fits(e) != TRS_OK) return;
+    R->retry_ms = std::min(R->retry_ms * 2u, 2000u);
+    R->base = R->seen_done = e->step_count;
+    host_store(&R->mb->posted, e->step_count);
+    R->launched = false;
+    R->enabled = true;
+    R->fell_back = false;
+}
 bool resident_running(const trs_env* e) { return e && e->res && e->res->running; }
 void resident_clear_fault(trs_env* e) { if (e && e->res) e->res->broken = false; }
 bool resident_fits_dynamic_filter(const trs_env* e)
@@ -942,15 +1199,27 @@ bool resident_fits_dynamic_filter(const trs_env* e)
     return ((base + 15) & ~15) + dyn_lds_bytes(e->H) <= 160 * 1024;
 }
 
-int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride)
+int resident_post(trs_env* e, const float* st, const float* th, const float* br, const uint8_t* rs, int synth, int n, size_t stride, int* n_done)
 {
+    DevLock lock(e);
     Resident* R = e->res;
     Mailbox* mb = R->mb;
+    *n_done = 0;
     if (R->broken) return trs_internal_fail(TRS_ERR_DEVICE, "a resident worker gave up earlier: the env state is undefined, load the track again (trs_load_track)");
     for (int k = 0; k < n; ++k) {
         const uint64_t s = e->step_count;
-        if (!R->running) { R->base = R->seen_done = s; R->launched = false; }   // no worker: nothing is in flight that a flag will report (the step counter may have moved or restarted since; launched steps are ahead of the worker on the same stream)
-        if (s >= R->base + kSlots) { int rc = wait_done(e, s - kSlots); if (rc) return rc; }   // ring slot, counters and done flag of s % 8 are free
+        if (!R->running) {
+            if (host_load(&mb->posted) > R->seen_done && host_load(&mb->posted) == s) {
+                // posts that raced with the worker's exit while another handle took the GPU over (evict): they are still in the ring
+                int rc = worker_launch(e, R->seen_done);
+                if (rc) return rc;
+            } else { R->base = R->seen_done = s; R->launched = false; }   // no worker: nothing is in flight that a flag will report (the step counter may have moved or restarted since; launched steps are ahead of the worker on the same stream)
+        }
+        if (s >= R->base + kSlots) {                                  // ring slot, counters and done flag of s % 8 are free
+            int rc = wait_done(e, s - kSlots);
+            if (rc) return rc;
+            if (!R->enabled) { *n_done = k; return kFellBack; }       // the handle went back to launch mode: the caller launches steps k.. itself
+        }
         WEntry en{};
         const size_t off = (size_t)k * stride;
         en.steer = st ? st + off : nullptr; en.thr = th ? th + off : nullptr; en.brk = br ? br + off : nullptr;
@@ -965,8 +1234,13 @@ int resident_post(trs_env* e, const float* st, const float* th, const float* br,
         std::atomic_thread_fence(std::memory_order_seq_cst);     // the post is visible before `exited` is read
         e->step_count = s + 1;
         if (!R->running) { int rc = worker_launch(e, s); if (rc) return rc; }
-        else if (host_load(&mb->exited)) { int rc = handle_exit(e); if (rc) return rc; }
+        else if (host_load(&mb->exited)) {
+            int rc = handle_exit(e);
+            if (rc == kFellBack) { *n_done = k + 1; return kFellBack; }   // (step k was in the ring: it has been launched with the rest)
+            if (rc) return rc;
+        }
     }
+    *n_done = n;
     return TRS_OK;
 }
 
@@ -974,6 +1248,7 @@ int resident_wait(trs_env* e)
 {
     Resident* R = e->res;
     if (!R) return TRS_OK;
+    DevLock lock(e);
     if (R->launched && !R->running) {                        // the newest steps went through launches (resident_note_launch): wait for the stream
         RCHK(hipStreamSynchronize(e->sP));
         R->launched = false;
@@ -990,6 +1265,7 @@ void resident_note_launch(trs_env* e)
 {
     Resident* R = e->res;
     if (!R) return;
+    DevLock lock(e);
     R->launched = true;
     R->base = R->seen_done = e->step_count;
 }
@@ -998,11 +1274,14 @@ int resident_quiesce(trs_env* e)
 {
     Resident* R = e->res;
     if (!R || !R->mb) return TRS_OK;
+    DevLock lock(e);
     int rc = TRS_OK;
-    for (int guard = 0; R->running && guard < 4; ++guard) {
-        host_store(&R->mb->close, 1);
+    if (!R->running && R->enabled && !R->broken && host_load(&R->mb->posted) > R->seen_done && host_load(&R->mb->posted) == e->step_count)
+        rc = worker_launch(e, R->seen_done);                 // posts an eviction left in the ring (see resident_post): they complete here
+    for (int guard = 0; !rc && R->running && guard < 4; ++guard) {
+        host_store(&R->mb->close, kCloseLeave);
         rc = handle_exit(e);                                 // waits for the kernel; relaunches (with `close` cleared) if posts raced
-        if (rc) break;
+        if (rc == kFellBack) { rc = TRS_OK; break; }         // the posted steps are launches on the handle's stream now
     }
     if (!rc && R->running) rc = trs_internal_fail(TRS_ERR_DEVICE, "resident worker did not leave");
     R->base = R->seen_done = e->step_count;
@@ -1015,7 +1294,9 @@ void resident_destroy(trs_env* e)
 {
     Resident* R = e->res;
     if (!R) return;
-    if (R->running) { host_store(&R->mb->close, 1); (void)hipStreamSynchronize(e->sP); }
+    DevLock lock(e);
+    if (slot_of(e).owner == e) slot_of(e).owner = nullptr;
+    if (R->running) { host_store(&R->mb->close, kCloseLeave); (void)hipStreamSynchronize(e->sP); }
     if (R->mb) (void)hipHostFree(R->mb);
     if (R->hctl) (void)hipHostFree(R->hctl);
     (void)hipFree(R->dc);
@@ -1027,12 +1308,18 @@ void resident_destroy(trs_env* e)
 hipStream_t resident_copy_stream(trs_env* e) { return (e->res && e->res->running) ? e->res->sC : e->sP; }
 
 // controls handed over as host arrays: into this step's slot of the pinned staging buffer, which the device reads over PCIe
-int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps)
+int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const float* h_br, const uint8_t* h_rs, int n_steps, int* n_done)
 {
+    DevLock lock(e);
     Resident* R = e->res;
+    *n_done = 0;
     const uint64_t s = e->step_count;
-    if (!R->running) R->base = R->seen_done = s;
-    if (s >= R->base + kSlots) { int rc = wait_done(e, s - kSlots); if (rc) return rc; }     // the staging slot is free as well
+    if (!R->running && !(host_load(&R->mb->posted) > R->seen_done && host_load(&R->mb->posted) == s)) R->base = R->seen_done = s;
+    if (s >= R->base + kSlots) {                             // the staging slot is free as well
+        int rc = wait_done(e, s - kSlots);
+        if (rc) return rc;
+        if (!R->enabled) return kFellBack;
+    }
     unsigned char* slot = R->hctl + (s & (kSlots - 1)) * R->hctl_slot;
     const size_t n = (size_t)e->n;
     float* f = reinterpret_cast<float*>(slot);
@@ -1045,14 +1332,21 @@ int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const f
     for (int k = 0; k < n_steps; ++k) {
         if (k > 0) {
             const uint64_t sk = e->step_count;
-            if (sk >= R->base + kSlots) { int rc = wait_done(e, sk - kSlots); if (rc) return rc; }
+            if (sk >= R->base + kSlots) {
+                int rc = wait_done(e, sk - kSlots);
+                if (rc) return rc;
+                if (!R->enabled) { *n_done = k; return kFellBack; }
+            }
             unsigned char* sl = R->hctl + (sk & (kSlots - 1)) * R->hctl_slot;
             if (sl != slot) std::memcpy(sl, slot, n * 12);
             slot = sl; f = reinterpret_cast<float*>(slot); rsb = slot + n * 12;
         }
-        int rc = resident_post(e, f, f + n, h_br ? f + 2 * n : nullptr, (k == 0 && h_rs) ? rsb : nullptr, 0, 1, 0);
+        int one = 0;
+        int rc = resident_post(e, f, f + n, h_br ? f + 2 * n : nullptr, (k == 0 && h_rs) ? rsb : nullptr, 0, 1, 0, &one);
+        if (rc == kFellBack) { *n_done = k + one; return kFellBack; }
         if (rc) return rc;
     }
+    *n_done = n_steps;
     return TRS_OK;
 }
 
@@ -1062,7 +1356,8 @@ TRS_EXPORT int trs_resident_debug_lifetime(trs_env* e, int life_us)
 {
     if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
     if (!e->res) return trs_internal_fail(TRS_ERR_STATE, "resident mode has not been selected on this handle");
-    e->res->life_us = life_us > 0 ? (unsigned)std::min(life_us, 10000000) : 500000u;
+    DevLock lock(e);
+    e->res->life_us = life_us > 0 ? (unsigned)std::min(life_us, 10000000) : kDefaultLifeUs;
     return TRS_OK;
 }
 
@@ -1077,6 +1372,7 @@ __global__ void trs_worker_debug_abort_kernel(Mailbox* mb, DevCtl* dc)
 TRS_EXPORT int trs_resident_debug_abort(trs_env* e)
 {
     if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    DevLock lock(e);
     if (!e->res || !e->res->running) return trs_internal_fail(TRS_ERR_STATE, "no resident worker is running on this handle");
     RCHK(hipSetDevice(e->device));
     hipLaunchKernelGGL(trs_worker_debug_abort_kernel, dim3(1), dim3(1), 0, e->res->sC, e->res->mb, e->res->dc);
@@ -1085,11 +1381,21 @@ TRS_EXPORT int trs_resident_debug_abort(trs_env* e)
     return TRS_OK;
 }
 
+TRS_EXPORT int trs_get_step_mode(trs_env* e, int* mode, int* fell_back)
+{
+    if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
+    DevLock lock(e);
+    if (mode) *mode = (e->res && e->res->enabled) ? TRS_STEP_RESIDENT : TRS_STEP_LAUNCH;
+    if (fell_back) *fell_back = (e->res && e->res->fell_back) ? 1 : 0;
+    return TRS_OK;
+}
+
 TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
 {
     if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
     if (mode != TRS_STEP_LAUNCH && mode != TRS_STEP_RESIDENT) return trs_internal_fail(TRS_ERR_ARG, "mode must be TRS_STEP_LAUNCH or TRS_STEP_RESIDENT");
     RCHK(hipSetDevice(e->device));
+    DevLock lock(e);
     if (mode == TRS_STEP_LAUNCH) {
         if (!e->res) return TRS_OK;
         int rc = resident_quiesce(e);
@@ -1111,5 +1417,7 @@ TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
     if (idle_us > 0) R->idle_us = (unsigned)std::min(idle_us, 1000000);
     if (!R->enabled) { R->base = R->seen_done = e->step_count; host_store(&R->mb->posted, e->step_count); }
     R->enabled = true;
+    R->fell_back = false;
+    R->retry_ms = kRetryMs0;
     return TRS_OK;
 }

@@ -205,6 +205,13 @@ class BatchedEnv:
     def sync(self):
         self.api.check(self.api.sync(self._h), "sync")
 
+    def step_mode(self):
+        """``("resident" | "launch", fell_back)`` (``trs_get_step_mode``).  ``fell_back``: resident mode was selected and the library went back to
+        launches by itself because the GPU is shared with another process's resident worker (``include/trsim.h``)."""
+        mode, fb = C.c_int(0), C.c_int(0)
+        self.api.check(self.api.get_step_mode(self._h, C.byref(mode), C.byref(fb)), "get_step_mode")
+        return ("resident" if mode.value == 1 else "launch"), bool(fb.value)
+
     def quiesce(self):
         """Resident mode: the worker kernel leaves the GPU (posted steps complete first); the next step starts a new one
         (``trs_quiesce``).  Call before work of another stream that needs the CUs the worker occupies (collectives)."""
