@@ -238,6 +238,77 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def image_path_leg(device):
+    """ImgPreprocessing on the device (components/img_preprocessing.py:37-102) on the env's own frames: per 1024 frames of
+    120x160 and per 256 of 240x320 — trim, trim + dynamic brightness, trim + HSV masks, + Canny: us per batch, GB/s of algorithmic traffic (2 x H x W x 3 B
+    per frame: read once + written once) and the fraction of the 8 TB/s HBM peak.  Fixed lengths, clocks pre-warmed (PREWARM_S), HIP events on the env's stream."""
+    from triton_racer_sim_amd.env import BatchedEnv
+    cfgs = (("trim", {"preprocessing_contrast_enhancement_ratio": 1.2}),
+            ("trim_dynamic_brightness", {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True}),
+            ("trim_hsv_masks", {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_color_filter_enabled": True}),
+            ("trim_dynamic_masks_canny", {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True,
+                                          "preprocessing_color_filter_enabled": True, "preprocessing_edge_detection_enabled": True}))
+    out = {}
+    for n, h, w in ((1024, 120, 160), (256, 240, 320)):
+        env = BatchedEnv(n_envs=n, auto_reset=True, img_h=h, img_w=w, device=device)
+        env.step_synthetic(20, 1)
+        leg = {}
+        for name, cfg in cfgs:
+            pc = env.pre_config(cfg)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < PREWARM_S:
+                for _ in range(20):
+                    env.preprocess_latest(pc)
+                env.sync()
+            reps = 100
+            env.event_record(0)
+            for _ in range(reps):
+                env.preprocess_latest(pc)
+            env.event_record(1)
+            env.sync()
+            us = env.event_elapsed_ms(0, 1) * 1e3 / reps
+            gbs = 2.0 * h * w * 3 * n / us / 1e3
+            leg[name] = {"us_per_batch": round(us, 2), "GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        out[f"{n}x{h}x{w}"] = leg
+        env.close()
+    out["note"] = ("trs_preprocess on device-resident frames (components/img_preprocessing.py:37-102), one batch per call; algorithmic traffic = one read + one write of every "
+                   "frame byte; device time by HIP events, 100 calls after an 80 ms pre-warm per configuration")
+    return out
+
+
+def filtered_step_leg(device):
+    """cam/processed_img straight from the rasteriser (trs_set_frame_filter): the resident step at 1024 envs x 120x160 with raw frames, with the static
+    filter (trim + HSV masks: the palette is filtered on the host, zero extra traffic) and with dynamic brightness (per-env palettes inside the worker kernel):
+    us per step, every step posted on its own; host wall clock between completion flags, worker resident (the definition of the main line's `value`)."""
+    from triton_racer_sim_amd.env import BatchedEnv
+    static = {"preprocessing_color_filter_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2}
+    dyn = dict(static, preprocessing_dynamic_brightness_enabled=True)
+    n, steps = 1024, 2000
+    env = BatchedEnv(n_envs=n, auto_reset=True, device=device)
+    env.set_step_mode(True, 100000)
+    out = {}
+    for name, flt in (("raw_frames", None), ("static_palette_filter", static), ("dynamic_brightness", dyn)):
+        if flt is None:
+            env.set_frame_filter(enabled=False)
+        else:
+            env.set_frame_filter(flt)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < PREWARM_S:
+            env.step_synthetic(400, 1)
+            env.sync()
+        t1 = time.perf_counter()
+        env.step_synthetic(steps, 1)
+        env.sync()
+        wall = time.perf_counter() - t1
+        us = wall * 1e6 / steps
+        out[name] = {"us_per_step": round(us, 3), "env_steps_per_s": round(n * steps / wall, 1),
+                     "frac_of_hbm_peak": round(algorithmic_bytes(120, 160, True) * n * steps / wall / 1e9 / HBM_PEAK_GBS, 5)}
+    env.close()
+    out["note"] = ("1024 envs x 120x160, resident worker, every step posted on its own, 2000 steps after an 80 ms pre-warm each; the filter of "
+                   "components/img_preprocessing.py:81-102 (+ HSV masks :65-71) applied by the rasteriser itself: no second pass over the frames")
+    return out
+
+
 class phase:
     """``with phase("name", seconds):`` — a phase of a multi-rank run that can only stall on ANOTHER rank (rendezvous, barrier, collective).  When it
     takes longer than ``seconds`` the rank says which phase it is stuck in and exits with code 3 (the launcher then stops the other ranks): no silent
@@ -585,8 +656,10 @@ def main():
             pws, pmacs = pilot_weights(args.img_h, args.img_w)
             env.pilot_load(pws)
             psteps = 200                                              # a fixed 40 ms whatever --steps says: 20 steps (4 ms) would be timed at idle clocks
-            env.step_pilot(100)
-            env.sync()
+            t_pw = time.perf_counter()
+            while time.perf_counter() - t_pw < PREWARM_S:              # the same pre-warm as the main line (100 steps were 20 ms of the 25-40 the clocks need)
+                env.step_pilot(50)
+                env.sync()
             env.event_record(2)
             env.step_pilot(psteps)
             env.event_record(3)
@@ -607,8 +680,10 @@ def main():
                 w5, macs5 = pilot_weights(240, 320)
                 env5.pilot_load(w5)
                 env5.step_synthetic(2, 1)
-                env5.step_pilot(40)                                         # 25 ms: clocks up again after the host-side weight generation
-                env5.sync()
+                t_pw = time.perf_counter()
+                while time.perf_counter() - t_pw < PREWARM_S:               # clocks up again after the host-side weight generation
+                    env5.step_pilot(20)
+                    env5.sync()
                 env5.event_record(0)
                 env5.step_pilot(60)
                 env5.event_record(1)
@@ -663,6 +738,17 @@ def main():
             phys_leg = physics_256(local_rank)
         except Exception as exc:
             phys_leg = {"error": str(exc)}
+        # ... the image path (ImgPreprocessing on the device) and the step with the filter behind the rasteriser: fixed shapes and lengths
+        image_leg = filtered_leg = None
+        if (args.img_h, args.img_w) == (120, 160) and not args.depth:
+            try:
+                image_leg = image_path_leg(local_rank)
+            except Exception as exc:
+                image_leg = {"error": str(exc)}
+            try:
+                filtered_leg = filtered_step_leg(local_rank)
+            except Exception as exc:
+                filtered_leg = {"error": str(exc)}
         env.set_step_mode(resident, 100000)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -691,6 +777,10 @@ def main():
             also["config1_car_loop"] = car_leg
         if phys_leg:
             also["physics_256"] = phys_leg
+        if image_leg:
+            also["image_path"] = image_leg
+        if filtered_leg:
+            also["filtered_step"] = filtered_leg
     if dist is not None:
         wall = max_over_ranks(wall, host_group)
 

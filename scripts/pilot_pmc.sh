@@ -12,7 +12,7 @@ pass() {  # name, counters...
   rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -o p -- python3 bench.py --no-cpu-baseline --pilot --envs-per-gpu ${PL_ENVS:-1024} --steps 6 --warmup 2 "${EXTRA[@]}" > /dev/null 2>gpurun_out/pmc_${tag}_$name.err
 }
 pass sq SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU &&
-pass tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE &&
+{ [ -n "$PL_SQ_ONLY" ] || pass tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE; } &&
 python3 - <<PY
 import csv,glob,collections
 def label(k):

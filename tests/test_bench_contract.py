@@ -38,6 +38,16 @@ def test_bench_line_has_the_contract_keys():
     assert "error" not in p2 and p2["envs"] == 256 and p2["us_per_step_spl1"] > 0 and p2["us_per_step_spl16"] > 0 and p2["env_steps_per_s_spl16"] > 1e6
     assert p2["tick_launch_us"] > 0 and p2["tick_resident_us"] > 0            # the consumer-paced tick, launched and posted to the resident physics worker
     assert d["value_incl_worker_launch"] > 0 and d["config"]["launcher"] in ("self", "external", "torch.distributed.run")
+    # the image path and the filtered step are in the driver's line
+    ip = also["image_path"]
+    assert "error" not in ip
+    for shape in ("1024x120x160", "256x240x320"):
+        assert {"trim", "trim_dynamic_brightness", "trim_hsv_masks", "trim_dynamic_masks_canny"} <= set(ip[shape])
+        for leg in ip[shape].values():
+            assert leg["us_per_batch"] > 0 and leg["GBps"] > 0 and 0 < leg["frac_of_hbm_peak"] < 1
+    fs = also["filtered_step"]
+    assert "error" not in fs and {"raw_frames", "static_palette_filter", "dynamic_brightness"} <= set(fs)
+    assert all(fs[k]["us_per_step"] > 0 for k in ("raw_frames", "static_palette_filter", "dynamic_brightness"))
 
 
 def _json_lines(out):

@@ -77,27 +77,25 @@ def test_configs4_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
     and activations, i.e. the product's stated arithmetic, any summation order) — and KerasPilot's post-processing is the
     reference's scalar Python (keras_pilot.py:78-95).  240x320 RGB + depth.
 
-    Round 4: the stimulus is raised instead of the threshold lowered.  The speed output is biased by + 0.45 (a
-    predicted speed of ~9 units/s: full throttle for the whole run) and the steering column of the output layer is scaled by 12, so that
-    the cars accelerate to > 3 units/s within 24 ticks and steer by tenths of the lock, crossing dozens of track points each.
+    The stimulus (rounds 4-5): a Glorot-random network's outputs barely depend on the image, so the test shapes the
+    output layer until the controls matter.  The speed output is biased by + 0.45 (a predicted speed of ~9 units/s: full throttle for the whole
+    run: the cars reach ~8 units/s); the steering column is scaled by 24 and its bias is set so that the first frames steer by 0.2 of the lock on
+    average (the mean raw output x 24 alone would be 0.62: three of eight cars leave the road within the 24 ticks).  Measured on the oracle side
+    (which is where `steer_seen` comes from): steering std 0.0285 over cars and ticks, |steer| max 0.26, every car on the road, dozens of track
+    points crossed each.  Round 4 had scaled by 12 only, measured std 0.0144 and lowered the assertion to 0.005 against its own docstring; the
+    assertion is 0.02 again, as first written.
 
-    Tolerances from the MEASURED control error (gpurun_out/r04_t1.log, printed by the test): the two pilots differ by fp32 summation order in
-    front of fp16 roundings — 5.6e-4 per raw output here (6.7e-3 on the steering after the x 12; tests/test_pilot.py measures <= 4e-4 on single
-    passes) and 3.6e-4 on the throttle (atan's slope at ~0.9 of full scale is small); after 24 ticks at up to 8 units/s the states differ by
-    8e-4 in position, 1.1e-3 rad in yaw, 2.8e-4 in speed, 8e-4 in cte.  Asserted: about 3 x those values (round 3 asserted 3e-2 on the controls
-    and 5e-3 in pose for cars that moved 0.1 unit)."""
+    Tolerances from the MEASURED control error (printed by the test): the two pilots differ by fp32 summation order in front of fp16 roundings —
+    ~5.6e-4 per raw output (tests/test_pilot.py measures <= 4e-4 on single passes), i.e. ~1.3e-2 on the steering after the x 24, and 3.6e-4 on the
+    throttle (atan's slope at ~0.9 of full scale is small); the states then differ by ~1e-3 after 24 ticks at 8 units/s.  Asserted: 2-3 x the measured values."""
     from test_pilot import make_weights, pilot_postprocess, torch_layer, torch_tail
     n, h, w, ticks = 8, 240, 320, 24
     ws = make_weights(h, w, seed=19)
-    ws[-2] = ws[-2].copy(); ws[-2][:, 0] *= 12.0                      # steering that matters ...
+    ws[-2] = ws[-2].copy(); ws[-2][:, 0] *= 24.0                      # steering that matters (its bias: below, from the first frames) ...
     ws[-1] = ws[-1] + np.float32([0.0, 0.45])                         # ... and a throttle that makes the cars move (as tests/test_pilot.py:149 does)
     cfg = {"spd_ctl_threshold": 1.1, "spd_ctl_reverse_multiplier": 1.0}
-    g = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True)
-    g.pilot_load(ws)
-    g.step_pilot(1, cfg)                                             # tick 1: no frame yet -> (0, 0, 0)
     o = make_env("oracle", n_envs=n, img_h=h, img_w=w, depth=True)
     o.step(0.0, 0.0, 0.0)
-    assert np.array_equal(g.fetch("img"), o.fetch("img"))
     seg0 = o.fetch("seg_idx").copy()
 
     def mirror_pilot(frames):
@@ -105,6 +103,12 @@ def test_configs4_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
         for layer in range(8):
             x = torch_layer(layer, x, ws, mirror=True)
         return torch_tail(x, ws)
+
+    ws[-1] = ws[-1] - np.float32([mirror_pilot(o.fetch("img"))[:, 0].mean() - 0.2, 0.0])   # the first frames steer by 0.2 of the lock on average
+    g = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True)
+    g.pilot_load(ws)
+    g.step_pilot(1, cfg)                                             # tick 1: no frame yet -> (0, 0, 0)
+    assert np.array_equal(g.fetch("img"), o.fetch("img"))
 
     worst_ctl = np.zeros(3)
     steer_seen = []
@@ -125,9 +129,10 @@ def test_configs4_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
     # the stimulus: the loop is compared where the controls matter
     assert o.fetch("speed").max() > 3.0 and o.fetch("speed").min() > 2.0
     assert moved.min() >= 5                                           # every car crossed track-point boundaries
-    assert np.abs(steer_seen).max() > 0.1 and steer_seen.std() > 0.005   # a quarter of the steering lock, varying with what each car sees
-    assert worst_ctl[0] <= 2e-2 and worst_ctl[1] <= 1.2e-3 and worst_ctl[2] == 0.0, worst_ctl
-    for name, tol in (("pos_x", 3e-3), ("pos_z", 3e-3), ("yaw", 4e-3), ("speed", 1e-3), ("cte", 3e-3)):
+    assert np.abs(steer_seen).max() > 0.2 and steer_seen.std() > 0.02    # a quarter of the steering lock, varying with what each car sees (0.02: as first written in round 4)
+    assert o.fetch("done").sum() == 0                                 # ... and every car still on the road
+    assert worst_ctl[0] <= 3e-2 and worst_ctl[1] <= 1.2e-3 and worst_ctl[2] == 0.0, worst_ctl
+    for name, tol in (("pos_x", 4e-3), ("pos_z", 4e-3), ("yaw", 6e-3), ("speed", 1e-3), ("cte", 4e-3)):
         assert errs[name] <= tol, (name, errs[name])
     assert np.count_nonzero(g.fetch("seg_idx") != o.fetch("seg_idx")) <= 1
     assert np.array_equal(g.fetch("done"), o.fetch("done"))
