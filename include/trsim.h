@@ -360,7 +360,6 @@ typedef struct trs_pilot_tuning {
     int32_t chain_layers;        /* 4: conv4..conv7 in one launch (trs_conv_chain_kernel) when F frames of every activation fit LDS; 3: conv5..7; 0: off */
     int32_t dense;               /* 1: dense1 / dense4 with 64 frames per workgroup where K is long (240x320), else 32; 2: always 32 (A/B) */
     int32_t ksplit;              /* 0: automatic; else K slices of dense1 */
-    int32_t chain_mfma;          /* 32: the chain on v_mfma_f32_32x32x16_f16 (trs_conv_chain_kernel); 16: on v_mfma_f32_16x16x32_f16 with two-plane LDS images and column tables (trs_conv_chain16_kernel, round 5) */
 } trs_pilot_tuning;
 void trs_default_pilot_tuning(trs_pilot_tuning* t);
 int trs_pilot_set_tuning(trs_env* env, const trs_pilot_tuning* t_or_null);

@@ -103,7 +103,6 @@ class TrsPilotTuning(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("no_fuse", C.c_int32), ("fuse_band_r2", C.c_int32), ("fuse_wsplit_max", C.c_int32), ("fuse_roll", C.c_int32),
         ("span_layers_mask", C.c_int32), ("frame5", C.c_int32), ("frame_layers_mask", C.c_int32), ("chain_layers", C.c_int32), ("dense", C.c_int32), ("ksplit", C.c_int32),
-        ("chain_mfma", C.c_int32),
     ]
 
 

@@ -578,8 +578,9 @@ __global__ __launch_bounds__(BLOCK, 2) void trs_conv_chain_kernel(const ChainPar
     }
 }
 
-#include "trsim_pilot_chain16.hpp"   // the same chain on v_mfma_f32_16x16x32_f16 with a two-plane, table-driven LDS image (round 5)
-
+// (Round 5 rebuilt this chain on v_mfma_f32_16x16x32_f16 with a conflict-free LDS image — two planes of channel granules, host tables that fill 16-pixel blocks by
+// residue class: bank conflicts 46 % -> 9.5 % of the LDS cycles, MFMA cycles -15 % — and it was 7-14 % SLOWER on every box: the K loops are bound by the instructions
+// around the MFMAs, and a 16x16x32 MFMA takes twice the issue slots per FLOP.  Removed again; profiles/r05_pilot_chain16.txt has the numbers and the stamps.)
 // ---- conv3 with its input frames in LDS (round 2) -----------------------------------------------------------------------------
 // conv3 (5x5 stride 2, 32 -> 64 channels) on the span kernel below reads three 1 KB fragments from LDS per two MFMAs (its weights
 // live in LDS: 192 B/clk per CU at full MFMA rate against the 128 the LDS delivers) — 43 us per 1024 frames.  This is the frame
@@ -1687,7 +1688,6 @@ struct PilotCtx {
     const uint8_t* last_frames = nullptr; bool act0_valid = false;           // conv1's activation is only materialised on demand (debug getter)
     void* slab = nullptr; size_t slab_bytes = 0;   // dense1 partial sums [slices][n][100] fp32
     int chain_first = -1, chain_lds = 0; ChainParams chain{};   // conv(chain_first + 1) .. conv7 in one launch (trs_conv_chain_kernel); -1: layer by layer
-    bool chain16 = false; Chain16Params chain16p{}; int chain16_lds = 0; u4v* chain16_cols = nullptr;   // the chain on 16x16x32 MFMAs (trs_conv_chain16_kernel) with its column tables
     bool chain_mid_valid = true;          // act[chain_first .. 5] hold the last pass (the chain never writes them; the debug getter runs the single layers on demand)
     u4v* w2_parity = nullptr;             // conv2's granules in the band kernel's order: per kernel row the even conv1 columns (kw 0, 2, 4), then the odd (1, 3)
     trs_pilot_tuning tun{};               // the kernel choices this context was loaded with (trs_pilot_set_tuning, else the defaults)
@@ -1708,7 +1708,6 @@ void free_ctx(PilotCtx* c)
     for (auto& a : c->act) (void)hipFree(a);
     (void)hipFree(c->w2); (void)hipFree(c->b2); (void)hipFree(c->w3); (void)hipFree(c->b3); (void)hipFree(c->w4); (void)hipFree(c->b4);
     (void)hipFree(c->raw); (void)hipFree(c->tmp_frames); (void)hipFree(c->slab); (void)hipFree(c->slab2); (void)hipFree(c->xblob); (void)hipFree(c->w2_parity);
-    (void)hipFree(c->chain16_cols);
     delete c;
 }
 
@@ -1854,17 +1853,10 @@ int forward(PilotCtx* c, const TrsEnvView& v, const uint8_t* d_frames, int n)
     c->chain_mid_valid = c->chain_first < 0;
     for (int i = first; i < 8; ++i) {
         if (i == c->chain_first) {                                          // conv(i + 1) .. conv7 in one launch, activations in LDS
-            if (c->chain16) {
-                Chain16Params q = c->chain16p;
-                q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain16_kernel<64 * TRS_C16_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain16_lds));
-                hipLaunchKernelGGL(trs_conv_chain16_kernel<64 * TRS_C16_WAVES>, dim3((n + q.F - 1) / q.F), dim3(64 * TRS_C16_WAVES), c->chain16_lds, v.stream, q);
-            } else {
-                ChainParams q = c->chain;
-                q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
-                hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
-            }
+            ChainParams q = c->chain;
+            q.in = static_cast<const u4v*>(in); q.out = static_cast<unsigned short*>(c->act[6]); q.N = n;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_conv_chain_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, c->chain_lds));
+            hipLaunchKernelGGL(trs_conv_chain_kernel<512>, dim3((n + q.F - 1) / q.F), dim3(512), c->chain_lds, v.stream, q);
             HIPCHK(hipGetLastError());
             in = c->act[6];
             in_bytes = (size_t)n * c->act_elems[6] * 2;
@@ -1985,7 +1977,7 @@ TRS_EXPORT void trs_default_pilot_tuning(trs_pilot_tuning* t)
     std::memset(t, 0, sizeof *t);
     t->struct_size = (uint32_t)sizeof *t;
     t->fuse_band_r2 = 6; t->fuse_wsplit_max = 4; t->span_layers_mask = 0x6;
-    t->fuse_roll = 1; t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->dense = 1; t->chain_mfma = 32;
+    t->fuse_roll = 1; t->frame5 = 1; t->frame_layers_mask = 0x78; t->chain_layers = 4; t->dense = 1;
 }
 
 TRS_EXPORT int trs_pilot_set_tuning(trs_env* e, const trs_pilot_tuning* t)
@@ -2307,103 +2299,6 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                     q.L[j] = ChainLayer{l.w, l.bias, l.IH, l.IW, l.OH, l.OW, l.COUT, l.CIN / 8, l.CIN / 8 == 8 ? 3 : 4, nt, 2, magic(l.OH * l.OW), magic(l.OW)};
                 }
                 c->chain_first = first; c->chain_lds = (int)total;
-            }
-        }
-        // ... the same chain on 16x16x32 MFMAs (trsim_pilot_chain16.hpp): two-plane LDS images, column tables, items of pb x 16 pixels by cb x 16 channels
-        c->chain16 = false;
-        if (c->chain_first >= 0 && T.chain_mfma == 16) {
-            const ChainParams& o = c->chain;
-            const int first = c->chain_first, nl = o.nl, f = o.F;
-            const bool split = o.split_first != 0;
-            Chain16Params q{};
-            q.F = f; q.nl = nl; q.split_first = o.split_first;
-            auto align256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-            auto units_in = [&](int j) { return (split && j == 0) ? f / 2 : f; };
-            // Per layer: the padding between the units of its INPUT image.  A column of a block must hold a pixel of ITS residue class (window start = i mod 16),
-            // so a layer needs max-class-size blocks; with the units IH x IW pixels apart the classes of these small images are uneven (conv7 at 120x160: 11
-            // blocks for 144 pixels).  A few pixels of padding per unit shift the units' rows against each other until every class is ceil(pixels / 16) or
-            // one more: 9 blocks.  The smallest padding (< 16 pixels) with the smallest largest class is taken.
-            int unit_in[4]; size_t plane[4], img[4];
-            std::vector<std::vector<u4v>> cls_of[4];
-            for (int j = 0; j < nl; ++j) {
-                const ConvLayer& l = c->L[first + j];
-                const int units = units_in(j), ihw = l.IH * l.IW;
-                int best_pad = 0; size_t best_max = (size_t)-1;
-                for (int pad = 0; pad < 16; ++pad) {
-                    size_t cnt[16] = {};
-                    for (int ul = 0; ul < units; ++ul)
-                        for (int oy = 0; oy < l.OH; ++oy)
-                            for (int ox = 0; ox < l.OW; ++ox) ++cnt[(ul * (ihw + pad) + oy * l.IW + ox) & 15];
-                    const size_t mx = *std::max_element(cnt, cnt + 16);
-                    if (mx < best_max) { best_max = mx; best_pad = pad; }
-                }
-                unit_in[j] = ihw + best_pad;
-                plane[j] = align256((size_t)units * unit_in[j] * (l.CIN / 16) * 16);
-                img[j] = 2 * plane[j];
-            }
-            // regions as in the 32x32 chain: split: A = conv4 out / conv6 out, B = conv4 in (two frames at a time) / conv5 out; else A = first in / second out, B = first out
-            // (an image holds F units even where a pass writes or reads half of them)
-            auto img_full = [&](int j) { return 2 * align256((size_t)f * unit_in[j] * (c->L[first + j].CIN / 16) * 16); };
-            size_t a, b;
-            if (split) { a = std::max(img_full(1), img_full(3)); b = std::max(img[0], img_full(2)); }
-            else { a = std::max(img_full(0), img_full(2)); b = img_full(1); }
-            const size_t total = a + b + 4 * 128 * 4;
-            bool ok = total <= 160 * 1024;
-            std::vector<u4v> cols;
-            constexpr int nw = TRS_C16_WAVES;                                   // waves per workgroup
-            for (int j = 0; j < nl && ok; ++j) {
-                const ConvLayer& l = c->L[first + j];
-                const int units = units_in(j);
-                if (j > 0 || !split) plane[j] = img_full(j) / 2;                // every image but a split first layer's holds F units
-                // columns by residue class: column i of every block holds a valid output pixel whose window's first input pixel p (linear index in the
-                // LDS image) is = i (mod 16); block t takes the t-th such pixel of every class.  A class that has run out repeats its last pixel without an
-                // output slot (its reads stay conflict-free, its results are dropped).
-                std::vector<std::vector<u4v>> cls(16);
-                const int unit_out = j + 1 < nl ? unit_in[j + 1] : 0;
-                for (int ul = 0; ul < units; ++ul)
-                    for (int oy = 0; oy < l.OH; ++oy)
-                        for (int ox = 0; ox < l.OW; ++ox) {
-                            const unsigned pidx = (unsigned)(ul * unit_in[j] + oy * l.IW + ox), m = (unsigned)((ul * l.OH + oy) * l.OW + ox);
-                            cls[pidx & 15].push_back(u4v{pidx, m, (unsigned)(ul * unit_out + oy * l.OW + ox), 0u});
-                        }
-                size_t nblk = 0;
-                for (auto& v : cls) { nblk = std::max(nblk, v.size()); if (v.empty()) ok = false; }
-                if (!ok) break;
-                // items: pb pixel blocks x cb channel blocks; the split that leaves the busiest of the 4 waves the fewest MFMAs per k-step, and among equals the one
-                // with the fewest pixel groups (every pixel group fetches the layer's weights again: the L1 weight stream is what bounds this kernel)
-                const int ncb = l.COUT / 16, best_cb = 2, ncg = ncb / 2;
-                int best_pb = 0; long best_cost = 1L << 60;
-                for (int pb : kChain16Pb) {
-                    if (nw == 8 && pb > 9) continue;                            // (two waves per SIMD: 256 registers each)
-                    const int npg = ((int)nblk + pb - 1) / pb, items = npg * ncg;
-                    const int per_wave = (items + nw - 1) / nw;
-                    const long cost = ((long)per_wave * pb * 2 * 16 + (long)per_wave * 30) * 64 + npg;
-                    if (cost < best_cost) { best_cost = cost; best_pb = pb; }
-                }
-                // (the kernel's layers: 64 channels out of 64 for every layer but the last two: 128 out of 64, 128 out of 128)
-                if ((j == 0 && l.COUT != 64) || (j == nl - 1 && l.COUT != 128) || (l.COUT != 64 && l.COUT != 128)) { ok = false; break; }
-                const int npg = ((int)nblk + best_pb - 1) / best_pb;
-                Chain16Layer& L = q.L[j];
-                L = Chain16Layer{};
-                L.w = l.w; L.bias = l.bias;
-                L.IW = l.IW; L.IHW = l.IH * l.IW; L.OHW = l.OH * l.OW; L.COUT = l.COUT; L.cg = l.CIN / 8; L.cgs = l.CIN / 8 == 8 ? 3 : 4;
-                L.unit_in = unit_in[j];
-                L.pb = best_pb; L.cb = best_cb; L.n_pgroups = npg; L.n_cgroups = ncb / best_cb;
-                L.plane_in = (int)plane[j];
-                L.cols = reinterpret_cast<const u4v*>(cols.size());            // offset for now; the base is added after the upload
-                for (int blk = 0; blk < npg * best_pb; ++blk)
-                    for (int i = 0; i < 16; ++i) {
-                        const auto& v = cls[i];
-                        cols.push_back((size_t)blk < v.size() ? v[blk] : u4v{v.back().x, 0xffffffffu, 0u, 0u});
-                    }
-            }
-            if (ok) {
-                (void)hipFree(c->chain16_cols); c->chain16_cols = nullptr;
-                int rcc = upload(&c->chain16_cols, cols);
-                if (rcc) return rcc;
-                for (int j = 0; j < nl; ++j) q.L[j].cols = c->chain16_cols + (size_t)reinterpret_cast<uintptr_t>(q.L[j].cols);
-                q.offA = 0; q.offB = (int)a; q.off_bias = (int)(a + b);
-                c->chain16p = q; c->chain16_lds = (int)total; c->chain16 = true;
             }
         }
     }
