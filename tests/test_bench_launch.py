@@ -92,3 +92,22 @@ def test_spawn_flag_takes_the_launch_path_at_one_gpu(tmp_path):
     """, n=1, extra=("--spawn",))
     assert out.returncode == 0, out.stderr[-2000:]
     assert json.loads(out.stdout.strip()) == {"world": "1", "rank": "0"}
+
+
+def test_a_rank_that_stalls_in_a_phase_says_which_and_exits_3(tmp_path):
+    """bench.phase (round 5): a rendezvous / barrier / collective that can only stall on ANOTHER rank is bracketed by a watchdog — the rank
+    names the phase it is stuck in and exits with code 3 instead of waiting for torch.distributed's own timeout; the parent then stops the other ranks.  Driven with
+    stub ranks that use the real `phase` class of bench.py: rank 1 never reaches the barrier rank 0 waits at."""
+    out = _run(tmp_path, f"""
+        import os, sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        if os.environ["RANK"] == "0":
+            with bench.phase("host barrier (gloo)", 0.5):
+                time.sleep(30)        # the peer never arrives
+        else:
+            time.sleep(30)
+    """)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert "rank 0 stalled in phase 'host barrier (gloo)'" in out.stderr
+    assert "rank 0 exited with code 3" in out.stderr

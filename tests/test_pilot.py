@@ -141,6 +141,63 @@ def test_closed_loop_controls_follow_the_reference_tick_order(make_env):
     assert np.array_equal(a.fetch("img"), b.fetch("img"))
 
 
+def test_closed_loop_frames_stay_whole_when_uniform_rows_are_kept(make_env):
+    """Round 5: the closed loop's env steps write the uniform rows of a frame buffer (sky, beyond the far plane: 41 % of the bytes) only when the buffer
+    does not hold them yet.  Every frame of the loop must still be the oracle's frame for the pose it shows — across a frame-filter change (another palette,
+    other uniform rows), steps of other kinds in between (a resident worker, multi-step launches) and a track reload.  RGB + depth.  The comparison
+    is a fresh handle that renders WHOLE frames (plain trs_step) of the same step from the same state: that path is what tests/test_gpu_parity.py pins to the oracle."""
+    n, h, w = 6, 120, 160
+    g = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True)
+    ws = make_weights(h, w, seed=5)
+    ws[-1] = ws[-1] + np.float32([0.0, 0.4])
+    g.pilot_load(ws)
+    flt = {"preprocessing_color_filter_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.3}
+
+    g.step_pilot(7)                                                    # both buffers written whole once, then ground rows only
+    g.sync()
+    # the loop's latest frame against a fresh handle's whole-frame render of the same pose and controls
+    def same_as_whole_frames(where, filt=None):
+        ref = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True)
+        if filt:
+            ref.set_frame_filter(filt)
+        ref.step(0.0, 0.0, 0.0)
+        # replay the loop's last step from the state in front of it: the loop leaves (pose after the step, controls it used)
+        ref.set_pose(prev["pos_x"], prev["pos_y"], prev["pos_z"], prev["yaw"], prev["vel"])
+        ref.step(last_ctl[0], last_ctl[1], last_ctl[2])
+        assert np.array_equal(ref.fetch("img"), g.fetch("img")), where
+        assert np.array_equal(ref.fetch("depth").view(np.uint32), g.fetch("depth").view(np.uint32)), where
+
+    def one_tick():
+        nonlocal prev, last_ctl
+        prev = {k: g.fetch(k).copy() for k in ("pos_x", "pos_y", "pos_z", "yaw", "vel")}
+        g.step_pilot(1)
+        last_ctl = (g.fetch("ctl_steer").copy(), g.fetch("ctl_thr").copy(), g.fetch("ctl_brk").copy())
+
+    prev, last_ctl = None, None
+    for k in range(4):
+        one_tick()
+        same_as_whole_frames(f"plain loop, tick {k}")
+    g.set_frame_filter(flt)                                            # another palette: both buffers' uniform rows are stale now
+    for k in range(3):
+        one_tick()
+        same_as_whole_frames(f"filtered loop, tick {k}", flt)
+    g.set_frame_filter(enabled=False)
+    g.step_synthetic(5, 4)                                             # multi-step launches in between
+    g.set_step_mode(True); g.step_synthetic(3, 1); g.set_step_mode(False)   # ... and a resident worker
+    for k in range(3):
+        one_tick()
+        same_as_whole_frames(f"after other step kinds, tick {k}")
+    g.load_track("mountain_track")
+    g.step_pilot(3)
+    for k in range(2):
+        one_tick()
+        ref = make_env("hip", n_envs=n, img_h=h, img_w=w, depth=True, track="mountain_track")
+        ref.step(0.0, 0.0, 0.0)
+        ref.set_pose(prev["pos_x"], prev["pos_y"], prev["pos_z"], prev["yaw"], prev["vel"])
+        ref.step(*last_ctl)
+        assert np.array_equal(ref.fetch("img"), g.fetch("img")), f"after a track reload, tick {k}"
+
+
 def test_cnn_2d_model_type_closed_loop(make_env):
     """ModelType.CNN_2D (keras_pilot.py:56-64): the same network, outputs are (steering, throttle) capped to [-1, 1],
     breaking 0, smooth steering applied - against the loop done by hand."""

@@ -20,6 +20,7 @@ struct trs_env {
     // device memory
     unsigned char* slab = nullptr;       // state + controls
     uint8_t* img[2] = {nullptr, nullptr};
+    bool uniform_ok[2] = {false, false}; // frame buffer b holds the current palette's uniform rows (sky, beyond the far plane) of every env (launch_step)
     float* depth[2] = {nullptr, nullptr};
     unsigned char* blob_p = nullptr;     // physics LDS image
     unsigned char* blob_r = nullptr;     // raster LDS image

@@ -986,6 +986,7 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.ph = e->pp; wp.ph.synth = 0; wp.ph.write_cam = 0; wp.ph.n_steps = 0; wp.ph.step_off = 0; wp.ph.ctl_stride = 0;
     wp.ra = e->rp;
     wp.img0 = e->img[0]; wp.img1 = e->img[1]; wp.dep0 = e->depth[0]; wp.dep1 = e->depth[1];
+    e->uniform_ok[0] = e->uniform_ok[1] = false;            // (launch_step's bookkeeping of which buffer holds whole frames of the current palette: not kept across a worker)
     wp.mb = mb; wp.dc = R->dc;
     wp.start = start;
     wp.idle_ticks = (unsigned long long)R->idle_us * 100ull;
