@@ -93,7 +93,8 @@ enum {
     TRS_F_ROWDEPTH,  /* float[img_h] */
     TRS_F_CTL_STEER, /* float[n_envs]: the handle's own control arrays — what trs_step_host uploaded or the pilot of  */
     TRS_F_CTL_THR,   /*   trs_step_pilot produced last ('ai/steering', 'ai/throttle', 'ai/breaking' of KerasPilot.step, */
-    TRS_F_CTL_BRK    /*   keras_pilot.py:92-95)                                                                       */
+    TRS_F_CTL_BRK,   /*   keras_pilot.py:92-95)                                                                       */
+    TRS_F_DPITCH     /* float[n_points]: the view-pitch offset per raw track point of a track with elevation (include/trsim_spec.h, "tracks with elevation"); all zeros on a flat track */
 };
 
 typedef struct trs_map_info {

@@ -87,6 +87,35 @@
  *   SKY/FAR rows have row_lz = row_k = 0 and a palette whose 4 entries are equal.
  *   depth channel (optional, binary32 [H][W]): z-depth of the ground plane, constant along an image row:
  *     GROUND row: (float)(t*dz) world units;  SKY and FAR rows: (float)z_far.
+ *
+ * ---- tracks with elevation (round 5) -----------------------------------------
+ *   The raw points carry a height y (reference car_templates/track_data/mountain_track.json: y in 3.19 .. 7.35).  A track is HILLY when
+ *   max y - min y > TRS_HILL_MIN_RANGE; flat tracks (generated_track: 0.011) keep everything above, bit for bit.  On a hilly track the car
+ *   stands on the road's local slope and looks at a road that tilts against it ahead: the camera is fixed to the car, so what changes in
+ *   its image is the angle between its axis and the ground plane AHEAD.  The ground the camera sees is modelled as ONE plane per env and
+ *   frame — through the camera's foot point, tilted against the car's own plane by the change of slope between the car's track point
+ *   and a point TRS_HILL_AHEAD samples further on — i.e. the flat-ground camera above with a PER-ENV pitch (height cam_h and forward
+ *   offset cam_fwd unchanged: the rotation is taken about the camera, a documented approximation).  Row tables and the fogged palette
+ *   then depend on the env and the frame; they are evaluated in binary32 with the operation order below (host tables in binary64 as
+ *   before):
+ *   host, binary64, per raw point i (indices wrap, the track is closed):
+ *     h_i     = horizontal length of the step from point i to point i+1:  sqrt((Px[i+1]-Px[i])^2 + (Pz[i+1]-Pz[i])^2)   (0 for duplicates)
+ *     d_i     = h_{i-L} + h_{i-L+1} + ... + h_{i+L-1}    (the path from point i-L to point i+L, summed in this order), L = TRS_HILL_SPAN
+ *     g_i     = d_i > 1e-9 ? (Py[i+L] - Py[i-L]) / d_i : 0                      (smoothed grade)
+ *     theta_i = atan(g_i)
+ *     dpitch[i] = (float)clamp(theta_{i+A} - theta_i, -TRS_HILL_MAX_DPITCH, TRS_HILL_MAX_DPITCH),  A = TRS_HILL_AHEAD
+ *     sky[v]  = the SKY colour of image row v as above, for EVERY row v (g = min((v+0.5)/(H/2), 1))
+ *     far     = the FAR colour as above;  inv_f = (float)(1/f); hh = (float)(H/2); pitch_f = (float)pitch; cam_h_f, z_far_f = (float) of theirs;
+ *     inv_zfar_f = (float)(1/z_far); inv_cell_f = (float)(1/cell) (exact); fog_f = (float)TRS_FOG_MAX; base / fog colours as binary32
+ *   per env and frame, binary32 (R1: every operation rounded, no contraction), idx = the step's nearest raw track point:
+ *     P = pitch_f + dpitch[idx];   (sp, cp) = trs_sincos(P)
+ *     per image row v:  yn = (hh - ((float)v + 0.5f)) * inv_f;   dy = yn*cp - sp;   dz = yn*sp + cp
+ *       dy >= -1e-6f                  -> SKY row:  row_lz = row_k = 0, depth z_far_f, the four class colours = sky[v]
+ *       t = cam_h_f / (-dy);  zd = t*dz;  zd > z_far_f -> FAR row: row_lz = row_k = 0, depth z_far_f, colours = far
+ *       else GROUND row: row_lz = zd * inv_cell_f;  row_k = (t * inv_f) * inv_cell_f;  depth = zd
+ *            fw = fog_f * (zd * inv_zfar_f);  colour[c][ch] = (int)((base[c][ch] * (1.0f - fw) + fog[ch] * fw) + 0.5f)
+ *     pixels exactly as above with these row tables.  The depth frame is constant along a row of one frame, and now differs from env to env
+ *     and from frame to frame with the slope ahead.
  */
 #ifndef TRSIM_SPEC_H
 #define TRSIM_SPEC_H
@@ -136,6 +165,12 @@
 #define TRS_DEF_CAM_PITCH_DEG   10.0
 #define TRS_DEF_CAM_FWD         0.3f
 #define TRS_DEF_Z_FAR           40.0
+
+/* tracks with elevation */
+#define TRS_HILL_MIN_RANGE      0.25           /* max y - min y of the raw points above which a track is hilly */
+#define TRS_HILL_SPAN           8              /* grade over +- this many samples */
+#define TRS_HILL_AHEAD          24             /* the slope this many samples ahead against the slope here */
+#define TRS_HILL_MAX_DPITCH     0.2            /* rad */
 
 /* map classes */
 #define TRS_CLS_GRASS   0

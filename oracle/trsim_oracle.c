@@ -52,6 +52,12 @@ struct trs_env {
     uint32_t* pal;             /* [H][4] */
     float* rowdepth;           /* [H] */
     float* depth;              /* [n][H][W] when cfg.depth */
+    /* tracks with elevation (include/trsim_spec.h): per-point view-pitch offsets and what the per-env row tables need */
+    int hills;
+    float* dpitch;             /* [np] */
+    uint32_t* sky;             /* [H] sky colour of every row */
+    uint32_t far_rgb;
+    float inv_f, hh, pitch_f, cam_h_f, z_far_f, inv_zfar_f, fog_f;
     float map_x0f, map_z0f, inv_cellf;
     /* state */
     float *x, *y, *z, *yaw, *v, *speed, *cte, *ep_return, *last_return, *steer_filt;
@@ -189,14 +195,52 @@ static void render_env(struct trs_env* e, int i, float s, float c)
     float camz = ((e->z[i] + k->cam_fwd * c) - e->map_z0f) * e->inv_cellf;
     uint8_t* out = e->img + (size_t)i * H * W * 3;
     float half_w = (float)(W / 2);
+    /* row tables of THIS frame: the host's (flat track), or the env's own from the slope ahead of its track point (hilly track) */
+    const float* rowtab = e->rowtab; const uint32_t* palt = e->pal; const float* rowdepth = e->rowdepth;
+    float* h_rt = NULL; uint32_t* h_pal = NULL; float* h_dep = NULL;
+    if (e->hills) {
+        static const int base[4][3] = { TRS_RGB_GRASS, TRS_RGB_ROAD, TRS_RGB_EDGE, TRS_RGB_CENTRE };
+        static const int fog[3] = TRS_RGB_FOG;
+        h_rt = malloc(sizeof(float) * 2 * H); h_pal = malloc(sizeof(uint32_t) * 4 * H); h_dep = malloc(sizeof(float) * H);
+        float P = e->pitch_f + e->dpitch[e->seg_idx[i]], sp, cp;
+        spec_sincos(P, &sp, &cp);
+        for (int v = 0; v < H; ++v) {
+            float yn = (e->hh - ((float)v + 0.5f)) * e->inv_f;
+            float dy = yn * cp - sp, dzr = yn * sp + cp;
+            float lz = 0.0f, kk = 0.0f, dep = e->z_far_f;
+            uint32_t col[4];
+            if (dy >= -1e-6f) { for (int cc = 0; cc < 4; ++cc) col[cc] = e->sky[v]; }
+            else {
+                float t = e->cam_h_f / (-dy);
+                float zd = t * dzr;
+                if (zd > e->z_far_f) { for (int cc = 0; cc < 4; ++cc) col[cc] = e->far_rgb; }
+                else {
+                    lz = zd * e->inv_cellf; kk = (t * e->inv_f) * e->inv_cellf; dep = zd;
+                    float fw = e->fog_f * (zd * e->inv_zfar_f), om = 1.0f - fw;
+                    for (int cc = 0; cc < 4; ++cc) {
+                        uint32_t rgb = 0;
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float a = (float)base[cc][ch] * om, b = (float)fog[ch] * fw;
+                            float sum = a + b;
+                            rgb |= (uint32_t)(int)(sum + 0.5f) << (8 * ch);
+                        }
+                        col[cc] = rgb;
+                    }
+                }
+            }
+            h_rt[2 * v] = lz; h_rt[2 * v + 1] = kk; h_dep[v] = dep;
+            for (int cc = 0; cc < 4; ++cc) h_pal[4 * v + cc] = col[cc];
+        }
+        rowtab = h_rt; palt = h_pal; rowdepth = h_dep;
+    }
     if (e->depth)
         for (int v = 0; v < H; ++v)
-            for (int u = 0; u < W; ++u) e->depth[((size_t)i * H + v) * W + u] = e->rowdepth[v];
+            for (int u = 0; u < W; ++u) e->depth[((size_t)i * H + v) * W + u] = rowdepth[v];
     for (int v = 0; v < H; ++v) {
-        float lz = e->rowtab[2 * v], kk = e->rowtab[2 * v + 1];
+        float lz = rowtab[2 * v], kk = rowtab[2 * v + 1];
         float ax = fmaf(lz, s, camx), az = fmaf(lz, c, camz);
         float dx = kk * c, dz = -(kk * s);
-        const uint32_t* pal = e->pal + 4 * v;
+        const uint32_t* pal = palt + 4 * v;
         for (int u = 0; u < W; ++u) {
             float uf = (float)u + 0.5f - half_w;
             float gx = fmaf(uf, dx, ax), gz = fmaf(uf, dz, az);
@@ -210,6 +254,7 @@ static void render_env(struct trs_env* e, int i, float s, float c)
             out += 3;
         }
     }
+    free(h_rt); free(h_pal); free(h_dep);
 }
 
 /* ------------------------------------------------------------------ host-side table building */
@@ -349,6 +394,48 @@ static int build_track_tables(struct trs_env* e)
         for (int c = 0; c < 4; ++c)
             e->pal[4 * v + c] = (uint32_t)rgb[c][0] | ((uint32_t)rgb[c][1] << 8) | ((uint32_t)rgb[c][2] << 16);
     }
+    /* tracks with elevation (include/trsim_spec.h): grade over +- L samples, the slope A samples ahead against the slope here */
+    {
+        double ymin = e->py[0], ymax = e->py[0];
+        for (int i = 1; i < np; ++i) { if (e->py[i] < ymin) ymin = e->py[i]; if (e->py[i] > ymax) ymax = e->py[i]; }
+        e->hills = (ymax - ymin) > TRS_HILL_MIN_RANGE;
+        free(e->dpitch); free(e->sky);
+        e->dpitch = calloc((size_t)np, sizeof(float));
+        e->sky = calloc((size_t)H, sizeof(uint32_t));
+        const int L = TRS_HILL_SPAN, A = TRS_HILL_AHEAD;
+        double* hstep = malloc(sizeof(double) * np), *theta = malloc(sizeof(double) * np);
+        for (int i = 0; i < np; ++i) {
+            int j = (i + 1) % np;
+            double ddx = e->px[j] - e->px[i], ddz = e->pz[j] - e->pz[i];
+            hstep[i] = sqrt(ddx * ddx + ddz * ddz);
+        }
+        for (int i = 0; i < np; ++i) {
+            double d = 0.0;
+            for (int q = -L; q < L; ++q) d += hstep[((i + q) % np + np) % np];
+            double g = d > 1e-9 ? (e->py[(i + L) % np] - e->py[((i - L) % np + np) % np]) / d : 0.0;
+            theta[i] = atan(g);
+        }
+        for (int i = 0; i < np; ++i) {
+            double dp = theta[(i + A) % np] - theta[i];
+            if (dp > TRS_HILL_MAX_DPITCH) dp = TRS_HILL_MAX_DPITCH;
+            if (dp < -TRS_HILL_MAX_DPITCH) dp = -TRS_HILL_MAX_DPITCH;
+            e->dpitch[i] = e->hills ? (float)dp : 0.0f;
+        }
+        free(hstep); free(theta);
+        for (int v = 0; v < H; ++v) {
+            double g = ((double)v + 0.5) / ((double)H / 2.0);
+            if (g > 1.0) g = 1.0;
+            uint32_t rgbv = 0;
+            for (int ch = 0; ch < 3; ++ch)
+                rgbv |= (uint32_t)(int)floor((double)sky_top[ch] + ((double)sky_hor[ch] - (double)sky_top[ch]) * g + 0.5) << (8 * ch);
+            e->sky[v] = rgbv;
+        }
+        e->far_rgb = 0;
+        for (int ch = 0; ch < 3; ++ch)
+            e->far_rgb |= (uint32_t)(int)floor((double)base[0][ch] * (1.0 - TRS_FOG_MAX) + (double)fog[ch] * TRS_FOG_MAX + 0.5) << (8 * ch);
+        e->inv_f = (float)(1.0 / f); e->hh = (float)((double)H / 2.0); e->pitch_f = (float)pitch;
+        e->cam_h_f = (float)k->cam_h; e->z_far_f = (float)k->z_far; e->inv_zfar_f = (float)(1.0 / k->z_far); e->fog_f = (float)TRS_FOG_MAX;
+    }
     return TRS_OK;
 }
 
@@ -397,7 +484,7 @@ EXPORT int trso_create(const trs_config* cfg, int device, trs_env** out)
 EXPORT int trso_destroy(trs_env* e)
 {
     if (!e) return TRS_OK;
-    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal); free(e->rowdepth); free(e->depth);
+    free(e->px); free(e->py); free(e->pz); free(e->tang); free(e->start_yaw); free(e->map); free(e->rowtab); free(e->pal); free(e->rowdepth); free(e->depth); free(e->dpitch); free(e->sky);
     free(e->x); free(e->y); free(e->z); free(e->yaw); free(e->v); free(e->speed); free(e->cte); free(e->ep_return);
     free(e->last_return); free(e->steer_filt); free(e->seg_idx); free(e->ep_len); free(e->done); free(e->pending); free(e->was_reset); free(e->img); free(e->pre); free(e->mux);
     for (int k = 0; k < 32; ++k) free(e->scratch[k]);
@@ -535,6 +622,7 @@ EXPORT int trso_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_STATS: src = e->stats; need = sizeof e->stats; break;
     case TRS_F_DEPTH: src = e->depth; need = n * e->H * e->W * 4; break;
     case TRS_F_ROWDEPTH: src = e->rowdepth; need = (size_t)e->H * 4; break;
+    case TRS_F_DPITCH: src = e->dpitch; need = (size_t)e->np * 4; break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
     if (!src) return fail(TRS_ERR_STATE, "field not available");

@@ -65,7 +65,7 @@ FIELDS = {
     "img": 0, "pos_x": 1, "pos_y": 2, "pos_z": 3, "speed": 4, "cte": 5, "yaw": 6, "vel": 7,
     "seg_idx": 8, "ep_return": 9, "last_return": 10, "ep_len": 11, "done": 12,
     "map": 13, "rowtab": 14, "palette": 15, "tangent": 16, "steer_filt": 17, "stats": 18, "depth": 19, "rowdepth": 20,
-    "ctl_steer": 21, "ctl_thr": 22, "ctl_brk": 23,
+    "ctl_steer": 21, "ctl_thr": 22, "ctl_brk": 23, "dpitch": 24,
 }
 
 # every symbol include/trsim.h declares (suffix after the prefix)

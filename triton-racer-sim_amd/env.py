@@ -21,7 +21,7 @@ _FIELD_DTYPES = {
     "cte": np.float32, "yaw": np.float32, "vel": np.float32, "seg_idx": np.int32, "ep_return": np.float32,
     "last_return": np.float32, "ep_len": np.int32, "done": np.uint8, "map": np.uint32, "rowtab": np.float32,
     "palette": np.uint32, "tangent": np.float32, "steer_filt": np.float32, "stats": np.uint64, "depth": np.float32, "rowdepth": np.float32,
-    "ctl_steer": np.float32, "ctl_thr": np.float32, "ctl_brk": np.float32,
+    "ctl_steer": np.float32, "ctl_thr": np.float32, "ctl_brk": np.float32, "dpitch": np.float32,
 }
 
 
@@ -223,6 +223,7 @@ class BatchedEnv:
         return {
             "img": (self.n, self.H, self.W, 3), "map": (mi.map_h, mi.map_words) if mi else None,
             "rowtab": (self.H, 2), "palette": (self.H, 4), "tangent": (self.n_points, 2), "stats": (64,), "depth": (self.n, self.H, self.W), "rowdepth": (self.H,),
+            "dpitch": (self.n_points,),
         }.get(name, (self.n,))
 
     def fetch(self, name):
