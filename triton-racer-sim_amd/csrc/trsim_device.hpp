@@ -39,6 +39,18 @@ struct PParams {                        // physics kernel
     int auto_reset, synth, n_steps, write_cam;
     uint32_t step_off;
     unsigned long long seed;
+    const struct HillBlock* hill;       // tracks with elevation (include/trsim_spec.h): nullptr on a flat track.  ONE pointer: what the hilly path needs lives in device
+                                        // memory and is read there — kernel arguments sit in scalar registers for the whole kernel, and ten more of them cost the
+                                        // flat-track step 4-9 % (spilled scalars come back through v_readlane in the row loops: profiles/r05_hills.txt)
+};
+
+// What the kernels need on a track with elevation, in device memory (trs_load_track fills it).
+struct HillBlock {
+    const float* vpitch;                // [np] the view pitch of a frame whose nearest raw track point is idx: (float)pitch + dpitch[idx], one binary32 addition (host)
+    float* cam_pitch;                   // [kRing][n_envs] ring of the frames' view pitches beside PParams::cam (launch mode: the next launch's first frame)
+    int off_sky;                        // raster LDS image: uint32 sky[H] (the sky colour of every row)
+    unsigned far_rgb;
+    float inv_f, hh, cam_h_f, z_far_f, inv_zfar_f, fog_f, inv_cell_f;
 };
 
 struct RParams {                        // raster side of the step kernel
@@ -50,7 +62,8 @@ struct RParams {                        // raster side of the step kernel
     int map_w, map_h, map_pitch_b;
     int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
     int depth;                          // 1 = also write the binary32 z-depth frame
-    int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane)
+    int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane); 0 on a track with elevation
+    const struct HillBlock* hill;       // tracks with elevation: a frame's row tables are evaluated per env (hill_rows_build); nullptr on a flat track (see PParams::hill)
 };
 
 struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernels (their DYN instantiations)
@@ -280,7 +293,7 @@ __device__ __forceinline__ void env_store(const PParams& p, int e, const EnvRegs
     }
 }
 // What one env step hands on besides the new state: the camera parameters of the new pose (map-cell units) and the flags.
-struct StepOut { float4 cam; int is_done, do_reset; };
+struct StepOut { float4 cam; float pitch; int is_done, do_reset; };   // pitch: the frame's view pitch on a track with elevation (0 on a flat one)
 
 template <bool WT, typename T>
 __device__ __forceinline__ void store_out(T* ptr, T v)
@@ -363,13 +376,14 @@ __device__ __forceinline__ void env_advance(const PParams& p, const unsigned cha
     const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
     const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
     o.cam = make_float4(camx, camz, hs, hc);
+    o.pitch = p.hill ? p.hill->vpitch[idx] : 0.0f;          // (every lane reads the same word: one broadcast load, requested here, needed at the hand-off)
     o.is_done = is_done; o.do_reset = do_reset;
 }
 
 // ... inside the step kernels: controls from the launch's arrays, camera parameters to the global ring (the next launch's
 // first frame) and to this launch's LDS ring, then the progress counter the raster team waits on.
 __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
-                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane)
+                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane, float* pitch_out = nullptr, float* lpitch_slot = nullptr)
 {
     const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
     float steer = 0.f, thr = 0.f, brk = 0.f;
@@ -382,6 +396,10 @@ __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* 
     if (lane == 0) {
         if (p.write_cam) cam_out[e] = o.cam;                // for the next launch (its first frame)
         *lcam_slot = o.cam;                                 // for this launch's raster team
+        if (p.hill) {                                       // a track with elevation: the frame's view pitch rides along
+            if (p.write_cam && pitch_out) pitch_out[e] = o.pitch;
+            if (lpitch_slot) *lpitch_slot = o.pitch;
+        }
         if (o.is_done) atomicAdd(&p.stats[0], 1ull);
         if (o.do_reset) atomicAdd(&p.stats[1], 1ull);
         __hip_atomic_store(pprog_j, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // publish: step k of this env is done
@@ -414,6 +432,7 @@ __device__ __forceinline__ f2v ray_step(f2v kk2, f2v cns)
 struct RasterThread {
     const f2v* lrow;
     const float* lrowdepth;
+    unsigned pal_off;                   // LDS byte offset of the palette uint32[H][4] the rows are shaded from (the host's, or a frame's own on a track with elevation)
     f2v ufa, ufb, ufc, ufd;
     unsigned gwm1, ghm1, pitch;
     int cg, vstart, vground, col_off, row_bytes;
@@ -424,6 +443,7 @@ __device__ __forceinline__ RasterThread raster_thread(const RParams& p, const un
     RasterThread t;
     t.lrow = reinterpret_cast<const f2v*>(lds + p.off_rowtab);
     t.lrowdepth = reinterpret_cast<const float*>(lds + p.off_depth);
+    t.pal_off = (unsigned)p.off_pal;
     const float half_w = (float)(p.W / 2);
     t.gwm1 = (unsigned)(p.map_w - 1); t.ghm1 = (unsigned)(p.map_h - 1);
     t.cg = tid % p.gpr;
@@ -457,7 +477,7 @@ template <bool DEPTH>
 __device__ __forceinline__ void raster_uniform_rows(const RParams& p, const RasterThread& t, const FrameDesc& f)
 {
     for (int v = t.vstart; v < p.uni_rows; v += p.rows_per_pass) {
-        const uint32_t c = *(lds_u32p)(uintptr_t)((unsigned)p.off_pal + ((unsigned)v << 4));
+        const uint32_t c = *(lds_u32p)(uintptr_t)(t.pal_off + ((unsigned)v << 4));
         const u3v px3 = {__builtin_amdgcn_perm(c, c, 0x04020100u), __builtin_amdgcn_perm(c, c, 0x05040201u), __builtin_amdgcn_perm(c, c, 0x06050402u)};
         __builtin_amdgcn_raw_buffer_store_b96(px3, f.rgb, t.col_off + v * t.row_bytes, 0, TRS_STORE_AUX);
         if constexpr (DEPTH) {
@@ -477,7 +497,7 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
     for (int v = t.vground; v < p.H; v += p.rows_per_pass) {
         const int vn = v + p.rows_per_pass;
         const f2v rtn = t.lrow[vn < p.H ? vn : v];                          // prefetch the next row's table entry
-        const unsigned pal_a = (unsigned)p.off_pal + ((unsigned)v << 4);
+        const unsigned pal_a = t.pal_off + ((unsigned)v << 4);
         const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
         const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
         const f2v d = ray_step(kk2, cns);                                  // (dx, dz) = (k*c, -(k*s))
@@ -515,6 +535,97 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
 #endif
         rt = rtn;
     }
+}
+
+// ---- tracks with elevation (include/trsim_spec.h, "tracks with elevation") ------------------------------------------------------
+// On a hilly track a frame's row tables depend on the env and the step: the view pitch P = pitch + dpitch[nearest track point] (the slope ahead against
+// the slope here) comes from the physics wave with the camera parameters, and the raster team evaluates the H rows once per env and frame into a
+// table of its own in LDS — float2 rowtab[H] | uint32 palette[H][4] | float depth[H], the layout of the host's tables, so the row loops above only get
+// another base (raster_use_table).  Thread v < H of the raster team computes row v: binary32, the spec's operation order (no contraction: the kernels
+// are built with -ffp-contract=off; the division is IEEE).  Two tables alternate, so ONE team barrier per env frame orders the writers of a table behind
+// its last readers (a wave reaches the barrier of env j + 1 only after it has shaded env j - 1, whose table is the one being rewritten).
+constexpr int kHillRowBytes = 28;
+__host__ __device__ inline int hill_table_bytes(int H) { return (kHillRowBytes * H + 15) & ~15; }
+
+__device__ __forceinline__ void hill_rows_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int tid)
+{
+    if (tid >= p.H) return;
+    const trsim::HillBlock hb = *p.hill;                     // (uniform address: scalar loads)
+    const int v = tid;
+    float sp, cp;
+    spec_sincos(P, sp, cp);
+    const float yn = (hb.hh - ((float)v + 0.5f)) * hb.inv_f;
+    const float dy = yn * cp - sp, dz = yn * sp + cp;
+    float lz = 0.0f, kk = 0.0f, dep = hb.z_far_f;
+    uint32_t c0, c1, c2, c3;
+    if (dy >= -1e-6f) {
+        c0 = c1 = c2 = c3 = *(lds_u32p)(uintptr_t)((unsigned)hb.off_sky + ((unsigned)v << 2));
+    } else {
+        const float t = hb.cam_h_f / (-dy);
+        const float zd = t * dz;
+        if (zd > hb.z_far_f) {
+            c0 = c1 = c2 = c3 = hb.far_rgb;
+        } else {
+            lz = zd * hb.inv_cell_f; kk = (t * hb.inv_f) * hb.inv_cell_f; dep = zd;
+            const float fw = hb.fog_f * (zd * hb.inv_zfar_f), om = 1.0f - fw;
+            constexpr int base[4][3] = {TRS_RGB_GRASS, TRS_RGB_ROAD, TRS_RGB_EDGE, TRS_RGB_CENTRE};
+            constexpr int fog[3] = TRS_RGB_FOG;
+            uint32_t col[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t rgb = 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float a = (float)base[c][ch] * om, b = (float)fog[ch] * fw;
+                    const float sum = a + b;
+                    rgb |= (uint32_t)(int)(sum + 0.5f) << (8 * ch);
+                }
+                col[c] = rgb;
+            }
+            c0 = col[0]; c1 = col[1]; c2 = col[2]; c3 = col[3];
+        }
+    }
+    unsigned char* const tab = lds + tab_off;
+    reinterpret_cast<f2v*>(tab)[v] = f2v{lz, kk};
+    reinterpret_cast<u4v*>(tab + 8 * p.H)[v] = u4v{c0, c1, c2, c3};
+    reinterpret_cast<float*>(tab + 24 * p.H)[v] = dep;
+}
+
+// the row loops read their tables from the frame's own table at tab_off
+__device__ __forceinline__ RasterThread raster_use_table(const RasterThread& t, const unsigned char* lds, unsigned tab_off, int H)
+{
+    RasterThread r = t;
+    r.lrow = reinterpret_cast<const f2v*>(lds + tab_off);
+    r.pal_off = tab_off + 8u * (unsigned)H;
+    r.lrowdepth = reinterpret_cast<const float*>(lds + tab_off + 24u * (unsigned)H);
+    return r;
+}
+
+// (the raster team's barrier: a counter in LDS, bounded by the caller's `bail` — its comment is with raster_dyn_batch below)
+template <typename Bail>
+__device__ __forceinline__ bool team_barrier_wait(const int* dbar, int target, Bail& bail)
+{
+    for (unsigned spins = 0; __hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u && bail(spins == 1023u)) return false;
+    }
+    return true;
+}
+
+// One env frame on a track with elevation.  Only the HILLS instantiations of the step kernels contain it: as a run-time branch inside the flat kernels' per-env
+// loops (a second copy of the row loop beside the flat one) it cost the FLAT-track step 3-6 % on the single-step paths, and as an out-of-line call — which gives the
+// whole kernel a stack and the calling convention's register budget — a factor of 2.5 (same-box A/Bs in profiles/r05_hills.txt).  `arrive` = the team-barrier
+// target of this env frame; returns false when the barrier gave up (resident worker: abort / safety).
+template <bool DEPTH, typename Bail>
+__device__ __forceinline__ bool raster_hill_frame(const RParams& p, const RasterThread& t, unsigned char* lds, unsigned tab_off, float P, const FrameDesc& f,
+                                                              const float4 cam, int* hbar, int arrive, int tid, int lane, Bail& bail)
+{
+    hill_rows_build(p, lds, tab_off, P, tid);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!team_barrier_wait(hbar, arrive, bail)) return false;
+    raster_ground_rows<DEPTH>(p, raster_use_table(t, lds, tab_off, p.H), f, cam);
+    return true;
 }
 
 // The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).
@@ -624,15 +735,6 @@ __device__ __forceinline__ void dyn_stage_tables(unsigned char* lds_base, const 
 // The team barrier of raster_dyn_batch: a BOUNDED spin.  Every 1024 polls (~30 us) it asks `bail(first)` whether to give up — the resident worker
 // answers from its abort bit and its safety deadline (a wave of the team that left at an aborted wait_posted never arrives here: ADVICE r03); a
 // launched kernel has no abort and passes a callable that says no.  false = gave up: the caller leaves the kernel.
-template <typename Bail>
-__device__ __forceinline__ bool team_barrier_wait(const int* dbar, int target, Bail& bail)
-{
-    for (unsigned spins = 0; __hip_atomic_load(dbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spins) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 1023u) == 1023u && bail(spins == 1023u)) return false;
-    }
-    return true;
-}
 
 template <bool DEPTH, typename Bail>
 __device__ __forceinline__ bool raster_dyn_batch(const RParams& p, const FParams& f, const RasterThread& rth, unsigned char* lds_base, const float4 (&cams)[kDynBatch],

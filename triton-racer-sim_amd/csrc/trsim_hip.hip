@@ -84,6 +84,7 @@ struct SParams {
                                         // launch (camera parameters from the global ring, written by the previous launch)
     unsigned step_base;                 // absolute index of this launch's physics step 0
     int lds_off_phys, lds_off_cam, lds_off_prog, cam_stride;   // LDS: physics image, float4 lcam[n_phys][cam_stride], int pprog[cam_stride]
+    int lds_off_pitch, lds_off_hill;    // tracks with elevation: float lpitch[n_phys + 1][cam_stride] beside lcam; two row tables (hill_table_bytes each) + the team-barrier counter
     int skip_uniform;                   // 1: the target frame buffer already holds this palette's uniform rows (sky, beyond the far plane: they depend on neither the
                                         // pose nor the step) of every env — an earlier step wrote them and nothing has touched them since: only the rows that see the
                                         // track are written.  Set by the closed pilot loop only (trs_internal_step_launch); every other step path writes whole frames.
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
 }
 
 
-template <bool DEPTH, bool DYN>
+template <bool DEPTH, bool DYN, bool HILLS = false>      // HILLS: a track with elevation (its own instantiations: the flat kernels' loops do not change for it)
 __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 {
     const int tid = threadIdx.x;
@@ -136,6 +137,9 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
+    float* const lpitch = reinterpret_cast<float*>(smem + sp.lds_off_pitch);   // [n_phys + 1][cam_stride] view pitch per (step, env): tracks with elevation only
+    int* const hbar = reinterpret_cast<int*>(smem + sp.lds_off_hill + 2 * hill_table_bytes(p.H));   // the raster team's barrier counter of the per-env row tables
+    if (HILLS && tid == 0) *hbar = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0;   // esum[2][4][3], dbar
         dyn_stage_tables(smem, sp.fp, p.H, tid, kBlock, reinterpret_cast<const uint32_t*>(p.blob + p.off_pal));                   // OpenCV's reciprocals + the in-range byte masks (behind the prologue's barrier)
@@ -159,6 +163,10 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         if (has_c) lcam_prev[tid] = cv;
         if (raster_team && rendering && sp.r_first < 0)
             for (int j = tid + kRasterThreads; j < e_end - e_begin; j += kRasterThreads) lcam_prev[j] = cam_prev[e_begin + j];
+        if (HILLS && raster_team && rendering && sp.r_first < 0) {             // ... and its view pitch (a track with elevation)
+            const float* const pitch_prev = p.hill->cam_pitch + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
+            for (int j = tid; j < e_end - e_begin; j += kRasterThreads) lpitch[max(sp.n_phys, 1) * sp.cam_stride + j] = pitch_prev[e_begin + j];
+        }
     }
     STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this wave's DMA pieces have landed
@@ -179,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 env_load(sp.ph, e, st);
                 for (int k = 0; k < sp.n_phys; ++k) {
                     const uint32_t t = sp.step_base + (uint32_t)k;
-                    env_step(sp.ph, lphys, e, st, t, k, ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs, &lcam[k * sp.cam_stride + j], &pprog[j], lane);
+                    env_step(sp.ph, lphys, e, st, t, k, ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs, &lcam[k * sp.cam_stride + j], &pprog[j], lane,
+                             HILLS ? sp.ph.hill->cam_pitch + (size_t)(t & (kRing - 1)) * sp.ph.n_envs : nullptr, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
                 }
                 env_store(sp.ph, e, st, lane);
             }
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                     const int j = e - e_begin;
                     EnvRegs st;
                     env_load(sp.ph, e, st);
-                    env_step(sp.ph, lphys, e, st, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], lane);
+                    env_step(sp.ph, lphys, e, st, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], lane,
+                             HILLS ? sp.ph.hill->cam_pitch + (size_t)(t & (kRing - 1)) * sp.ph.n_envs : nullptr, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
                     env_store(sp.ph, e, st, lane);
                 }
                 if (sp.n_phys > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores have reached L2 before the next step reloads them
@@ -264,6 +274,15 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         } else {                                                              // wait until the physics team has finished this step of env j
             while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
             cam = lcam[sidx * sp.cam_stride + j];
+        }
+        if constexpr (HILLS) {
+            // a track with elevation: this frame's row tables from its own view pitch (trsim_device.hpp, hill_rows_build), then the same row loop on them
+            const float P = lpitch[(sidx < 0 ? max(sp.n_phys, 1) : sidx) * sp.cam_stride + j];
+            const int hit = (sidx - sp.r_first) * (e_end - e_begin) + j;      // env frames so far (the same in every wave)
+            const unsigned tab = (unsigned)sp.lds_off_hill + (unsigned)((hit & 1) * hill_table_bytes(p.H));
+            auto never = [](bool) { return false; };                          // (a launch has no abort: every raster wave arrives)
+            (void)raster_hill_frame<DEPTH>(p, rth, smem, tab, P, fd, cam, hbar, (kRasterThreads / 64) * (hit + 1), tid, lane, never);
+            continue;
         }
         raster_ground_rows<DEPTH>(p, rth, fd, cam);
     }
@@ -987,6 +1006,11 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
     sp.lds_off_prog = sp.lds_off_cam + (std::max(n_phys, 1) + 1) * sp.cam_stride * 16;   // + one row: poses of the step before the launch
     int lds = sp.lds_off_prog + sp.cam_stride * 4 + 16;                            // + spare counters
+    sp.lds_off_pitch = sp.lds_off_hill = lds;
+    if (e->rp.hill) {                                                               // a track with elevation: view pitches beside the camera ring, two per-env row tables, a counter
+        sp.lds_off_pitch = lds; lds += (std::max(n_phys, 1) + 1) * sp.cam_stride * 4;
+        sp.lds_off_hill = (lds + 15) & ~15; lds = sp.lds_off_hill + 2 * hill_table_bytes(e->H) + 16;
+    }
     const bool dyn = e->has_frame_filter && e->filter_dynamic;
     // Which frame buffers hold the CURRENT palette's uniform rows for every env (e->uniform_ok[b]): a launch that renders whole frames into a buffer makes it
     // so; a palette change (upload_palette: track, frame filter) or the dynamic-brightness filter (its uniform rows follow each frame's own mean) undoes it.
@@ -1012,7 +1036,10 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
         lds = sp.fp.lds_off + dyn_lds_bytes(e->H);                         // palettes of a batch of 4 envs + channel sums + barrier counter + the mask tables
     }
     const dim3 grid(grid_of(e)), block(kBlock);
-    if (dyn) {
+    if (e->rp.hill) {                                       // a track with elevation (no frame filters there: trs_set_frame_filter)
+        if (e->rp.depth) hipLaunchKernelGGL((trs_step_kernel<true, false, true>), grid, block, lds, e->sP, sp);
+        else hipLaunchKernelGGL((trs_step_kernel<false, false, true>), grid, block, lds, e->sP, sp);
+    } else if (dyn) {
         if (e->rp.depth) hipLaunchKernelGGL((trs_step_kernel<true, true>), grid, block, lds, e->sP, sp);
         else hipLaunchKernelGGL((trs_step_kernel<false, true>), grid, block, lds, e->sP, sp);
     } else {
@@ -1127,7 +1154,10 @@ int create_impl(const trs_config* cfg, int device, trs_env* e)
     HIPCHK(hipMemsetAsync(e->stats, 0, 64 * sizeof(unsigned long long), e->sP));
     HIPCHK(hipMalloc((void**)&e->cam, (size_t)kRing * n * sizeof(float4)));
     HIPCHK(hipMemsetAsync(e->cam, 0, (size_t)kRing * n * sizeof(float4), e->sP));
-    k.stats = e->stats; k.cam = e->cam;
+    HIPCHK(hipMalloc((void**)&e->cam_pitch, (size_t)kRing * n * sizeof(float)));   // the frames' view pitches beside the camera ring (tracks with elevation)
+    HIPCHK(hipMemsetAsync(e->cam_pitch, 0, (size_t)kRing * n * sizeof(float), e->sP));
+    HIPCHK(hipMalloc((void**)&e->hill_block, sizeof(trsim::HillBlock)));
+    k.stats = e->stats; k.cam = e->cam; k.hill = nullptr;
     RParams& r = e->rp;
     r.stats = e->stats;
     if (cfg->render) {
@@ -1195,7 +1225,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
-    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam);
+    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->cam_pitch); (void)hipFree(e->dpitch); (void)hipFree(e->hill_block);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf); (void)hipFree(e->glue);
     for (void* sc : e->scratch) (void)hipFree(sc);
@@ -1226,8 +1256,8 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     PParams k = e->pp;
     RParams r = e->rp;
     struct Staged {                                          // device buffers of the new track; freed unless committed
-        unsigned char *blob_p = nullptr, *blob_r = nullptr; float *tangent = nullptr, *start_yaw = nullptr;
-        ~Staged() { (void)hipFree(blob_p); (void)hipFree(blob_r); (void)hipFree(tangent); (void)hipFree(start_yaw); }
+        unsigned char *blob_p = nullptr, *blob_r = nullptr; float *tangent = nullptr, *start_yaw = nullptr, *dpitch = nullptr;
+        ~Staged() { (void)hipFree(blob_p); (void)hipFree(blob_r); (void)hipFree(tangent); (void)hipFree(start_yaw); (void)hipFree(dpitch); }
     } nb;
     int n_lds_r = 0, n_lds_p = 0, n_lds_step = 0, n_lds_off_phys = 0, n_pts_bytes = 0, n_max_spl = 1, n_max_dyn = 0;
 
@@ -1248,6 +1278,9 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     r.off_rowtab = (int)roff; roff += align_up((size_t)e->H * 8, 16);
     r.off_pal = (int)roff; roff += (size_t)e->H * 16;
     r.off_depth = (int)roff; roff += align_up((size_t)e->H * 4, 16);
+    const int off_sky = (int)roff;
+    if (T.hills) roff += align_up((size_t)e->H * 4, 16);     // a track with elevation: the sky colour of every row rides in the raster image (hill_rows_build)
+    r.hill = T.hills ? e->hill_block : nullptr;
     r.blob_bytes = (int)roff;
     n_lds_r = (int)align_up(roff, 16);
     if ((size_t)r.blob_bytes > (size_t)100 * 1024)
@@ -1255,7 +1288,10 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     // tangents ride in LDS when the fused kernel's image (raster tables + points + tangents) still fits a CU's 160 KiB
     n_lds_off_phys = n_lds_r;
     const size_t grid_bytes = align_up(T.grid_start.size() * 2, 16) + align_up(T.grid_pts.size() * 2, 16);
-    k.tan_in_lds = ((size_t)n_lds_off_phys + off + grid_bytes + tan_bytes <= 160 * 1024) ? 1 : 0;
+    // (... and leaves room for what the kernels keep behind the tables: the camera hand-off ring of a few steps, and on a track with elevation the two per-env
+    // row tables + the view pitches — the mountain track's points + tangents fill the CU to within 150 bytes on their own)
+    const size_t behind = (size_t)k.envs_per_wg * 4 + 16 + (size_t)k.envs_per_wg * 20 * 3 + (T.hills ? (size_t)2 * hill_table_bytes(e->H) + 64 : 0);
+    k.tan_in_lds = ((size_t)n_lds_off_phys + off + grid_bytes + tan_bytes + behind <= 160 * 1024) ? 1 : 0;
     if (k.tan_in_lds) off += tan_bytes;
     // nearest-point accelerator tables ride behind the points (uint16 cell starts + point lists)
     k.grid_nx = T.grid_nx; k.grid_nz = T.grid_nz; k.grid_x0 = T.grid_x0; k.grid_z0 = T.grid_z0;
@@ -1281,6 +1317,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     std::memcpy(hr.data() + r.off_rowtab, T.rowtab.data(), (size_t)e->H * 8);
     std::memcpy(hr.data() + r.off_pal, T.palette.data(), (size_t)e->H * 16);
     std::memcpy(hr.data() + r.off_depth, T.rowdepth.data(), (size_t)e->H * 4);
+    if (T.hills) std::memcpy(hr.data() + off_sky, T.sky.data(), (size_t)e->H * 4);
 
     HIPCHK(hipMalloc((void**)&nb.blob_p, off));
     HIPCHK(hipMalloc((void**)&nb.blob_r, roff));
@@ -1290,30 +1327,49 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     HIPCHK(hipMemcpy(nb.blob_r, hr.data(), roff, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(nb.tangent, T.tangent.data(), (size_t)n_points * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(nb.start_yaw, T.start_yaw.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&nb.dpitch, (size_t)n_points * 4));
+    {   // the view pitch of a frame whose nearest raw track point is idx: pitch_f + dpitch[idx], ONE binary32 addition as the spec has it
+        std::vector<float> vp((size_t)n_points);
+        for (int i = 0; i < n_points; ++i) vp[i] = T.pitch_f + T.dpitch[i];
+        HIPCHK(hipMemcpy(nb.dpitch, vp.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
+    }
     k.blob = nb.blob_p; k.start_yaw = nb.start_yaw; k.tangent_g = nb.tangent;
+    k.hill = T.hills ? e->hill_block : nullptr;
     r.blob = nb.blob_r;
     k.np = n_points; r.map_w = T.info.map_w; r.map_h = T.info.map_h;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, n_lds_p));
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
-        const int free_b = 160 * 1024 - n_lds_step - epw * 4 - 16 - epw * 16;
-        n_max_spl = std::max(1, std::min(16, free_b / (epw * 16)));
+        // (a track with elevation: + two per-env row tables and their counter, + 4 bytes of view pitch per env and step beside the 16 of the camera parameters)
+        const int hill_b = T.hills ? 2 * hill_table_bytes(e->H) + 32 + epw * 4 : 0, per_step = epw * (T.hills ? 20 : 16);
+        const int free_b = 160 * 1024 - n_lds_step - epw * 4 - 16 - epw * 16 - hill_b;
+        n_max_spl = std::max(1, std::min(16, free_b / per_step));
         const int free_dyn = free_b - (dyn_lds_bytes(e->H) + 32);
         n_max_dyn = free_dyn >= epw * 16 ? std::min(16, free_dyn / (epw * 16)) : 0;
-        if (e->cfg.render && free_b < epw * 16) return fail(TRS_ERR_LIMIT, "no LDS left for the camera hand-off ring");
+        if (e->cfg.render && free_b < per_step) return fail(TRS_ERR_LIMIT, T.hills ? "no LDS left for the camera hand-off ring and the per-env row tables of a track with elevation"
+                                                                                                 : "no LDS left for the camera hand-off ring");
+        if (T.hills) n_max_dyn = 0;                              // (the dynamic-brightness filter is not available on a track with elevation)
     }
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifndef TRS_SINGLE_VARIANT
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_step_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_locate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, k.blob_bytes));
     // ---- commit: nothing above has touched the handle ----
     e->track_loaded = false;                                 // (until the state arrays below are in place)
-    (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw);
-    e->blob_p = nb.blob_p; e->blob_r = nb.blob_r; e->tangent = nb.tangent; e->start_yaw = nb.start_yaw;
+    (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->dpitch);
+    e->blob_p = nb.blob_p; e->blob_r = nb.blob_r; e->tangent = nb.tangent; e->start_yaw = nb.start_yaw; e->dpitch = nb.dpitch;
+    {
+        trsim::HillBlock hb{};
+        hb.vpitch = nb.dpitch; hb.cam_pitch = e->cam_pitch; hb.off_sky = off_sky; hb.far_rgb = T.far_rgb;
+        hb.inv_f = T.inv_f; hb.hh = T.hh; hb.cam_h_f = T.cam_h_f; hb.z_far_f = T.z_far_f; hb.inv_zfar_f = T.inv_zfar_f; hb.fog_f = T.fog_f; hb.inv_cell_f = T.inv_cellf;
+        HIPCHK(hipMemcpy(e->hill_block, &hb, sizeof hb, hipMemcpyHostToDevice));
+    }
     nb = Staged{};
     e->tab = std::move(T);
     e->pp = k; e->rp = r;
@@ -1342,6 +1398,11 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     e->step_count = 0;
     e->track_loaded = true;
     trsim::resident_clear_fault(e);
+    if (e->has_frame_filter && e->rp.hill) {               // (frame filters behind the rasteriser: not on a track with elevation yet, see trs_set_frame_filter)
+        e->has_frame_filter = false; e->filter_dynamic = false;
+        (void)upload_palette(e);
+        return fail(TRS_ERR_STATE, "this track has elevation: the frame filter that was set has been removed (on such a track a frame's palette is evaluated per env inside the kernels; use trs_preprocess on the rendered frames)");
+    }
     if (e->has_frame_filter && e->filter_dynamic && e->max_steps_dyn < 1) {
         e->has_frame_filter = false; e->filter_dynamic = false;
         (void)upload_palette(e);
@@ -1517,6 +1578,7 @@ TRS_EXPORT int trs_copy_to_host(trs_env* e, int which, void* dst, size_t bytes)
     case TRS_F_ROWTAB: if (e->track_loaded) { src = e->blob_r + e->rp.off_rowtab; need = (size_t)e->H * 8; } break;
     case TRS_F_PALETTE: if (e->track_loaded) { src = e->blob_r + e->rp.off_pal; need = (size_t)e->H * 16; } break;
     case TRS_F_TANGENT: if (e->track_loaded) { src = e->tangent; need = (size_t)k.np * 8; } break;
+    case TRS_F_DPITCH: if (e->track_loaded) { src = e->tab.dpitch.data(); need = e->tab.dpitch.size() * 4; host_src = true; } break;
     default: return fail(TRS_ERR_ARG, "unknown field");
     }
     if (!src) return fail(TRS_ERR_STATE, "field not available");
@@ -1732,7 +1794,7 @@ int upload_palette(trs_env* e)
     std::vector<uint32_t> pal(e->tab.palette);
     if (e->has_frame_filter && !e->filter_dynamic)             // dynamic brightness: the kernel filters a per-env palette itself
         for (auto& c : pal) c = filter_colour(e->frame_filter, c);
-    e->rp.uni_rows = leading_uniform_rows(pal, e->H);
+    e->rp.uni_rows = e->rp.hill ? 0 : leading_uniform_rows(pal, e->H);   // (a track with elevation: which rows are sky depends on the env and the frame)
     e->uniform_ok[0] = e->uniform_ok[1] = false;               // (the closed pilot loop's steps skip rows an earlier step wrote: not across a palette change)
     { int rq = sync_all(e); if (rq) return rq; }               // frames in flight keep the palette they were launched with
     HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
@@ -1791,6 +1853,9 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
         int rc = check_pre(c);
         if (rc) return rc;
         if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
+        if (e->track_loaded && e->rp.hill)
+            return fail(TRS_ERR_STATE, "the loaded track has elevation: a frame's palette is evaluated per env inside the kernels there, and the frame filter behind the rasteriser "
+                                       "is not built for that yet; use trs_preprocess on the rendered frames");
         if (c->dynamic_brightness) {
             const int rpp = kRasterThreads / (e->W / 4);
             if (rpp < 1 || (79 + rpp - 1) / rpp > 16) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 4 registers), use trs_preprocess");

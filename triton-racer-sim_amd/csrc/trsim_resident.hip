@@ -95,6 +95,7 @@ struct WParams {
     unsigned long long idle_ticks, life_ticks, safety_ticks;   // wall_clock64() ticks (100 MHz)
     unsigned long long checkin_ticks;                       // how long the dispatcher waits for every workgroup of the launch to report in
     int lds_off_phys, lds_off_ctl, n_blocks;
+    int lds_off_hill;                                       // a track with elevation: two per-env row tables (hill_table_bytes each) + the raster team's barrier counter
     FParams fp;                                             // DYN instantiation: ImgPreprocessing with dynamic brightness behind the rasteriser (trs_set_frame_filter)
 };
 #ifndef TRS_RESIDENT_DIAG
@@ -129,7 +130,7 @@ struct Resident {
                                          // rate (20 Hz, car_templates/manage.py:38) or better, and a worker restart (~35 us) per 50 ms costs 0.1 %
     unsigned char* hctl = nullptr;       // pinned staging for host-array controls: [kSlots] x (3 float[n] + uint8[n])
     size_t hctl_slot = 0;
-    int lds_bytes = 0, lds_off_ctl = 0, lds_off_dyn = 0;
+    int lds_bytes = 0, lds_off_ctl = 0, lds_off_dyn = 0, lds_off_hill = 0;
     long long pw_capacity_envs = 0;      // physics-only handles: envs whose workgroups the GPU holds at once (worker_fits)
     int pw_capacity_lds = -1;            //   ... asked for this LDS need
 };
@@ -197,7 +198,7 @@ __device__ __forceinline__ T sys_load_val(const T* p)
 }
 
 // what a workgroup shares in LDS (behind the tables)
-constexpr int kSlotWords = 20;  // one hand-off slot: camera parameters (4) | x y z yaw v speed cte seg epr epl sf last_return (12) | done | 3 spare
+constexpr int kSlotWords = 20;  // one hand-off slot: camera parameters (4) | x y z yaw v speed cte seg epr epl sf last_return (12) | done | view pitch (a track with elevation) | 2 spare
 struct WLds {
     u64* word;          // posted count | flags as last seen by this workgroup's leader
     u64* fwd;           // steps this workgroup has completely passed on (the forwarder's count; the dispatcher's idle clock reads it)
@@ -487,7 +488,7 @@ __device__ __forceinline__ int wait_lds_ge(const WParams& wp, const WLds& l, Dut
     }
 }
 
-template <bool DEPTH, bool DYN>
+template <bool DEPTH, bool DYN, bool HILLS = false>      // HILLS: a track with elevation (its own instantiations, see raster_hill_frame)
 __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -515,6 +516,8 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
     if (tid < kSlots) l.arrive[tid] = 0;
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
+    int* const hbar = reinterpret_cast<int*>(smem + wp.lds_off_hill + 2 * hill_table_bytes(p.H));   // (a track with elevation: the row tables' team-barrier counter)
+    if (HILLS && tid == 0) *hbar = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0;   // channel sums, team-barrier counter
         dyn_stage_tables(smem, wp.fp, p.H, tid, kBlock, reinterpret_cast<const uint32_t*>(p.blob + p.off_pal));                   // the filter's tables, once per launch: the raster waves' steady state issues no loads
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                     sl[4] = st.x; sl[5] = st.y; sl[6] = st.z; sl[7] = st.yaw; sl[8] = st.v; sl[9] = st.speed; sl[10] = st.cte;
                     sl[11] = __int_as_float(st.seg); sl[12] = st.epr; sl[13] = __int_as_float(st.epl); sl[14] = st.sf; sl[15] = lr;
                     sl[16] = __int_as_float(st.done);
+                    if constexpr (HILLS) sl[17] = o.pitch;
                     if (o.is_done) atomicAdd(&P.stats[0], 1ull);
                     if (o.do_reset) atomicAdd(&P.stats[1], 1ull);
                     drain_lds();                              // the slot is in LDS before the counter moves
@@ -736,11 +740,28 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             if (probe) t_pose += now_clk() - tq0;
             const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
             const float4 cam = *reinterpret_cast<const float4*>(sl);
+            float vpitch = 0.0f;
+            if constexpr (HILLS) vpitch = sl[17];
             const bool mine = (j % (kRasterThreads / 64)) == wave;
             unsigned tel = 0;
             if (mine) tel = __float_as_uint(sl[4 + min(lane, 12)]);      // lanes 0..11 their word, lane 12 `done`
-            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel), "v"(vpitch) : "memory");
             if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (HILLS) {
+                // a track with elevation: this frame's row tables from its own view pitch (hill_rows_build), two tables alternating, one team barrier per env frame —
+                // bounded like every other wait of the worker (abort bit, safety deadline)
+                const int hit = r * n_loc + j;                          // env frames of this launch so far (the same in every wave)
+                const unsigned tab = (unsigned)wp.lds_off_hill + (unsigned)((hit & 1) * hill_table_bytes(p.H));
+                u64 t0_bar = 0;
+                auto bail = [&](bool first) -> bool {
+                    if (lds_load64(l.word) & kAbortBit) return true;
+                    const u64 now = (u64)wall_clock64();
+                    if (first) { t0_bar = now; return false; }
+                    if (now - t0_bar > wp.safety_ticks) { worker_abort(wp, l, 5u); return true; }
+                    return false;
+                };
+                if (!raster_hill_frame<DEPTH>(p, rth, smem, tab, vpitch, fd, cam, hbar, (kRasterThreads / 64) * (hit + 1), tid, lane, bail)) return;
+            } else
             raster_ground_rows<DEPTH>(p, rth, fd, cam);
             if (mine && !(kDiag & 2)) {                     // the step's telemetry of env j: two wave instructions, written through
                 const size_t e = (size_t)(e_begin + j);
@@ -963,7 +984,11 @@ int worker_fits(trs_env* e)
     R->lds_off_ctl = (e->lds_step + 15) & ~15;              // behind the tables
     R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
     if (e->has_frame_filter && e->filter_dynamic) { R->lds_off_dyn = (R->lds_bytes + 15) & ~15; R->lds_bytes = R->lds_off_dyn + dyn_lds_bytes(e->H); }
-    if (R->lds_bytes > 160 * 1024) return trs_internal_fail(TRS_ERR_LIMIT, "too many envs per workgroup for the resident worker's LDS state");
+    R->lds_off_hill = (R->lds_bytes + 15) & ~15;
+    if (e->rp.hill) R->lds_bytes = R->lds_off_hill + 2 * hill_table_bytes(e->H) + 16;   // a track with elevation: the per-env row tables (trsim_device.hpp, hill_rows_build)
+    if (R->lds_bytes > 160 * 1024)
+        return trs_internal_fail(TRS_ERR_LIMIT, e->rp.hill ? "the resident worker's LDS state and the per-env row tables of a track with elevation do not fit beside this track's tables: use TRS_STEP_LAUNCH"
+                                                            : "too many envs per workgroup for the resident worker's LDS state");
     return TRS_OK;
 }
 
@@ -993,7 +1018,7 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.life_ticks = (unsigned long long)R->life_us * 100ull;   // 50 ms by default: then the dispatcher leaves and the host starts a new worker at its next post
     wp.safety_ticks = 200000000ull;                         // 2 s
     wp.checkin_ticks = 200000ull;                           // 2 ms: every workgroup of a launch that has the GPU to itself reports in within tens of microseconds
-    wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl;
+    wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl; wp.lds_off_hill = R->lds_off_hill;
     const int grid = e->cfg.render ? (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg : (e->n + kPwEnvs - 1) / kPwEnvs;
     wp.n_blocks = grid;
     hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)start);
@@ -1017,6 +1042,14 @@ int worker_launch(trs_env* e, uint64_t start)
         wp.fp.w0 = std::min(40, e->H); wp.fp.w1 = std::min(119, e->H);     // img[40:119] (img_preprocessing.py:88)
         wp.fp.tabs = e->dyn_tab;
         wp.fp.lds_off = R->lds_off_dyn;
+    }
+    if (e->rp.hill) {                                       // a track with elevation (no frame filters there)
+        if (e->rp.depth) hipLaunchKernelGGL((trs_worker_kernel<true, false, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
+        else hipLaunchKernelGGL((trs_worker_kernel<false, false, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
+        RCHK(hipGetLastError());
+        R->running = true;
+        R->t_launch = std::chrono::steady_clock::now();
+        return TRS_OK;
     }
     if (e->rp.depth) { if (dyn) hipLaunchKernelGGL((trs_worker_kernel<true, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
                        else hipLaunchKernelGGL((trs_worker_kernel<true, false>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp); }
@@ -1414,6 +1447,8 @@ TRS_EXPORT int trs_set_step_mode(trs_env* e, int mode, int idle_us)
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_worker_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(trs_physics_worker_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (idle_us > 0) R->idle_us = (unsigned)std::min(idle_us, 1000000);
     if (!R->enabled) { R->base = R->seen_done = e->step_count; host_store(&R->mb->posted, e->step_count); }

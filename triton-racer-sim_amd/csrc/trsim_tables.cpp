@@ -211,6 +211,41 @@ int build_tables(const trs_config& cfg, const double* xyz, int n_points, TrackTa
         for (int c = 0; c < 4; ++c)
             T.palette[4 * v + c] = (uint32_t)rgb[c][0] | ((uint32_t)rgb[c][1] << 8) | ((uint32_t)rgb[c][2] << 16);
     }
+
+    // ---- tracks with elevation (include/trsim_spec.h): is the track hilly, and by how much does the road A samples ahead tilt against the road here ----
+    {
+        const int n = n_points;
+        const auto mm = std::minmax_element(T.py.begin(), T.py.end());
+        T.hills = (*mm.second - *mm.first) > TRS_HILL_MIN_RANGE;
+        T.dpitch.assign((size_t)n, 0.0f);
+        if (T.hills) {
+            std::vector<double> step((size_t)n), slope((size_t)n);
+            auto wrap = [n](int i) { return ((i % n) + n) % n; };
+            for (int i = 0; i < n; ++i) {
+                const int j = wrap(i + 1);
+                step[i] = std::sqrt((T.px[j] - T.px[i]) * (T.px[j] - T.px[i]) + (T.pz[j] - T.pz[i]) * (T.pz[j] - T.pz[i]));
+            }
+            for (int i = 0; i < n; ++i) {
+                double run = 0.0;                                          // the path from sample i - L to sample i + L, summed in index order
+                for (int q = -TRS_HILL_SPAN; q < TRS_HILL_SPAN; ++q) run += step[wrap(i + q)];
+                const double rise = T.py[wrap(i + TRS_HILL_SPAN)] - T.py[wrap(i - TRS_HILL_SPAN)];
+                slope[i] = std::atan(run > 1e-9 ? rise / run : 0.0);
+            }
+            for (int i = 0; i < n; ++i)
+                T.dpitch[i] = (float)std::min(std::max(slope[wrap(i + TRS_HILL_AHEAD)] - slope[i], -(double)TRS_HILL_MAX_DPITCH), (double)TRS_HILL_MAX_DPITCH);
+        }
+        T.sky.assign((size_t)H, 0u);
+        for (int v = 0; v < H; ++v) {
+            const double g = std::min(((double)v + 0.5) / half_h, 1.0);
+            uint32_t rgbv = 0;
+            for (int ch = 0; ch < 3; ++ch) rgbv |= (uint32_t)round_colour((double)sky_top[ch] + ((double)sky_hor[ch] - (double)sky_top[ch]) * g) << (8 * ch);
+            T.sky[v] = rgbv;
+        }
+        T.far_rgb = 0;
+        for (int ch = 0; ch < 3; ++ch) T.far_rgb |= (uint32_t)round_colour((double)base[0][ch] * (1.0 - TRS_FOG_MAX) + (double)fog[ch] * TRS_FOG_MAX) << (8 * ch);
+        T.inv_f = (float)(1.0 / f); T.hh = (float)half_h; T.pitch_f = (float)pitch;
+        T.cam_h_f = (float)cfg.cam_h; T.z_far_f = (float)cfg.z_far; T.inv_zfar_f = (float)(1.0 / cfg.z_far); T.fog_f = (float)TRS_FOG_MAX;
+    }
     return TRS_OK;
 }
 

@@ -26,6 +26,12 @@ struct TrackTables {
     std::vector<float> rowdepth;           // [H] z-depth of the ground plane per image row (z_far for sky / far rows)
     std::vector<uint32_t> palette;         // [H][4] 0x00BBGGRR
     float map_x0f = 0, map_z0f = 0, inv_cellf = 0;
+    // tracks with elevation (include/trsim_spec.h): the per-point view-pitch offsets and what the kernels need to evaluate a frame's row tables per env
+    bool hills = false;
+    std::vector<float> dpitch;             // [n]; all zeros on a flat track
+    std::vector<uint32_t> sky;             // [H] sky colour of every image row
+    uint32_t far_rgb = 0;                  // colour of the rows beyond the far plane
+    float inv_f = 0, hh = 0, pitch_f = 0, cam_h_f = 0, z_far_f = 0, inv_zfar_f = 0, fog_f = 0;
     // nearest-point accelerator (trsim_spec.h R3): points bucketed by (x, z) cell, ascending index inside a cell
     int grid_nx = 0, grid_nz = 0;
     double grid_x0 = 0, grid_z0 = 0;
