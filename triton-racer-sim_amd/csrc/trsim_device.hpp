@@ -489,7 +489,9 @@ __device__ __forceinline__ void raster_uniform_rows(const RParams& p, const Rast
 }
 
 // rows that see the track, from the camera parameters (camx, camz, sin, cos) of the env's pose
-template <bool DEPTH>
+// UNI_CHECK (tracks with elevation: which rows are sky or beyond the far plane depends on the frame): a row whose table entry has row_k == 0 — exactly the SKY and
+// FAR rows — takes its one colour without the four map lookups.
+template <bool DEPTH, bool UNI_CHECK = false>
 __device__ __forceinline__ void raster_ground_rows(const RParams& p, const RasterThread& t, const FrameDesc& f, const float4 cam)
 {
     const f2v sc = {cam.z, cam.w}, cns = {cam.w, -cam.z}, camxz = {cam.x, cam.y};
@@ -516,7 +518,9 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
 #if TRS_ABLATE == 2   /* diagnostic build: stores only */
         const uint32_t c0p = (uint32_t)v, c1p = c0p + 1, c2p = c0p + 2, c3p = c0p + 3; (void)shade;
 #else
-        const uint32_t c0p = shade(t.ufa), c1p = shade(t.ufb), c2p = shade(t.ufc), c3p = shade(t.ufd);
+        uint32_t c0p, c1p, c2p, c3p;
+        if (UNI_CHECK && rt.y == 0.0f) c0p = c1p = c2p = c3p = *(lds_u32p)(uintptr_t)pal_a;
+        else { c0p = shade(t.ufa); c1p = shade(t.ufb); c2p = shade(t.ufc); c3p = shade(t.ufd); }
 #endif
         // 4 x 0x00BBGGRR -> 12 bytes R,G,B,R,G,B,...  (v_perm_b32: selector bytes 0-3 = 2nd operand, 4-7 = 1st)
         const uint32_t w0 = __builtin_amdgcn_perm(c1p, c0p, 0x04020100u);
@@ -624,7 +628,7 @@ __device__ __forceinline__ bool raster_hill_frame(const RParams& p, const Raster
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!team_barrier_wait(hbar, arrive, bail)) return false;
-    raster_ground_rows<DEPTH>(p, raster_use_table(t, lds, tab_off, p.H), f, cam);
+    raster_ground_rows<DEPTH, true>(p, raster_use_table(t, lds, tab_off, p.H), f, cam);
     return true;
 }
 
