@@ -193,13 +193,16 @@ int trs_quiesce(trs_env* env);
 /* trs_step followed by trs_sync in ONE call: the lock-step consumer of core/car.py:45-53 (post the controls, wait for the frame) crosses
  * the FFI once per tick instead of twice.  Same arguments and errors as trs_step. */
 int trs_step_wait(trs_env* env, const float* d_steering, const float* d_throttle, const float* d_brake_or_null, const uint8_t* d_reset_or_null, int n_steps);
-/* ---- test hooks of the resident worker: UNSTABLE, not part of the drop-in surface (no reference interface stands behind them; they exist so
- * that tests/test_resident.py can force the worker's rare paths).  trs_resident_debug_lifetime: a worker leaves by itself after life_us
- * microseconds (default 50,000; <= 0 restores it) and the next post starts a new one — many worker generations under load.  Needs
- * trs_set_step_mode first.  trs_resident_debug_abort: sets the running worker's abort bit from outside, as a wave does whose bounded wait gave up:
- * every wave must leave within its next poll and the next call must fail with TRS_ERR_DEVICE ("resident worker gave up") instead of hanging. */
+/* ---- test hooks of the resident worker: NOT part of libtrsim.so.  They exist only in builds with -DTRS_TEST_HOOKS (csrc/libtrsim_testhooks.so, which
+ * __graft_entry__.build() compiles for tests/test_resident.py beside the product library: the same sources + these two entry points).  No reference interface
+ * stands behind them.  trs_resident_debug_lifetime: a worker leaves by itself after life_us microseconds (default 50,000; <= 0 restores it) and the next post
+ * starts a new one — many worker generations under load.  Needs trs_set_step_mode first.  trs_resident_debug_abort: sets the running worker's abort bit from
+ * outside, as a wave does whose bounded wait gave up: every wave must leave within its next poll and the next call must fail with TRS_ERR_DEVICE ("resident
+ * worker gave up") instead of hanging. */
+#ifdef TRS_TEST_HOOKS
 int trs_resident_debug_lifetime(trs_env* env, int life_us);
 int trs_resident_debug_abort(trs_env* env);
+#endif
 
 /* Telemetry of the last step (components/gyminterface.py:76,95-104) as device pointers. */
 int trs_get_state(trs_env* env, trs_state_view* out);

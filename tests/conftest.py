@@ -54,16 +54,30 @@ def hip_api():
     return _ffi.load_hip_library()
 
 
+@pytest.fixture(scope="session")
+def hip_hooks_api():
+    """Function table of the TEST build of the HIP library (csrc/libtrsim_testhooks.so: the product's sources + the two trs_resident_debug_* entry points)."""
+    import ctypes
+    from triton_racer_sim_amd import _ffi
+    import __graft_entry__
+    path = __graft_entry__.build_hip_testhooks()
+    _ffi._share_torch_hip_runtime()
+    return _ffi.Api(ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL), "trs_")
+
+
 @pytest.fixture()
-def make_env(oracle_api):
-    """Factory for env pairs: make_env('hip', ...) / make_env('oracle', ...)."""
+def make_env(oracle_api, request):
+    """Factory for env pairs: make_env('hip', ...) / make_env('oracle', ...); make_env('hip_hooks', ...) binds the test build of the HIP library."""
     from triton_racer_sim_amd.env import BatchedEnv
     made = []
 
     def _make(kind, **kw):
         if kind != "oracle":
             ensure_hip_library()
-        env = BatchedEnv(_api=oracle_api, **kw) if kind == "oracle" else BatchedEnv(**kw)
+        if kind == "hip_hooks":
+            env = BatchedEnv(_api=request.getfixturevalue("hip_hooks_api"), **kw)
+        else:
+            env = BatchedEnv(_api=oracle_api, **kw) if kind == "oracle" else BatchedEnv(**kw)
         made.append(env)
         return env
 

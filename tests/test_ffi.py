@@ -10,21 +10,35 @@ from conftest import ROOT
 from triton_racer_sim_amd import _ffi
 
 
-def header_functions():
+def header_functions(test_hooks=False):
+    """Functions include/trsim.h declares; the block inside #ifdef TRS_TEST_HOOKS only when asked for."""
     with open(os.path.join(ROOT, "include", "trsim.h")) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\b(trs_[a-z_0-9]+)\s*\(", text)))
+    hooks = "".join(re.findall(r"#ifdef TRS_TEST_HOOKS(.*?)#endif", text, flags=re.S))
+    if not test_hooks:
+        text = re.sub(r"#ifdef TRS_TEST_HOOKS.*?#endif", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(trs_[a-z_0-9]+)\s*\(", text)))
+    return names if not test_hooks else sorted(set(re.findall(r"\b(trs_[a-z_0-9]+)\s*\(", hooks)))
 
 
 def test_header_declares_what_the_binding_binds():
     assert header_functions() == sorted("trs_" + s for s in _ffi.SYMBOLS + _ffi.PILOT_SYMBOLS)
+    assert header_functions(test_hooks=True) == sorted("trs_" + s for s in _ffi.HOOK_SYMBOLS)
 
 
-def test_hip_library_exports_every_symbol():
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("trs_"))
+
+
+def test_hip_library_exports_exactly_the_header():
+    """libtrsim.so = the drop-in surface, nothing else: the two trs_resident_debug_* test hooks live in csrc/libtrsim_testhooks.so (-DTRS_TEST_HOOKS) only."""
     from conftest import ensure_hip_library
-    lib = ctypes.CDLL(ensure_hip_library())       # built by __graft_entry__.build(); loading needs no GPU
-    for name in header_functions():
-        assert hasattr(lib, name), name
+    import __graft_entry__
+    assert exported(ensure_hip_library()) == header_functions()
+    hooks_lib = __graft_entry__.build_hip_testhooks()
+    assert exported(hooks_lib) == sorted(header_functions() + header_functions(test_hooks=True))
 
 
 def test_oracle_exports_the_same_abi(oracle_api):

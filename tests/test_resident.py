@@ -160,7 +160,7 @@ def test_resident_worker_generations_under_load(make_env):
     """The worker leaves on its own when its lifetime is spent, even while posts keep coming; the host restarts it from the
     first step it did not take.  With a 1.5 ms lifetime a 4,000-step run crosses that seam dozens of times."""
     n = 128
-    g, o = make_env("hip", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)
+    g, o = make_env("hip_hooks", n_envs=n, auto_reset=True), make_env("oracle", n_envs=n, auto_reset=True)   # (the test build of the library: csrc/libtrsim_testhooks.so)
     g.set_step_mode(True)
     g.resident_lifetime(1500)                                    # trs_resident_debug_lifetime
     for chunk in (1500, 1, 2499):
@@ -317,7 +317,7 @@ def test_resident_physics_256_envs_configs1_many_steps(make_env):
 def test_resident_physics_worker_generations_idle_exit_and_launch_mix(make_env):
     """Workers that leave (idle, a short lifetime under load) and are restarted by the next post; launches and resets in between."""
     n = 96
-    g, o = make_env("hip", n_envs=n, render=False, auto_reset=True), make_env("oracle", n_envs=n, render=False, auto_reset=True)
+    g, o = make_env("hip_hooks", n_envs=n, render=False, auto_reset=True), make_env("oracle", n_envs=n, render=False, auto_reset=True)
     g.set_step_mode(True, idle_us=300)
     for env in (g, o):
         env.step_synthetic(5, 1)
@@ -347,7 +347,7 @@ def test_resident_abort_makes_every_wave_leave_and_the_host_gets_an_error(make_e
     so on every later step, and loading the track again makes it usable."""
     for kw in (dict(filter=True), dict(filter=False), dict(filter=False, render=False)):
         n = 1024 if kw.get("render", True) else 256
-        g = make_env("hip", n_envs=n, auto_reset=True, render=kw.get("render", True))
+        g = make_env("hip_hooks", n_envs=n, auto_reset=True, render=kw.get("render", True))
         if kw["filter"]:
             g.set_frame_filter({"preprocessing_dynamic_brightness_enabled": True, "preprocessing_contrast_enhancement_ratio": 1.2})
         g.set_step_mode(True, idle_us=100000)

@@ -122,8 +122,10 @@ PILOT_ARRAYS_OF_TYPE = {"cnn_2d_speed_control": 22, "cnn_2d": 22, "cnn_2d_speed_
 
 # HIP library only: the CNN pilot is a floating-point kernel whose checker is a PyTorch fp32 reference, not the C oracle
 PILOT_SYMBOLS = ["default_pilot_config", "pilot_load", "pilot_forward", "pilot_forward_host", "pilot_forward_ex", "pilot_forward_host_ex",
-                 "pilot_debug_layer", "pilot_range_check", "pilot_act", "step_pilot", "default_pilot_tuning", "pilot_set_tuning",
-                 "resident_debug_lifetime", "resident_debug_abort"]      # (the last two: test hooks of the resident worker, which the oracle does not have either)
+                 "pilot_debug_layer", "pilot_range_check", "pilot_act", "step_pilot", "default_pilot_tuning", "pilot_set_tuning"]
+# test hooks of the resident worker: only in csrc/libtrsim_testhooks.so (-DTRS_TEST_HOOKS), never in the product library
+HOOK_SYMBOLS = ["resident_debug_lifetime", "resident_debug_abort"]
+HIP_TESTHOOKS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libtrsim_testhooks.so")
 
 
 class Api:
@@ -193,9 +195,8 @@ class Api:
             "step_pilot": (i32, [vp, C.POINTER(TrsPilotConfig), i32]),
             "default_pilot_tuning": (None, [C.POINTER(TrsPilotTuning)]),
             "pilot_set_tuning": (i32, [vp, C.POINTER(TrsPilotTuning)]),
-            "resident_debug_lifetime": (i32, [vp, i32]),
-            "resident_debug_abort": (i32, [vp]),
         }
+        hooks = {"resident_debug_lifetime": (i32, [vp, i32]), "resident_debug_abort": (i32, [vp])}
         for name, (res, args) in sigs.items():
             fn = getattr(cdll, prefix + name)
             fn.restype, fn.argtypes = res, args
@@ -203,6 +204,12 @@ class Api:
         self.has_pilot = hasattr(cdll, prefix + "pilot_load")
         if self.has_pilot:
             for name, (res, args) in pilot.items():
+                fn = getattr(cdll, prefix + name)
+                fn.restype, fn.argtypes = res, args
+                setattr(self, name, fn)
+        self.has_test_hooks = hasattr(cdll, prefix + "resident_debug_lifetime")
+        if self.has_test_hooks:
+            for name, (res, args) in hooks.items():
                 fn = getattr(cdll, prefix + name)
                 fn.restype, fn.argtypes = res, args
                 setattr(self, name, fn)

@@ -501,7 +501,15 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
         const f2v rtn = t.lrow[vn < p.H ? vn : v];                          // prefetch the next row's table entry
         const unsigned pal_a = t.pal_off + ((unsigned)v << 4);
         const f2v lz2 = {rt.x, rt.x}, kk2 = {rt.y, rt.y};
-        const f2v a = __builtin_elementwise_fma(lz2, sc, camxz);           // (ax, az)
+        f2v a;                                                             // (ax, az)
+        if constexpr (UNI_CHECK) {
+            // (the HILLS instantiations: hipcc picked the in-place cross-half packed form here — v_pk_fma_f32 v[10:11], v[10:11], .. op_sel_hi:[0,1,1], the one
+            // tests/test_build_lint.py screens for (DESIGN.md "Packed FP32") — so the two fused multiply-adds are written apart: the same IEEE results)
+            a.x = __builtin_fmaf(rt.x, sc.x, camxz.x);
+            a.y = __builtin_fmaf(rt.x, sc.y, camxz.y);
+        } else {
+            a = __builtin_elementwise_fma(lz2, sc, camxz);
+        }
         const f2v d = ray_step(kk2, cns);                                  // (dx, dz) = (k*c, -(k*s))
         auto shade = [&](f2v uf) -> uint32_t {
             const f2v g = __builtin_elementwise_fma(uf, d, a);             // (gx, gz)

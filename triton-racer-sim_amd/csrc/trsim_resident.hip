@@ -1386,6 +1386,7 @@ int resident_post_host(trs_env* e, const float* h_st, const float* h_th, const f
 
 }  // namespace trsim
 
+#ifdef TRS_TEST_HOOKS   /* csrc/libtrsim_testhooks.so only (include/trsim.h) */
 TRS_EXPORT int trs_resident_debug_lifetime(trs_env* e, int life_us)
 {
     if (!e) return trs_internal_fail(TRS_ERR_ARG, "null handle");
@@ -1414,6 +1415,7 @@ TRS_EXPORT int trs_resident_debug_abort(trs_env* e)
     RCHK(hipStreamSynchronize(e->res->sC));
     return TRS_OK;
 }
+#endif
 
 TRS_EXPORT int trs_get_step_mode(trs_env* e, int* mode, int* fell_back)
 {

@@ -432,11 +432,16 @@ class BatchedEnv:
         self.api.check(self.api.pilot_set_tuning(self._h, C.byref(t)), "pilot_set_tuning")
 
     def resident_lifetime(self, life_us):
-        """Test hook (``trs_resident_debug_lifetime``): resident workers leave by themselves after ``life_us``."""
+        """Test hook (``trs_resident_debug_lifetime``): resident workers leave by themselves after ``life_us``.  Only in the test build of the library
+        (``csrc/libtrsim_testhooks.so``, ``-DTRS_TEST_HOOKS``): bind it with ``BatchedEnv(_api=...)`` as ``tests/conftest.py`` does."""
+        if not getattr(self.api, "has_test_hooks", False):
+            raise RuntimeError("trs_resident_debug_lifetime is not part of libtrsim.so: bind csrc/libtrsim_testhooks.so (tests/conftest.py: make_env('hip_hooks', ...))")
         self.api.check(self.api.resident_debug_lifetime(self._h, int(life_us)), "resident_debug_lifetime")
 
     def resident_abort(self):
-        """Test hook (``trs_resident_debug_abort``): the running worker's abort bit is set from outside."""
+        """Test hook (``trs_resident_debug_abort``): the running worker's abort bit is set from outside (test build of the library only)."""
+        if not getattr(self.api, "has_test_hooks", False):
+            raise RuntimeError("trs_resident_debug_abort is not part of libtrsim.so: bind csrc/libtrsim_testhooks.so (tests/conftest.py: make_env('hip_hooks', ...))")
         self.api.check(self.api.resident_debug_abort(self._h), "resident_debug_abort")
 
     def pilot_config(self, cfg=None):
