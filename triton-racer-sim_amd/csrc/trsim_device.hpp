@@ -551,19 +551,22 @@ __device__ __forceinline__ void raster_ground_rows(const RParams& p, const Raste
 
 // ---- tracks with elevation (include/trsim_spec.h, "tracks with elevation") ------------------------------------------------------
 // On a hilly track a frame's row tables depend on the env and the step: the view pitch P = pitch + dpitch[nearest track point] (the slope ahead against
-// the slope here) comes from the physics wave with the camera parameters, and the raster team evaluates the H rows once per env and frame into a
-// table of its own in LDS — float2 rowtab[H] | uint32 palette[H][4] | float depth[H], the layout of the host's tables, so the row loops above only get
-// another base (raster_use_table).  Thread v < H of the raster team computes row v: binary32, the spec's operation order (no contraction: the kernels
-// are built with -ffp-contract=off; the division is IEEE).  Two tables alternate, so ONE team barrier per env frame orders the writers of a table behind
-// its last readers (a wave reaches the barrier of env j + 1 only after it has shaded env j - 1, whose table is the one being rewritten).
+// the slope here) comes from the physics wave with the camera parameters, and the raster team evaluates the rows into tables of its own in LDS —
+// float2 rowtab[H] | uint32 palette[H][4] | float depth[H], the layout of the host's tables, so the row loops above only get another base
+// (raster_use_table).  One thread computes one row: binary32, the spec's operation order (no contraction: the kernels are built with
+// -ffp-contract=off; the division is IEEE).  The envs of a workgroup go through in BATCHES of hill_batch(H) (as many whole tables as the 512 raster
+// threads fill in one pass, at most 4): team barrier (the previous batch's tables have been read by every wave) - build - team barrier - shade the
+// batch's envs.  (First form: one table per env frame behind its own barrier, two tables alternating: 14.7 us per step at 1024 envs x 120x160 against
+// 9.45 flat — the waves of the flat kernels never meet; profiles/r05_hills.txt.)
 constexpr int kHillRowBytes = 28;
+constexpr int kHillBatchMax = 4;
 __host__ __device__ inline int hill_table_bytes(int H) { return (kHillRowBytes * H + 15) & ~15; }
+__host__ __device__ inline int hill_batch(int H) { const int b = kRasterThreads / (H > 0 ? H : 1); return b < 1 ? 1 : (b > kHillBatchMax ? kHillBatchMax : b); }
+__host__ __device__ inline int hill_lds_bytes(int H) { return hill_batch(H) * hill_table_bytes(H) + 16; }   // the batch's tables + the team-barrier counter
 
-__device__ __forceinline__ void hill_rows_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int tid)
+__device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int v)
 {
-    if (tid >= p.H) return;
     const trsim::HillBlock hb = *p.hill;                     // (uniform address: scalar loads)
-    const int v = tid;
     float sp, cp;
     spec_sincos(P, sp, cp);
     const float yn = (hb.hh - ((float)v + 0.5f)) * hb.inv_f;
@@ -624,20 +627,27 @@ __device__ __forceinline__ bool team_barrier_wait(const int* dbar, int target, B
     return true;
 }
 
-// One env frame on a track with elevation.  Only the HILLS instantiations of the step kernels contain it: as a run-time branch inside the flat kernels' per-env
-// loops (a second copy of the row loop beside the flat one) it cost the FLAT-track step 3-6 % on the single-step paths, and as an out-of-line call — which gives the
-// whole kernel a stack and the calling convention's register budget — a factor of 2.5 (same-box A/Bs in profiles/r05_hills.txt).  `arrive` = the team-barrier
-// target of this env frame; returns false when the barrier gave up (resident worker: abort / safety).
-template <bool DEPTH, typename Bail>
-__device__ __forceinline__ bool raster_hill_frame(const RParams& p, const RasterThread& t, unsigned char* lds, unsigned tab_off, float P, const FrameDesc& f,
-                                                              const float4 cam, int* hbar, int arrive, int tid, int lane, Bail& bail)
+// The tables of a batch of nb envs (view pitches P[0..nb)), between the batch's two team barriers.  Only the HILLS instantiations of the step kernels contain
+// this: as a run-time branch inside the flat kernels' per-env loops the hilly path cost the FLAT-track step 3-6 % on the single-step paths, and as an out-of-line
+// call — which gives the whole kernel a stack and the calling convention's register budget — a factor of 2.5 (same-box A/Bs in profiles/r05_hills.txt).
+// `done_before` = team barriers this kernel has passed so far x raster waves; returns false when a barrier gave up (resident worker: abort / safety).
+template <typename Bail>
+__device__ __forceinline__ bool hill_batch_build(const RParams& p, unsigned char* lds, unsigned tab0, const float (&P)[kHillBatchMax], int nb, int* hbar, int done_before,
+                                                 int tid, int lane, Bail& bail)
 {
-    hill_rows_build(p, lds, tab_off, P, tid);
+    constexpr int nrw = kRasterThreads / 64;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of the previous batch's tables have returned
+    if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!team_barrier_wait(hbar, done_before + nrw, bail)) return false;
+    const unsigned tb = (unsigned)hill_table_bytes(p.H);
+    for (int row = tid; row < nb * p.H; row += kRasterThreads) {
+        const int bi = row / p.H, v = row - bi * p.H;
+        const float Pv = bi == 0 ? P[0] : (bi == 1 ? P[1] : (bi == 2 ? P[2] : P[3]));
+        hill_row_build(p, lds, tab0 + (unsigned)bi * tb, Pv, v);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (!team_barrier_wait(hbar, arrive, bail)) return false;
-    raster_ground_rows<DEPTH, true>(p, raster_use_table(t, lds, tab_off, p.H), f, cam);
-    return true;
+    return team_barrier_wait(hbar, done_before + 2 * nrw, bail);
 }
 
 // The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
     float* const lpitch = reinterpret_cast<float*>(smem + sp.lds_off_pitch);   // [n_phys + 1][cam_stride] view pitch per (step, env): tracks with elevation only
-    int* const hbar = reinterpret_cast<int*>(smem + sp.lds_off_hill + 2 * hill_table_bytes(p.H));   // the raster team's barrier counter of the per-env row tables
+    int* const hbar = reinterpret_cast<int*>(smem + sp.lds_off_hill + hill_batch(p.H) * hill_table_bytes(p.H));   // the raster team's barrier counter of the per-env row tables
     if (HILLS && tid == 0) *hbar = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0;   // esum[2][4][3], dbar
@@ -236,6 +236,36 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     // pipelined launch got 6 % LONGER (13.5 -> 14.4 us at 1024 envs: the frames are then written in two sweeps over all envs
     // instead of one contiguous 57.6 KB stream per env).  Env by env it is.)
     for (int e = e_begin; e < e_end; ++e) {
+        if constexpr (HILLS) {
+            // ---- a track with elevation: the envs go through in batches — poses and view pitches of the batch, its row tables between two team barriers
+            // (trsim_device.hpp, hill_batch_build), then the same row loop on each env's table
+            const int HB = hill_batch(p.H);
+            if ((e - e_begin) % HB != 0) continue;                            // the batch leader's iteration does the work
+            const int nbatch = (e_end - e_begin + HB - 1) / HB;
+            const int it = (sidx - sp.r_first) * nbatch + (e - e_begin) / HB; // batches so far (the same in every wave)
+            const int nb = min(HB, e_end - e);
+            float4 cams[kHillBatchMax]; float Pv[kHillBatchMax];
+#pragma unroll
+            for (int bi = 0; bi < kHillBatchMax; ++bi) {
+                cams[bi] = make_float4(0.f, 0.f, 0.f, 1.f); Pv[bi] = 0.f;
+                if (bi < nb) {
+                    const int j = e - e_begin + bi;
+                    if (sidx < 0) { cams[bi] = lcam_prev[j]; Pv[bi] = lpitch[max(sp.n_phys, 1) * sp.cam_stride + j]; }
+                    else {
+                        while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
+                        cams[bi] = lcam[sidx * sp.cam_stride + j]; Pv[bi] = lpitch[sidx * sp.cam_stride + j];
+                    }
+                }
+            }
+            auto never = [](bool) { return false; };                          // (a launch has no abort: every raster wave arrives)
+            (void)hill_batch_build(p, smem, (unsigned)sp.lds_off_hill, Pv, nb, hbar, it * 2 * (kRasterThreads / 64), tid, lane, never);
+#pragma unroll
+            for (int bi = 0; bi < kHillBatchMax; ++bi)
+                if (bi < nb)
+                    raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)sp.lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
+                                                    frame_desc<DEPTH>(p, img, dep, e + bi), cams[bi]);
+            continue;
+        }
         if constexpr (DYN) {
             // ---- dynamic brightness behind the rasteriser: the frame's own mean over rows [w0, w1) only needs the class of
             // every pixel there, so, for up to kDynBatch envs at a time: (A) classify those rows once (classes kept in
@@ -274,15 +304,6 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         } else {                                                              // wait until the physics team has finished this step of env j
             while (__hip_atomic_load(&pprog[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < sidx + 1) __builtin_amdgcn_s_sleep(2);
             cam = lcam[sidx * sp.cam_stride + j];
-        }
-        if constexpr (HILLS) {
-            // a track with elevation: this frame's row tables from its own view pitch (trsim_device.hpp, hill_rows_build), then the same row loop on them
-            const float P = lpitch[(sidx < 0 ? max(sp.n_phys, 1) : sidx) * sp.cam_stride + j];
-            const int hit = (sidx - sp.r_first) * (e_end - e_begin) + j;      // env frames so far (the same in every wave)
-            const unsigned tab = (unsigned)sp.lds_off_hill + (unsigned)((hit & 1) * hill_table_bytes(p.H));
-            auto never = [](bool) { return false; };                          // (a launch has no abort: every raster wave arrives)
-            (void)raster_hill_frame<DEPTH>(p, rth, smem, tab, P, fd, cam, hbar, (kRasterThreads / 64) * (hit + 1), tid, lane, never);
-            continue;
         }
         raster_ground_rows<DEPTH>(p, rth, fd, cam);
     }
@@ -1009,7 +1030,7 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.lds_off_pitch = sp.lds_off_hill = lds;
     if (e->rp.hill) {                                                               // a track with elevation: view pitches beside the camera ring, two per-env row tables, a counter
         sp.lds_off_pitch = lds; lds += (std::max(n_phys, 1) + 1) * sp.cam_stride * 4;
-        sp.lds_off_hill = (lds + 15) & ~15; lds = sp.lds_off_hill + 2 * hill_table_bytes(e->H) + 16;
+        sp.lds_off_hill = (lds + 15) & ~15; lds = sp.lds_off_hill + hill_lds_bytes(e->H);
     }
     const bool dyn = e->has_frame_filter && e->filter_dynamic;
     // Which frame buffers hold the CURRENT palette's uniform rows for every env (e->uniform_ok[b]): a launch that renders whole frames into a buffer makes it
@@ -1290,7 +1311,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     const size_t grid_bytes = align_up(T.grid_start.size() * 2, 16) + align_up(T.grid_pts.size() * 2, 16);
     // (... and leaves room for what the kernels keep behind the tables: the camera hand-off ring of a few steps, and on a track with elevation the two per-env
     // row tables + the view pitches — the mountain track's points + tangents fill the CU to within 150 bytes on their own)
-    const size_t behind = (size_t)k.envs_per_wg * 4 + 16 + (size_t)k.envs_per_wg * 20 * 3 + (T.hills ? (size_t)2 * hill_table_bytes(e->H) + 64 : 0);
+    const size_t behind = (size_t)k.envs_per_wg * 4 + 16 + (size_t)k.envs_per_wg * 20 * 3 + (T.hills ? (size_t)hill_lds_bytes(e->H) + 64 : 0);
     k.tan_in_lds = ((size_t)n_lds_off_phys + off + grid_bytes + tan_bytes + behind <= 160 * 1024) ? 1 : 0;
     if (k.tan_in_lds) off += tan_bytes;
     // nearest-point accelerator tables ride behind the points (uint16 cell starts + point lists)
@@ -1342,7 +1363,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     {   // room left in the CU's 160 KiB for the in-launch camera ring: float4 per env per step + one counter per env
         const int epw = k.envs_per_wg;
         // (a track with elevation: + two per-env row tables and their counter, + 4 bytes of view pitch per env and step beside the 16 of the camera parameters)
-        const int hill_b = T.hills ? 2 * hill_table_bytes(e->H) + 32 + epw * 4 : 0, per_step = epw * (T.hills ? 20 : 16);
+        const int hill_b = T.hills ? hill_lds_bytes(e->H) + 16 + epw * 4 : 0, per_step = epw * (T.hills ? 20 : 16);
         const int free_b = 160 * 1024 - n_lds_step - epw * 4 - 16 - epw * 16 - hill_b;
         n_max_spl = std::max(1, std::min(16, free_b / per_step));
         const int free_dyn = free_b - (dyn_lds_bytes(e->H) + 32);

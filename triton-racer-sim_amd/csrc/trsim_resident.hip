@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
     if (tid == 0) { lds_store64(l.word, wp.start); lds_store64(l.fwd, wp.start); }
     if (tid < kSlots) l.arrive[tid] = 0;
     for (int j = tid; j < 2 * epw; j += kBlock) l.pprog[j] = 0;          // pprog | rread
-    int* const hbar = reinterpret_cast<int*>(smem + wp.lds_off_hill + 2 * hill_table_bytes(p.H));   // (a track with elevation: the row tables' team-barrier counter)
+    int* const hbar = reinterpret_cast<int*>(smem + wp.lds_off_hill + hill_batch(p.H) * hill_table_bytes(p.H));   // (a track with elevation: the row tables' team-barrier counter)
     if (HILLS && tid == 0) *hbar = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + wp.fp.lds_off + kDynBatch * p.H * 16)[tid] = 0;   // channel sums, team-barrier counter
@@ -722,6 +722,57 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             }
             continue;
         }
+        if constexpr (HILLS) {
+            // A track with elevation: the envs of a step go through in batches (trsim_device.hpp, hill_batch_build): poses, view pitches and telemetry of the batch from
+            // the hand-off slots, the batch's row tables between two team barriers — bounded like every other wait of the worker (abort bit, safety deadline) — then
+            // the row loop per env on its table.  Arrivals owed are settled at the step's start, as in the dynamic-brightness path: everything issued since the end of
+            // step `owed` is then whole steps.
+            while (s - owed >= keep) {
+                wait_vmcnt_le((int)(s - owed - 1) * nstep);
+                raster_arrive(l, owed++, lane);
+            }
+            const int HB = hill_batch(p.H);
+            const int nbatch = (n_loc + HB - 1) / HB;
+            for (int b0 = 0; b0 < n_loc; b0 += HB) {
+                const int nb = min(HB, n_loc - b0);
+                float4 cams[kHillBatchMax]; float Pv[kHillBatchMax];
+                unsigned tel = 0; int mine_j = -1;
+#pragma unroll
+                for (int bi = 0; bi < kHillBatchMax; ++bi) {
+                    cams[bi] = make_float4(0.f, 0.f, 0.f, 1.f); Pv[bi] = 0.f;
+                    const int j = b0 + bi;
+                    if (bi < nb) {
+                        if (!wait_lds_ge(wp, l, nullptr, &l.pprog[j], r + 1, 3u, lane)) return;
+                        const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
+                        cams[bi] = *reinterpret_cast<const float4*>(sl);
+                        Pv[bi] = sl[17];
+                        if ((j % (kRasterThreads / 64)) == wave) { mine_j = j; tel = __float_as_uint(sl[4 + min(lane, 12)]); }
+                        asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cams[bi].x), "v"(cams[bi].y), "v"(cams[bi].z), "v"(cams[bi].w), "v"(tel), "v"(Pv[bi]) : "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                u64 t0_bar = 0;
+                auto bail = [&](bool first) -> bool {
+                    if (lds_load64(l.word) & kAbortBit) return true;
+                    const u64 now = (u64)wall_clock64();
+                    if (first) { t0_bar = now; return false; }
+                    if (now - t0_bar > wp.safety_ticks) { worker_abort(wp, l, 5u); return true; }
+                    return false;
+                };
+                if (!hill_batch_build(p, smem, (unsigned)wp.lds_off_hill, Pv, nb, hbar, (r * nbatch + b0 / HB) * 2 * (kRasterThreads / 64), tid, lane, bail)) return;
+#pragma unroll
+                for (int bi = 0; bi < kHillBatchMax; ++bi)
+                    if (bi < nb)
+                        raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)wp.lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
+                                                        frame_desc<DEPTH>(p, img, dep, e_begin + b0 + bi), cams[bi]);
+                if (mine_j >= 0 && !(kDiag & 2)) {                    // the step's telemetry of this wave's env of the batch (a wave owns at most one of a batch of <= 4 <= 8)
+                    const size_t e = (size_t)(e_begin + mine_j);
+                    if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else if (lane < 14) __hip_atomic_store((__attribute__((address_space(1))) unsigned char*)(uintptr_t)optr + e, (unsigned char)(lane == 12 ? tel : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            continue;
+        }
         const bool sweep = ahead == 0;
         if (sweep)
             for (int j = 0; j < n_loc; ++j) raster_uniform_rows<DEPTH>(p, rth, frame_desc<DEPTH>(p, img, dep, e_begin + j));
@@ -740,28 +791,11 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
             if (probe) t_pose += now_clk() - tq0;
             const float* const sl = l.slot + ((size_t)(r & (kCamDepth - 1)) * epw + j) * kSlotWords;
             const float4 cam = *reinterpret_cast<const float4*>(sl);
-            float vpitch = 0.0f;
-            if constexpr (HILLS) vpitch = sl[17];
             const bool mine = (j % (kRasterThreads / 64)) == wave;
             unsigned tel = 0;
             if (mine) tel = __float_as_uint(sl[4 + min(lane, 12)]);      // lanes 0..11 their word, lane 12 `done`
-            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel), "v"(vpitch) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(cam.x), "v"(cam.y), "v"(cam.z), "v"(cam.w), "v"(tel) : "memory");
             if (lane == 0) __hip_atomic_fetch_add(&l.rread[j], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if constexpr (HILLS) {
-                // a track with elevation: this frame's row tables from its own view pitch (hill_rows_build), two tables alternating, one team barrier per env frame —
-                // bounded like every other wait of the worker (abort bit, safety deadline)
-                const int hit = r * n_loc + j;                          // env frames of this launch so far (the same in every wave)
-                const unsigned tab = (unsigned)wp.lds_off_hill + (unsigned)((hit & 1) * hill_table_bytes(p.H));
-                u64 t0_bar = 0;
-                auto bail = [&](bool first) -> bool {
-                    if (lds_load64(l.word) & kAbortBit) return true;
-                    const u64 now = (u64)wall_clock64();
-                    if (first) { t0_bar = now; return false; }
-                    if (now - t0_bar > wp.safety_ticks) { worker_abort(wp, l, 5u); return true; }
-                    return false;
-                };
-                if (!raster_hill_frame<DEPTH>(p, rth, smem, tab, vpitch, fd, cam, hbar, (kRasterThreads / 64) * (hit + 1), tid, lane, bail)) return;
-            } else
             raster_ground_rows<DEPTH>(p, rth, fd, cam);
             if (mine && !(kDiag & 2)) {                     // the step's telemetry of env j: two wave instructions, written through
                 const size_t e = (size_t)(e_begin + j);
@@ -985,7 +1019,7 @@ int worker_fits(trs_env* e)
     R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
     if (e->has_frame_filter && e->filter_dynamic) { R->lds_off_dyn = (R->lds_bytes + 15) & ~15; R->lds_bytes = R->lds_off_dyn + dyn_lds_bytes(e->H); }
     R->lds_off_hill = (R->lds_bytes + 15) & ~15;
-    if (e->rp.hill) R->lds_bytes = R->lds_off_hill + 2 * hill_table_bytes(e->H) + 16;   // a track with elevation: the per-env row tables (trsim_device.hpp, hill_rows_build)
+    if (e->rp.hill) R->lds_bytes = R->lds_off_hill + hill_lds_bytes(e->H);   // a track with elevation: the per-env row tables (trsim_device.hpp, hill_rows_build)
     if (R->lds_bytes > 160 * 1024)
         return trs_internal_fail(TRS_ERR_LIMIT, e->rp.hill ? "the resident worker's LDS state and the per-env row tables of a track with elevation do not fit beside this track's tables: use TRS_STEP_LAUNCH"
                                                             : "too many envs per workgroup for the resident worker's LDS state");
