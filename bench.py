@@ -309,6 +309,32 @@ def filtered_step_leg(device):
     return out
 
 
+def hilly_track_leg(device):
+    """A track with elevation (include/trsim_spec.h, round 5): the reference's mountain track (car_templates/track_data/mountain_track.json), 1024 envs x 120x160 —
+    a frame's view pitch follows the slope ahead, the row tables and the depth frame are evaluated per env inside the kernel.  Resident worker, every step posted on
+    its own; host wall clock between completion flags, 2000 steps after an 80 ms pre-warm; RGB and RGB + depth."""
+    from triton_racer_sim_amd.env import BatchedEnv
+    n, steps = 1024, 2000
+    out = {}
+    for name, depth in (("rgb", False), ("rgb_depth", True)):
+        env = BatchedEnv(n_envs=n, auto_reset=True, track="mountain_track", depth=depth, device=device)
+        env.set_step_mode(True, 100000)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < PREWARM_S:
+            env.step_synthetic(400, 1)
+            env.sync()
+        t1 = time.perf_counter()
+        env.step_synthetic(steps, 1)
+        env.sync()
+        wall = time.perf_counter() - t1
+        B = algorithmic_bytes(120, 160, True, depth)
+        out[name] = {"us_per_step": round(wall * 1e6 / steps, 3), "env_steps_per_s": round(n * steps / wall, 1), "frac_of_hbm_peak": round(B * n * steps / wall / 1e9 / HBM_PEAK_GBS, 5)}
+        env.close()
+    out["note"] = ("mountain_track (2,664 points, 4.2 units of height): per-env view pitch from the slope ahead (up to 4.1 deg), row tables / fogged palette / row depth "
+                   "evaluated per env and frame by the raster team (HILLS instantiation of trs_worker_kernel); the flat generated track is the main line")
+    return out
+
+
 class phase:
     """``with phase("name", seconds):`` — a phase of a multi-rank run that can only stall on ANOTHER rank (rendezvous, barrier, collective).  When it
     takes longer than ``seconds`` the rank says which phase it is stuck in and exits with code 3 (the launcher then stops the other ranks): no silent
@@ -749,6 +775,12 @@ def main():
                 filtered_leg = filtered_step_leg(local_rank)
             except Exception as exc:
                 filtered_leg = {"error": str(exc)}
+        hilly_leg = None
+        if (args.img_h, args.img_w) == (120, 160) and not args.depth:
+            try:
+                hilly_leg = hilly_track_leg(local_rank)
+            except Exception as exc:
+                hilly_leg = {"error": str(exc)}
         env.set_step_mode(resident, 100000)
         Bx = algorithmic_bytes(args.img_h, args.img_w, render, args.depth)
         rate = lambda ms: round(n * args.steps / (ms * 1e-3), 1)
@@ -781,6 +813,8 @@ def main():
             also["image_path"] = image_leg
         if filtered_leg:
             also["filtered_step"] = filtered_leg
+        if hilly_leg:
+            also["hilly_track"] = hilly_leg
     if dist is not None:
         wall = max_over_ranks(wall, host_group)
 

@@ -48,6 +48,8 @@ def test_bench_line_has_the_contract_keys():
     fs = also["filtered_step"]
     assert "error" not in fs and {"raw_frames", "static_palette_filter", "dynamic_brightness"} <= set(fs)
     assert all(fs[k]["us_per_step"] > 0 for k in ("raw_frames", "static_palette_filter", "dynamic_brightness"))
+    ht = also["hilly_track"]                                                 # a track with elevation (round 5): the mountain track's step in the driver's line
+    assert "error" not in ht and ht["rgb"]["us_per_step"] > 0 and ht["rgb_depth"]["us_per_step"] > 0 and 0 < ht["rgb"]["frac_of_hbm_peak"] < 1
 
 
 def _json_lines(out):
