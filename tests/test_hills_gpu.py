@@ -82,19 +82,38 @@ def test_hilly_track_resident_mode_equals_oracle(make_env, n, depth):
     frames_equal(g, o, "flat track after a hilly one", depth)
 
 
-def test_frame_filters_are_refused_on_a_hilly_track(make_env):
+def test_frame_filters_on_a_hilly_track(make_env):
+    """The static frame filter behind the rasteriser (trs_set_frame_filter: trim + HSV masks, components/img_preprocessing.py:37-74,92-99) on a track with elevation: a row's
+    ground colours are blended per env and frame inside the kernel, so the filter of one colour runs there on each of them (hill_filter_colour) — against the oracle, which
+    renders the raw frame and filters every pixel.  The dynamic-brightness variant is refused there with the reason (its palette and the per-env row tables are two
+    instantiations of the kernels that do not combine yet); trs_preprocess on the rendered frames works on any track."""
     pts = track_points("mountain")
+    cfgs = ({"preprocessing_contrast_enhancement_ratio": 1.25, "preprocessing_contrast_enhancement_offset": 100.0},
+            {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_color_filter_enabled": True})
+    for cfg in cfgs:
+        g, o = make_env("hip", n_envs=40, track=pts, auto_reset=True), make_env("oracle", n_envs=40, track=pts, auto_reset=True)
+        for env in (g, o):
+            env.set_frame_filter(cfg)
+            env.step_synthetic(9, 1)
+        frames_equal(g, o, f"static filter {cfg}, launches")
+        g.set_step_mode(True)
+        for env in (g, o):
+            env.step_synthetic(11, 1)
+        frames_equal(g, o, f"static filter {cfg}, resident")
+        for env in (g, o):
+            env.set_frame_filter(enabled=False)
+            env.step_synthetic(3, 1)
+        frames_equal(g, o, "raw frames again")
     g = make_env("hip", n_envs=4, track=pts)
     with pytest.raises(RuntimeError, match="elevation"):
-        g.set_frame_filter({"preprocessing_contrast_enhancement_ratio": 1.2})
+        g.set_frame_filter({"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True})
     flat = make_env("hip", n_envs=4)
-    flat.set_frame_filter({"preprocessing_contrast_enhancement_ratio": 1.2})
+    flat.set_frame_filter({"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_dynamic_brightness_enabled": True})
     with pytest.raises(RuntimeError, match="elevation"):
-        flat.load_track(pts)                                   # the filter is removed, the track is loaded
+        flat.load_track(pts)                                   # the dynamic filter is removed, the track is loaded
     o = make_env("oracle", n_envs=4, track=pts)
     for env in (flat, o):
         env.step_synthetic(3, 1)
-    frames_equal(flat, o, "after the refused filter")
-    # ImgPreprocessing on the rendered frames still works (the separate kernel)
-    cfg = {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_color_filter_enabled": True}
+    frames_equal(flat, o, "after the refused dynamic filter")
+    cfg = {"preprocessing_contrast_enhancement_ratio": 1.2, "preprocessing_color_filter_enabled": True, "preprocessing_dynamic_brightness_enabled": True}
     assert np.array_equal(flat.preprocess_host(flat.fetch("img"), cfg), o.preprocess_host(o.fetch("img"), cfg))

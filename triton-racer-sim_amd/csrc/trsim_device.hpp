@@ -48,9 +48,16 @@ struct PParams {                        // physics kernel
 struct HillBlock {
     const float* vpitch;                // [np] the view pitch of a frame whose nearest raw track point is idx: (float)pitch + dpitch[idx], one binary32 addition (host)
     float* cam_pitch;                   // [kRing][n_envs] ring of the frames' view pitches beside PParams::cam (launch mode: the next launch's first frame)
-    int off_sky;                        // raster LDS image: uint32 sky[H] (the sky colour of every row)
-    unsigned far_rgb;
+    int off_sky;                        // raster LDS image: uint32 sky[H] (the sky colour of every row; filtered by the host when a frame filter is set)
+    unsigned far_rgb;                   // (likewise)
     float inv_f, hh, cam_h_f, z_far_f, inv_zfar_f, fog_f, inv_cell_f;
+    // the static frame filter (trs_set_frame_filter without dynamic brightness) on a track with elevation: the ground colours of a row are blended per env and
+    // frame, so the filter of ONE colour (img_preprocessing.py:37-74,92-99: the host's filter_colour) runs on each of them in hill_row_build
+    int filt, f_color, f_nfilters;
+    float f_contrast, f_offset;
+    unsigned f_lo[4], f_hi[4];          // packed h | s << 8 | v << 16
+    int f_dst[4];
+    const int* hsv_tab;                 // [512] OpenCV's sdiv | hdiv fixed-point reciprocals (global)
 };
 
 struct RParams {                        // raster side of the step kernel
@@ -564,6 +571,39 @@ __host__ __device__ inline int hill_table_bytes(int H) { return (kHillRowBytes *
 __host__ __device__ inline int hill_batch(int H) { const int b = kRasterThreads / (H > 0 ? H : 1); return b < 1 ? 1 : (b > kHillBatchMax ? kHillBatchMax : b); }
 __host__ __device__ inline int hill_lds_bytes(int H) { return hill_batch(H) * hill_table_bytes(H) + 16; }   // the batch's tables + the team-barrier counter
 
+// ImgPreprocessing.__process of ONE colour without dynamic brightness and Canny (img_preprocessing.py:37-74,92-99): the device twin of the host's filter_colour —
+// the same binary32 trim, OpenCV's 8-bit fixed-point HSV with its reciprocal tables, the masks written over their destination channels in filter order.
+__device__ __forceinline__ uint32_t hill_filter_colour(const trsim::HillBlock& hb, uint32_t bgr)
+{
+    int t[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float x = (float)((bgr >> (8 * ch)) & 255u);
+        x = x - hb.f_offset;
+        x = x * hb.f_contrast;
+        x = x + hb.f_offset;
+        x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+        t[ch] = (int)x;
+    }
+    int o0 = t[0], o1 = t[1], o2 = t[2];
+    if (hb.f_color) {
+        const int r = t[0], g = t[1], b = t[2];
+        const int vv = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = vv - vmin;
+        const int sat = (diff * hb.hsv_tab[vv] + (1 << 11)) >> 12;
+        int h = (vv == r) ? (g - b) : ((vv == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
+        h = (h * hb.hsv_tab[256 + diff] + (1 << 11)) >> 12;
+        if (h < 0) h += 180;
+        const int hh = min(h, 255), ss = min(sat, 255);
+        for (int f = 0; f < hb.f_nfilters; ++f) {
+            const int lo = (int)hb.f_lo[f], hi = (int)hb.f_hi[f];
+            const bool in = hh >= (lo & 255) && hh <= (hi & 255) && ss >= ((lo >> 8) & 255) && ss <= ((hi >> 8) & 255) && vv >= ((lo >> 16) & 255) && vv <= ((hi >> 16) & 255);
+            const int val = in ? 255 : 0, d = hb.f_dst[f];
+            o0 = d == 0 ? val : o0; o1 = d == 1 ? val : o1; o2 = d == 2 ? val : o2;
+        }
+    }
+    return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
+}
+
 __device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int v)
 {
     const trsim::HillBlock hb = *p.hill;                     // (uniform address: scalar loads)
@@ -595,7 +635,7 @@ __device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* 
                     const float sum = a + b;
                     rgb |= (uint32_t)(int)(sum + 0.5f) << (8 * ch);
                 }
-                col[c] = rgb;
+                col[c] = hb.filt ? hill_filter_colour(hb, rgb) : rgb;
             }
             c0 = col[0]; c1 = col[1]; c2 = col[2]; c3 = col[3];
         }

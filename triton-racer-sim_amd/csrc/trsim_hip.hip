@@ -1386,7 +1386,8 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     (void)hipFree(e->blob_p); (void)hipFree(e->blob_r); (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->dpitch);
     e->blob_p = nb.blob_p; e->blob_r = nb.blob_r; e->tangent = nb.tangent; e->start_yaw = nb.start_yaw; e->dpitch = nb.dpitch;
     {
-        trsim::HillBlock hb{};
+        trsim::HillBlock& hb = e->hill_host;                 // (host copy: upload_palette fills in the frame filter and sends the block again)
+        hb = trsim::HillBlock{};
         hb.vpitch = nb.dpitch; hb.cam_pitch = e->cam_pitch; hb.off_sky = off_sky; hb.far_rgb = T.far_rgb;
         hb.inv_f = T.inv_f; hb.hh = T.hh; hb.cam_h_f = T.cam_h_f; hb.z_far_f = T.z_far_f; hb.inv_zfar_f = T.inv_zfar_f; hb.fog_f = T.fog_f; hb.inv_cell_f = T.inv_cellf;
         HIPCHK(hipMemcpy(e->hill_block, &hb, sizeof hb, hipMemcpyHostToDevice));
@@ -1419,10 +1420,11 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     e->step_count = 0;
     e->track_loaded = true;
     trsim::resident_clear_fault(e);
-    if (e->has_frame_filter && e->rp.hill) {               // (frame filters behind the rasteriser: not on a track with elevation yet, see trs_set_frame_filter)
+    if (e->has_frame_filter && e->filter_dynamic && e->rp.hill) {   // (the dynamic-brightness filter is not built for tracks with elevation, see trs_set_frame_filter)
         e->has_frame_filter = false; e->filter_dynamic = false;
         (void)upload_palette(e);
-        return fail(TRS_ERR_STATE, "this track has elevation: the frame filter that was set has been removed (on such a track a frame's palette is evaluated per env inside the kernels; use trs_preprocess on the rendered frames)");
+        return fail(TRS_ERR_STATE, "this track has elevation: the dynamic-brightness frame filter that was set has been removed (a frame's palette is evaluated per env inside the kernels there; "
+                                   "the static filter works, or use trs_preprocess on the rendered frames)");
     }
     if (e->has_frame_filter && e->filter_dynamic && e->max_steps_dyn < 1) {
         e->has_frame_filter = false; e->filter_dynamic = false;
@@ -1819,6 +1821,30 @@ int upload_palette(trs_env* e)
     e->uniform_ok[0] = e->uniform_ok[1] = false;               // (the closed pilot loop's steps skip rows an earlier step wrote: not across a palette change)
     { int rq = sync_all(e); if (rq) return rq; }               // frames in flight keep the palette they were launched with
     HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
+    if (e->rp.hill) {
+        // a track with elevation: the kernels blend a row's ground colours per env and frame and run the static filter on each (hill_filter_colour); the sky colours and
+        // the far colour are constants: filtered here
+        const bool flt = e->has_frame_filter && !e->filter_dynamic;
+        trsim::HillBlock& hb = e->hill_host;
+        std::vector<uint32_t> sky(e->tab.sky);
+        hb.far_rgb = e->tab.far_rgb;
+        hb.filt = flt ? 1 : 0;
+        if (flt) {
+            const trs_pre_config& c = e->frame_filter;
+            for (auto& v : sky) v = filter_colour(c, v);
+            hb.far_rgb = filter_colour(c, hb.far_rgb);
+            { int rc = ensure_hsv_table(e); if (rc) return rc; }
+            hb.f_color = c.color_filter_enabled; hb.f_nfilters = c.n_filters; hb.f_contrast = c.contrast_ratio; hb.f_offset = c.contrast_offset;
+            for (int k = 0; k < 4; ++k) {
+                hb.f_lo[k] = (unsigned)(c.hsv_lo[k][0] | (c.hsv_lo[k][1] << 8) | (c.hsv_lo[k][2] << 16));
+                hb.f_hi[k] = (unsigned)(c.hsv_hi[k][0] | (c.hsv_hi[k][1] << 8) | (c.hsv_hi[k][2] << 16));
+                hb.f_dst[k] = c.dst_channel[k];
+            }
+            hb.hsv_tab = e->hsv_tab;
+        }
+        HIPCHK(hipMemcpy(e->blob_r + hb.off_sky, sky.data(), sky.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->hill_block, &hb, sizeof hb, hipMemcpyHostToDevice));
+    }
     return TRS_OK;
 }
 
@@ -1874,9 +1900,9 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
         int rc = check_pre(c);
         if (rc) return rc;
         if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
-        if (e->track_loaded && e->rp.hill)
-            return fail(TRS_ERR_STATE, "the loaded track has elevation: a frame's palette is evaluated per env inside the kernels there, and the frame filter behind the rasteriser "
-                                       "is not built for that yet; use trs_preprocess on the rendered frames");
+        if (c->dynamic_brightness && e->track_loaded && e->rp.hill)
+            return fail(TRS_ERR_STATE, "the loaded track has elevation: a frame's palette is evaluated per env inside the kernels there, and the dynamic-brightness filter behind the "
+                                       "rasteriser is not built for that; the static filter works, or use trs_preprocess on the rendered frames");
         if (c->dynamic_brightness) {
             const int rpp = kRasterThreads / (e->W / 4);
             if (rpp < 1 || (79 + rpp - 1) / rpp > 16) return fail(TRS_ERR_LIMIT, "image too wide for the in-kernel dynamic-brightness filter (class bits of the brightness rows live in 4 registers), use trs_preprocess");
