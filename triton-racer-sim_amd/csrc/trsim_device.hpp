@@ -594,7 +594,9 @@ __device__ __forceinline__ uint32_t hill_filter_colour(const trsim::HillBlock& h
         h = (h * hb.hsv_tab[256 + diff] + (1 << 11)) >> 12;
         if (h < 0) h += 180;
         const int hh = min(h, 255), ss = min(sat, 255);
-        for (int f = 0; f < hb.f_nfilters; ++f) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {                           // (unrolled: constant indices into the block's arrays — a run-time index would put them into scratch memory)
+            if (f >= hb.f_nfilters) break;
             const int lo = (int)hb.f_lo[f], hi = (int)hb.f_hi[f];
             const bool in = hh >= (lo & 255) && hh <= (hi & 255) && ss >= ((lo >> 8) & 255) && ss <= ((hi >> 8) & 255) && vv >= ((lo >> 16) & 255) && vv <= ((hi >> 16) & 255);
             const int val = in ? 255 : 0, d = hb.f_dst[f];
