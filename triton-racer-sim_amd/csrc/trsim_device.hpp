@@ -39,12 +39,11 @@ struct PParams {                        // physics kernel
     int auto_reset, synth, n_steps, write_cam;
     uint32_t step_off;
     unsigned long long seed;
-    const struct HillBlock* hill;       // tracks with elevation (include/trsim_spec.h): nullptr on a flat track.  ONE pointer: what the hilly path needs lives in device
-                                        // memory and is read there — kernel arguments sit in scalar registers for the whole kernel, and ten more of them cost the
-                                        // flat-track step 4-9 % (spilled scalars come back through v_readlane in the row loops: profiles/r05_hills.txt)
 };
 
-// What the kernels need on a track with elevation, in device memory (trs_load_track fills it).
+// What the kernels need on a track with elevation.  It lives in device memory BEHIND the raster LDS image's bytes (RParams::blob + hill_block_offset): the kernel
+// arguments of the flat-track kernels are exactly what they were before tracks had elevation — arguments sit in scalar registers for the whole kernel, and even one
+// more pointer shifted the flat single-step launch by 2-4 % (profiles/r05_hills.txt).  Only the HILLS instantiations ever form this address.
 struct HillBlock {
     const float* vpitch;                // [np] the view pitch of a frame whose nearest raw track point is idx: (float)pitch + dpitch[idx], one binary32 addition (host)
     float* cam_pitch;                   // [kRing][n_envs] ring of the frames' view pitches beside PParams::cam (launch mode: the next launch's first frame)
@@ -70,8 +69,8 @@ struct RParams {                        // raster side of the step kernel
     int off_rowtab, off_pal, off_depth, blob_bytes;   // off_depth: float rowdepth[H] (z-depth per image row)
     int depth;                          // 1 = also write the binary32 z-depth frame
     int uni_rows;                       // leading image rows whose four class colours are equal (sky, beyond the far plane); 0 on a track with elevation
-    const struct HillBlock* hill;       // tracks with elevation: a frame's row tables are evaluated per env (hill_rows_build); nullptr on a flat track (see PParams::hill)
 };
+__host__ __device__ inline size_t hill_block_offset(int blob_bytes) { return ((size_t)blob_bytes + 63) & ~(size_t)63; }
 
 struct FParams {                        // ImgPreprocessing with dynamic brightness, evaluated inside the step kernels (their DYN instantiations)
     double baseline;
@@ -316,8 +315,8 @@ __device__ __forceinline__ void store_out(T* ptr, T v)
 // STORE_LR: store last_return[e] here on a reset (the resident worker stores it itself, with its other outputs).
 template <bool WT, bool STORE_LR = true>
 __device__ __forceinline__ void env_advance(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int synth,
-                                            float steer, float thr, float brk, uint8_t rin, int lane, StepOut& o)
-{
+                                            float steer, float thr, float brk, uint8_t rin, int lane, StepOut& o, const trsim::HillBlock* hill = nullptr)
+{   // hill: a track with elevation (the HILLS instantiations of the step kernels pass it; nullptr = flat: a compile-time constant at every other call site)
     const double* lpx = reinterpret_cast<const double*>(lphys);
     const double* lpy = reinterpret_cast<const double*>(lphys + p.off_py);
     const double* lpz = reinterpret_cast<const double*>(lphys + p.off_pz);
@@ -383,14 +382,14 @@ __device__ __forceinline__ void env_advance(const PParams& p, const unsigned cha
     const float camx = ((x1 + p.cam_fwd * hs) - p.map_x0f) * p.inv_cellf;
     const float camz = ((z1 + p.cam_fwd * hc) - p.map_z0f) * p.inv_cellf;
     o.cam = make_float4(camx, camz, hs, hc);
-    o.pitch = p.hill ? p.hill->vpitch[idx] : 0.0f;          // (every lane reads the same word: one broadcast load, requested here, needed at the hand-off)
+    o.pitch = hill ? hill->vpitch[idx] : 0.0f;              // (every lane reads the same word: one broadcast load, requested here, needed at the hand-off)
     o.is_done = is_done; o.do_reset = do_reset;
 }
 
 // ... inside the step kernels: controls from the launch's arrays, camera parameters to the global ring (the next launch's
 // first frame) and to this launch's LDS ring, then the progress counter the raster team waits on.
 __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
-                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane, float* pitch_out = nullptr, float* lpitch_slot = nullptr)
+                                         float4* cam_out, float4* lcam_slot, int* pprog_j, int lane, const trsim::HillBlock* hill = nullptr, float* lpitch_slot = nullptr)
 {
     const uint8_t rin = (!p.synth && p.ctl_reset && k == 0) ? p.ctl_reset[e] : (uint8_t)0;
     float steer = 0.f, thr = 0.f, brk = 0.f;
@@ -399,12 +398,12 @@ __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* 
         steer = p.ctl_steer[ci]; thr = p.ctl_thr[ci]; brk = p.ctl_brk ? p.ctl_brk[ci] : 0.0f;
     }
     StepOut o;
-    env_advance<false>(p, lphys, e, s, t, p.synth, steer, thr, brk, rin, lane, o);
+    env_advance<false>(p, lphys, e, s, t, p.synth, steer, thr, brk, rin, lane, o, hill);
     if (lane == 0) {
         if (p.write_cam) cam_out[e] = o.cam;                // for the next launch (its first frame)
         *lcam_slot = o.cam;                                 // for this launch's raster team
-        if (p.hill) {                                       // a track with elevation: the frame's view pitch rides along
-            if (p.write_cam && pitch_out) pitch_out[e] = o.pitch;
+        if (hill) {                                         // a track with elevation: the frame's view pitch rides along (global ring for the next launch, LDS ring for this one)
+            if (p.write_cam) hill->cam_pitch[(size_t)(t & (kRing - 1)) * p.n_envs + e] = o.pitch;
             if (lpitch_slot) *lpitch_slot = o.pitch;
         }
         if (o.is_done) atomicAdd(&p.stats[0], 1ull);
@@ -608,7 +607,7 @@ __device__ __forceinline__ uint32_t hill_filter_colour(const trsim::HillBlock& h
 
 __device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int v)
 {
-    const trsim::HillBlock hb = *p.hill;                     // (uniform address: scalar loads)
+    const trsim::HillBlock hb = *reinterpret_cast<const trsim::HillBlock*>(p.blob + trsim::hill_block_offset(p.blob_bytes));   // (uniform address: scalar loads)
     float sp, cp;
     spec_sincos(P, sp, cp);
     const float yn = (hb.hh - ((float)v + 0.5f)) * hb.inv_f;

@@ -29,8 +29,8 @@ struct trs_env {
     float4* cam = nullptr;               // [kRing][n]
     float* cam_pitch = nullptr;          // [kRing][n] the frames' view pitches (tracks with elevation)
     float* dpitch = nullptr;             // [n_points] view pitch per raw track point (device: (float)pitch + dpitch[i])
-    trsim::HillBlock* hill_block = nullptr;   // device block the kernels read on a track with elevation (PParams::hill / RParams::hill point at it then)
-    trsim::HillBlock hill_host{};             // its host copy (trs_load_track fills the camera part, upload_palette the frame filter)
+    bool hilly = false;                       // the loaded track has elevation (include/trsim_spec.h): the HILLS instantiations of the step kernels run
+    trsim::HillBlock hill_host{};             // host copy of the block behind the raster image (trs_load_track fills the camera part, upload_palette the frame filter)
     unsigned long long* stats = nullptr;
     double* loc_q = nullptr; int32_t* loc_out = nullptr; int loc_cap = 0;
     uint8_t* pre = nullptr;              // processed frames of the env (trs_preprocess with d_dst == NULL)

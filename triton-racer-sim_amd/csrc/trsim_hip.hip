@@ -84,7 +84,6 @@ struct SParams {
                                         // launch (camera parameters from the global ring, written by the previous launch)
     unsigned step_base;                 // absolute index of this launch's physics step 0
     int lds_off_phys, lds_off_cam, lds_off_prog, cam_stride;   // LDS: physics image, float4 lcam[n_phys][cam_stride], int pprog[cam_stride]
-    int lds_off_pitch, lds_off_hill;    // tracks with elevation: float lpitch[n_phys + 1][cam_stride] beside lcam; two row tables (hill_table_bytes each) + the team-barrier counter
     int skip_uniform;                   // 1: the target frame buffer already holds this palette's uniform rows (sky, beyond the far plane: they depend on neither the
                                         // pose nor the step) of every env — an earlier step wrote them and nothing has touched them since: only the rows that see the
                                         // track are written.  Set by the closed pilot loop only (trs_internal_step_launch); every other step path writes whole frames.
@@ -137,8 +136,13 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
     int* const pprog = reinterpret_cast<int*>(smem + sp.lds_off_prog);         // [cam_stride] physics steps finished per env
     const bool rendering = sp.r_last >= sp.r_first;
     for (int j = tid; j < sp.cam_stride; j += kBlock) pprog[j] = 0;
-    float* const lpitch = reinterpret_cast<float*>(smem + sp.lds_off_pitch);   // [n_phys + 1][cam_stride] view pitch per (step, env): tracks with elevation only
-    int* const hbar = reinterpret_cast<int*>(smem + sp.lds_off_hill + hill_batch(p.H) * hill_table_bytes(p.H));   // the raster team's barrier counter of the per-env row tables
+    // tracks with elevation (HILLS instantiations only; the host's launch_step lays the same regions out): behind the progress counters float lpitch[n_phys + 1][cam_stride]
+    // (view pitch per step and env), then the batch's row tables and the raster team's barrier counter; the block of constants sits behind the raster image in memory
+    const int lds_off_pitch = sp.lds_off_prog + sp.cam_stride * 4 + 16;
+    const int lds_off_hill = (lds_off_pitch + (max(sp.n_phys, 1) + 1) * sp.cam_stride * 4 + 15) & ~15;
+    float* const lpitch = reinterpret_cast<float*>(smem + lds_off_pitch);
+    int* const hbar = reinterpret_cast<int*>(smem + lds_off_hill + hill_batch(p.H) * hill_table_bytes(p.H));
+    const trsim::HillBlock* const hill = HILLS ? reinterpret_cast<const trsim::HillBlock*>(p.blob + trsim::hill_block_offset(p.blob_bytes)) : nullptr;
     if (HILLS && tid == 0) *hbar = 0;
     if constexpr (DYN) {
         if (tid < 32) reinterpret_cast<int*>(smem + sp.fp.lds_off + 4 * p.H * 16)[tid] = 0;   // esum[2][4][3], dbar
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
         if (raster_team && rendering && sp.r_first < 0)
             for (int j = tid + kRasterThreads; j < e_end - e_begin; j += kRasterThreads) lcam_prev[j] = cam_prev[e_begin + j];
         if (HILLS && raster_team && rendering && sp.r_first < 0) {             // ... and its view pitch (a track with elevation)
-            const float* const pitch_prev = p.hill->cam_pitch + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
+            const float* const pitch_prev = hill->cam_pitch + (size_t)((sp.step_base - 1u) & (kRing - 1)) * sp.ph.n_envs;
             for (int j = tid; j < e_end - e_begin; j += kRasterThreads) lpitch[max(sp.n_phys, 1) * sp.cam_stride + j] = pitch_prev[e_begin + j];
         }
     }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 for (int k = 0; k < sp.n_phys; ++k) {
                     const uint32_t t = sp.step_base + (uint32_t)k;
                     env_step(sp.ph, lphys, e, st, t, k, ring + (size_t)(t & (kRing - 1)) * sp.ph.n_envs, &lcam[k * sp.cam_stride + j], &pprog[j], lane,
-                             HILLS ? sp.ph.hill->cam_pitch + (size_t)(t & (kRing - 1)) * sp.ph.n_envs : nullptr, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
+                             hill, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
                 }
                 env_store(sp.ph, e, st, lane);
             }
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                     EnvRegs st;
                     env_load(sp.ph, e, st);
                     env_step(sp.ph, lphys, e, st, t, k, cam_out, &lcam[k * sp.cam_stride + j], &pprog[j], lane,
-                             HILLS ? sp.ph.hill->cam_pitch + (size_t)(t & (kRing - 1)) * sp.ph.n_envs : nullptr, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
+                             hill, HILLS ? &lpitch[k * sp.cam_stride + j] : nullptr);
                     env_store(sp.ph, e, st, lane);
                 }
                 if (sp.n_phys > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores have reached L2 before the next step reloads them
@@ -258,11 +262,11 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
                 }
             }
             auto never = [](bool) { return false; };                          // (a launch has no abort: every raster wave arrives)
-            (void)hill_batch_build(p, smem, (unsigned)sp.lds_off_hill, Pv, nb, hbar, it * 2 * (kRasterThreads / 64), tid, lane, never);
+            (void)hill_batch_build(p, smem, (unsigned)lds_off_hill, Pv, nb, hbar, it * 2 * (kRasterThreads / 64), tid, lane, never);
 #pragma unroll
             for (int bi = 0; bi < kHillBatchMax; ++bi)
                 if (bi < nb)
-                    raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)sp.lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
+                    raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
                                                     frame_desc<DEPTH>(p, img, dep, e + bi), cams[bi]);
             continue;
         }
@@ -1027,10 +1031,10 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
     sp.lds_off_cam = e->lds_step;                                                   // ring + counters sit behind the tables
     sp.lds_off_prog = sp.lds_off_cam + (std::max(n_phys, 1) + 1) * sp.cam_stride * 16;   // + one row: poses of the step before the launch
     int lds = sp.lds_off_prog + sp.cam_stride * 4 + 16;                            // + spare counters
-    sp.lds_off_pitch = sp.lds_off_hill = lds;
-    if (e->rp.hill) {                                                               // a track with elevation: view pitches beside the camera ring, two per-env row tables, a counter
-        sp.lds_off_pitch = lds; lds += (std::max(n_phys, 1) + 1) * sp.cam_stride * 4;
-        sp.lds_off_hill = (lds + 15) & ~15; lds = sp.lds_off_hill + hill_lds_bytes(e->H);
+    if (e->hilly) {                                                                 // a track with elevation: view pitches behind the counters, the batch's row tables, a counter
+        const int off_pitch = lds;                                                  // (= lds_off_prog + cam_stride * 4 + 16: the HILLS kernels compute the same offsets)
+        const int off_hill = (off_pitch + (std::max(n_phys, 1) + 1) * sp.cam_stride * 4 + 15) & ~15;
+        lds = off_hill + hill_lds_bytes(e->H);
     }
     const bool dyn = e->has_frame_filter && e->filter_dynamic;
     // Which frame buffers hold the CURRENT palette's uniform rows for every env (e->uniform_ok[b]): a launch that renders whole frames into a buffer makes it
@@ -1057,7 +1061,7 @@ int launch_step(trs_env* e, const float* st, const float* th, const float* br, c
         lds = sp.fp.lds_off + dyn_lds_bytes(e->H);                         // palettes of a batch of 4 envs + channel sums + barrier counter + the mask tables
     }
     const dim3 grid(grid_of(e)), block(kBlock);
-    if (e->rp.hill) {                                       // a track with elevation (no frame filters there: trs_set_frame_filter)
+    if (e->hilly) {                                         // a track with elevation (its own instantiations; the dynamic-brightness filter is refused there)
         if (e->rp.depth) hipLaunchKernelGGL((trs_step_kernel<true, false, true>), grid, block, lds, e->sP, sp);
         else hipLaunchKernelGGL((trs_step_kernel<false, false, true>), grid, block, lds, e->sP, sp);
     } else if (dyn) {
@@ -1177,8 +1181,7 @@ int create_impl(const trs_config* cfg, int device, trs_env* e)
     HIPCHK(hipMemsetAsync(e->cam, 0, (size_t)kRing * n * sizeof(float4), e->sP));
     HIPCHK(hipMalloc((void**)&e->cam_pitch, (size_t)kRing * n * sizeof(float)));   // the frames' view pitches beside the camera ring (tracks with elevation)
     HIPCHK(hipMemsetAsync(e->cam_pitch, 0, (size_t)kRing * n * sizeof(float), e->sP));
-    HIPCHK(hipMalloc((void**)&e->hill_block, sizeof(trsim::HillBlock)));
-    k.stats = e->stats; k.cam = e->cam; k.hill = nullptr;
+    k.stats = e->stats; k.cam = e->cam;
     RParams& r = e->rp;
     r.stats = e->stats;
     if (cfg->render) {
@@ -1246,7 +1249,7 @@ TRS_EXPORT int trs_destroy(trs_env* e)
     if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     if (e->pilot) { trs_pilot_free(e->pilot); e->pilot = nullptr; }
     (void)hipFree(e->slab); (void)hipFree(e->img[0]); (void)hipFree(e->img[1]); (void)hipFree(e->depth[0]); (void)hipFree(e->depth[1]); (void)hipFree(e->blob_p); (void)hipFree(e->blob_r);
-    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->cam_pitch); (void)hipFree(e->dpitch); (void)hipFree(e->hill_block);
+    (void)hipFree(e->tangent); (void)hipFree(e->start_yaw); (void)hipFree(e->cam); (void)hipFree(e->cam_pitch); (void)hipFree(e->dpitch);
     (void)hipFree(e->stats); (void)hipFree(e->loc_q); (void)hipFree(e->loc_out);
     (void)hipFree(e->mux_state); (void)hipFree(e->edge_scratch); (void)hipFree(e->seq_buf); (void)hipFree(e->glue);
     for (void* sc : e->scratch) (void)hipFree(sc);
@@ -1301,7 +1304,6 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     r.off_depth = (int)roff; roff += align_up((size_t)e->H * 4, 16);
     const int off_sky = (int)roff;
     if (T.hills) roff += align_up((size_t)e->H * 4, 16);     // a track with elevation: the sky colour of every row rides in the raster image (hill_rows_build)
-    r.hill = T.hills ? e->hill_block : nullptr;
     r.blob_bytes = (int)roff;
     n_lds_r = (int)align_up(roff, 16);
     if ((size_t)r.blob_bytes > (size_t)100 * 1024)
@@ -1341,7 +1343,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     if (T.hills) std::memcpy(hr.data() + off_sky, T.sky.data(), (size_t)e->H * 4);
 
     HIPCHK(hipMalloc((void**)&nb.blob_p, off));
-    HIPCHK(hipMalloc((void**)&nb.blob_r, roff));
+    HIPCHK(hipMalloc((void**)&nb.blob_r, trsim::hill_block_offset((int)roff) + sizeof(trsim::HillBlock)));   // (+ the constants of a track with elevation, behind the image)
     HIPCHK(hipMalloc((void**)&nb.tangent, (size_t)n_points * 8));
     HIPCHK(hipMalloc((void**)&nb.start_yaw, (size_t)n_points * 4));
     HIPCHK(hipMemcpy(nb.blob_p, hp.data(), off, hipMemcpyHostToDevice));
@@ -1355,7 +1357,6 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         HIPCHK(hipMemcpy(nb.dpitch, vp.data(), (size_t)n_points * 4, hipMemcpyHostToDevice));
     }
     k.blob = nb.blob_p; k.start_yaw = nb.start_yaw; k.tangent_g = nb.tangent;
-    k.hill = T.hills ? e->hill_block : nullptr;
     r.blob = nb.blob_r;
     k.np = n_points; r.map_w = T.info.map_w; r.map_h = T.info.map_h;
     k.map_x0f = T.map_x0f; k.map_z0f = T.map_z0f; k.inv_cellf = T.inv_cellf;
@@ -1390,7 +1391,8 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
         hb = trsim::HillBlock{};
         hb.vpitch = nb.dpitch; hb.cam_pitch = e->cam_pitch; hb.off_sky = off_sky; hb.far_rgb = T.far_rgb;
         hb.inv_f = T.inv_f; hb.hh = T.hh; hb.cam_h_f = T.cam_h_f; hb.z_far_f = T.z_far_f; hb.inv_zfar_f = T.inv_zfar_f; hb.fog_f = T.fog_f; hb.inv_cell_f = T.inv_cellf;
-        HIPCHK(hipMemcpy(e->hill_block, &hb, sizeof hb, hipMemcpyHostToDevice));
+        e->hilly = T.hills;
+        HIPCHK(hipMemcpy(e->blob_r + trsim::hill_block_offset(r.blob_bytes), &hb, sizeof hb, hipMemcpyHostToDevice));
     }
     nb = Staged{};
     e->tab = std::move(T);
@@ -1420,7 +1422,7 @@ TRS_EXPORT int trs_load_track(trs_env* e, const double* h_xyz, int n_points)
     e->step_count = 0;
     e->track_loaded = true;
     trsim::resident_clear_fault(e);
-    if (e->has_frame_filter && e->filter_dynamic && e->rp.hill) {   // (the dynamic-brightness filter is not built for tracks with elevation, see trs_set_frame_filter)
+    if (e->has_frame_filter && e->filter_dynamic && e->hilly) {   // (the dynamic-brightness filter is not built for tracks with elevation, see trs_set_frame_filter)
         e->has_frame_filter = false; e->filter_dynamic = false;
         (void)upload_palette(e);
         return fail(TRS_ERR_STATE, "this track has elevation: the dynamic-brightness frame filter that was set has been removed (a frame's palette is evaluated per env inside the kernels there; "
@@ -1817,11 +1819,11 @@ int upload_palette(trs_env* e)
     std::vector<uint32_t> pal(e->tab.palette);
     if (e->has_frame_filter && !e->filter_dynamic)             // dynamic brightness: the kernel filters a per-env palette itself
         for (auto& c : pal) c = filter_colour(e->frame_filter, c);
-    e->rp.uni_rows = e->rp.hill ? 0 : leading_uniform_rows(pal, e->H);   // (a track with elevation: which rows are sky depends on the env and the frame)
+    e->rp.uni_rows = e->hilly ? 0 : leading_uniform_rows(pal, e->H);   // (a track with elevation: which rows are sky depends on the env and the frame)
     e->uniform_ok[0] = e->uniform_ok[1] = false;               // (the closed pilot loop's steps skip rows an earlier step wrote: not across a palette change)
     { int rq = sync_all(e); if (rq) return rq; }               // frames in flight keep the palette they were launched with
     HIPCHK(hipMemcpy(e->blob_r + e->rp.off_pal, pal.data(), pal.size() * 4, hipMemcpyHostToDevice));
-    if (e->rp.hill) {
+    if (e->hilly) {
         // a track with elevation: the kernels blend a row's ground colours per env and frame and run the static filter on each (hill_filter_colour); the sky colours and
         // the far colour are constants: filtered here
         const bool flt = e->has_frame_filter && !e->filter_dynamic;
@@ -1843,7 +1845,7 @@ int upload_palette(trs_env* e)
             hb.hsv_tab = e->hsv_tab;
         }
         HIPCHK(hipMemcpy(e->blob_r + hb.off_sky, sky.data(), sky.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(e->hill_block, &hb, sizeof hb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->blob_r + trsim::hill_block_offset(e->rp.blob_bytes), &hb, sizeof hb, hipMemcpyHostToDevice));
     }
     return TRS_OK;
 }
@@ -1900,7 +1902,7 @@ TRS_EXPORT int trs_set_frame_filter(trs_env* e, const trs_pre_config* c)
         int rc = check_pre(c);
         if (rc) return rc;
         if (c->edge_detection_enabled) return fail(TRS_ERR_ARG, "the Canny layer is a neighbourhood operator: not a palette filter, use trs_preprocess");
-        if (c->dynamic_brightness && e->track_loaded && e->rp.hill)
+        if (c->dynamic_brightness && e->track_loaded && e->hilly)
             return fail(TRS_ERR_STATE, "the loaded track has elevation: a frame's palette is evaluated per env inside the kernels there, and the dynamic-brightness filter behind the "
                                        "rasteriser is not built for that; the static filter works, or use trs_preprocess on the rendered frames");
         if (c->dynamic_brightness) {

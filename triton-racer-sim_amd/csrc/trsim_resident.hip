@@ -577,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                 float lr = q[11];
                 const float epr_before = st.epr;
                 StepOut o;
-                env_advance<true, false>(P, lphys, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o);
+                env_advance<true, false>(P, lphys, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o,
+                                         HILLS ? reinterpret_cast<const trsim::HillBlock*>(p.blob + trsim::hill_block_offset(p.blob_bytes)) : nullptr);
                 if (o.do_reset) lr = epr_before;
                 if (lane == 0) {
                     q[0] = st.x; q[1] = st.y; q[2] = st.z; q[3] = st.yaw; q[4] = st.v; q[5] = st.sf; q[6] = st.epr;
@@ -1019,9 +1020,9 @@ int worker_fits(trs_env* e)
     R->lds_bytes = (int)(R->lds_off_ctl + wlds_bytes(e->pp.envs_per_wg) + 16);
     if (e->has_frame_filter && e->filter_dynamic) { R->lds_off_dyn = (R->lds_bytes + 15) & ~15; R->lds_bytes = R->lds_off_dyn + dyn_lds_bytes(e->H); }
     R->lds_off_hill = (R->lds_bytes + 15) & ~15;
-    if (e->rp.hill) R->lds_bytes = R->lds_off_hill + hill_lds_bytes(e->H);   // a track with elevation: the per-env row tables (trsim_device.hpp, hill_rows_build)
+    if (e->hilly) R->lds_bytes = R->lds_off_hill + hill_lds_bytes(e->H);   // a track with elevation: the per-env row tables (trsim_device.hpp, hill_rows_build)
     if (R->lds_bytes > 160 * 1024)
-        return trs_internal_fail(TRS_ERR_LIMIT, e->rp.hill ? "the resident worker's LDS state and the per-env row tables of a track with elevation do not fit beside this track's tables: use TRS_STEP_LAUNCH"
+        return trs_internal_fail(TRS_ERR_LIMIT, e->hilly ? "the resident worker's LDS state and the per-env row tables of a track with elevation do not fit beside this track's tables: use TRS_STEP_LAUNCH"
                                                             : "too many envs per workgroup for the resident worker's LDS state");
     return TRS_OK;
 }
@@ -1077,7 +1078,7 @@ int worker_launch(trs_env* e, uint64_t start)
         wp.fp.tabs = e->dyn_tab;
         wp.fp.lds_off = R->lds_off_dyn;
     }
-    if (e->rp.hill) {                                       // a track with elevation (no frame filters there)
+    if (e->hilly) {                                       // a track with elevation (no frame filters there)
         if (e->rp.depth) hipLaunchKernelGGL((trs_worker_kernel<true, false, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
         else hipLaunchKernelGGL((trs_worker_kernel<false, false, true>), dim3(grid), dim3(kBlock), R->lds_bytes, e->sP, wp);
         RCHK(hipGetLastError());
