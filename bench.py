@@ -25,8 +25,8 @@ of the same workload run for PREWARM_S first, then the W warm-up steps.  In resi
 boundary: `value` is the host wall clock from the post of the first timed step to the completion flag of the last (env.sync() waits on the flags
 the worker writes once a step's frames are in memory); a device-wide synchronisation there would wait for the worker to leave, so torch's stream
 is synchronised instead.  `roofline.achieved` comes from a second pass of the same K steps bracketed by HIP events on the worker's own stream
-(= one whole worker launch: start-up, K steps, exit).  --profile-mode (scripts/profile.sh) drops the pre-warm and makes every worker dispatch of a
-trace serve exactly K steps.
+(= one whole worker launch: start-up, K steps, exit).  --profile-mode (scripts/profile.sh) runs the pre-warm by launches (a resident worker's
+pre-warm dispatch would be of no fixed length) and makes every worker dispatch of a trace serve exactly K steps.
 """
 import argparse
 import ctypes
@@ -444,7 +444,7 @@ def main():
     ap.add_argument("--pilot-tuning", default="", help="with --pilot: kernel choices for measurements, e.g. dense=2,ksplit=32 (fields of trs_pilot_tuning, include/trsim.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the informational 8-steps-per-launch leg (profiling runs: only the timed kernel in the trace)")
-    ap.add_argument("--profile-mode", action="store_true", help="for rocprofv3 runs (scripts/profile.sh): no clock pre-warm, and a resident worker is asked to leave after the "
+    ap.add_argument("--profile-mode", action="store_true", help="for rocprofv3 runs (scripts/profile.sh): the clock pre-warm goes by launches (trs_step_kernel), and a resident worker is asked to leave after the "
                                                                   "warm-up, so that every trs_worker_kernel dispatch of the trace serves exactly --steps (or --warmup) steps")
     ap.add_argument("--force-dist", action="store_true", help="initialise the nccl process group even at world size 1 (path rehearsal)")
     ap.add_argument("--spawn", action="store_true", help="go through the self-launch path (launch_ranks) even at --gpus 1: the rank runs as a child process of a parent that never touches the GPU")
@@ -487,8 +487,12 @@ def main():
         else:
             # device collectives (the one all-gather): nccl = RCCL over xGMI.  Barriers and the MAX over ranks: a gloo group, i.e. host
             # sockets — a barrier must not need CU resources while every CU holds a resident worker
+            # No device_id: the communicator is then created by the warm-up all-gather below (torch.cuda.set_device above names the GPU).  Measured at
+            # world size 1 (scripts/r05_dist_probe.py, profiles/r05_dist_probe.txt): with the EAGER communicator of device_id= the first posted steps
+            # after every stream synchronisation ran at 12.0-13.0 us instead of 10.0 and the next 2000 at 10.7 instead of 9.6 (-20 % on the driver's
+            # --steps 20 line, -10 % at --steps 2000); created lazily by its first collective the same communicator costs nothing measurable.
             with phase("init_process_group(nccl)", PHASE_S):
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=PHASE_S + 30))
+                dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=PHASE_S + 30))
             with phase("new_group(gloo)", PHASE_S):
                 host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=PHASE_S + 30))
         if dist.get_world_size() != args.gpus:
@@ -560,6 +564,15 @@ def main():
     # the driver's --warmup 5 is 50 us, so the clocks are brought up first — with untimed steps of the same workload, for PREWARM_S
     # seconds — and the W warm-up steps follow.  `config.prewarm_s` says so in the line.
     t_pw = time.perf_counter()
+    if args.profile_mode and resident:
+        # under the profiler the pre-warm steps go by LAUNCHES (trs_step_kernel: its own row of the stats table), so that every trs_worker_kernel
+        # dispatch in the trace is one of the three equal ones below, and all three run at loaded clocks like the line's own (until round 5 the
+        # profiled command had no pre-warm at all: its first dispatch ran 15-20 % slow and pulled the table's average off the line's figure)
+        env.set_step_mode(False)
+        while time.perf_counter() - t_pw < PREWARM_S:
+            run(400)
+            env.sync()
+        env.set_step_mode(True)
     while not args.profile_mode and time.perf_counter() - t_pw < PREWARM_S:
         run(50 if args.pilot else 400)
         env.sync()
@@ -854,7 +867,7 @@ def main():
                             + (" + fp32 depth" if render and args.depth else "")
                             + f" = {picked}" + (f": {n * world} envs in total over {world} GPUs, one RCCL all-gather of ep_return" if world > 1 else "")
                             + ", generated_track 1185 pts, synthetic controls seed 0x5EED, auto-reset",
-                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "prewarm_s": 0.0 if args.profile_mode else PREWARM_S,
+                "envs_total": n * world, "envs_per_gpu": n, "img_h": args.img_h, "img_w": args.img_w, "depth": bool(args.depth), "steps_per_launch": spl, "step_mode": "resident worker (posted steps)" if resident else "one launch per call", "prewarm_s": PREWARM_S if (resident or not args.profile_mode) else 0.0,
                 "timing": ("host wall clock from the post of the first timed step to the completion flag of the last (worker resident across the warm-up -> timed boundary)"
                            + ("; per rank between two host (gloo) barriers, MAX over ranks" if world > 1 else "") + "; "
                            "roofline.achieved from a second pass of the same steps bracketed by HIP events = one whole worker launch") if resident else "host wall clock around the timed steps; HIP events on the env's stream for roofline.achieved", "sharding": f"{world} shard(s), no data-path collective; one all-gather of ep_return closes the job, timed separately (`allgather`)" if world > 1 else "1 shard",

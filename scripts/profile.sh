@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r01}; shift || true
 # resident mode (the default): one worker launch per timed region, so warm-up and timed region get the SAME number of steps —
 # the kernel-stats average over the two trs_worker_kernel dispatches is then the figure bench.py reports
-# (--profile-mode: no time-based pre-warm, the worker leaves after the warm-up: three dispatches of 1000 steps each — warm-up, the
+# (--profile-mode: the time-based pre-warm runs by launches (trs_step_kernel, its own row), the worker leaves after the warm-up: three dispatches of 1000 steps each — warm-up, the
 # wall-clock pass, the event-bracketed pass — so the stats table's average is a per-1000-steps figure like bench.py's avg_launch_us)
 ARGS="--steps 1000 --warmup 1000 --no-cpu-baseline --no-also --profile-mode $@"
 cd "$(dirname "$0")/.."
