@@ -182,7 +182,7 @@ def test_allgather_through_torch_nccl_and_through_the_c_abi(make_env):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29651")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", rank=0, world_size=1)            # (no device_id, as bench.py: profiles/r05_dist_probe.txt)
     try:
         got = sh.allgather("ep_return")
         assert got.is_cuda and np.array_equal(got.cpu().numpy(), sh.env.fetch("ep_return"))
