@@ -143,3 +143,68 @@ def test_trained_closed_loop_against_oracle_env_plus_torch_pilot(make_env):
     assert steer_seen.std() > 0.02 and o.fetch("speed").min() > 1.0     # the controls matter
     assert worst[0] <= 1.5e-2 and worst[1] <= 4e-2 and worst[2] == 0.0
     assert errs["pos_x"] <= 2e-2 and errs["pos_z"] <= 2e-2 and errs["yaw"] <= 2e-2 and errs["speed"] <= 2e-2 and errs["cte"] <= 2e-2
+
+
+@pytest.mark.gpu
+def test_manage_py_drive_with_the_trained_model(tmp_path):
+    """`python manage.py drive --model m.h5` (car_templates/manage.py:46-108) with this package's parts: KerasPilot -> joystick (everybody in AI mode) ->
+    ControlMultiplexer -> GymInterface -> LocationTracker -> DataStorage in the reference's Car loop, ONE car, the model loaded from a file as the reference
+    does (keras_pilot.py:26; here the .npz form of model.get_weights()).  400 ticks: the car drives a third of the lap on the road, and the tub it records is
+    what `manage.py train` reads (img_k.jpg + record_k.json with the reference's keys)."""
+    import json
+
+    from conftest import load_golden
+    from triton_racer_sim_amd.components import BatchedControlMultiplexer, HipGymInterface, HipKerasPilot, LocationTracker
+    from triton_racer_sim_amd.core import Car, Component
+    from triton_racer_sim_amd.recorder import DataStorage
+
+    class Joystick(Component):
+        def __init__(self, n_ticks):
+            Component.__init__(self, inputs=[], outputs=["usr/mode", "usr/steering", "usr/throttle", "usr/breaking", "usr/reset", "usr/del_record", "usr/toggle_record"])
+            self.k, self.n = 0, n_ticks
+
+        def step(self, *args):
+            self.k += 1
+            if self.k > self.n:
+                raise KeyboardInterrupt
+            return "ai", 0.0, 0.0, 0.0, None, False, True
+
+    class Scalars(Component):                                         # the batched mux answers with arrays of one car; GymInterface takes scalars
+        def __init__(self):
+            Component.__init__(self, inputs=["mux/steering", "mux/throttle", "mux/breaking"], outputs=["mux/steering", "mux/throttle", "mux/breaking"])
+
+        def step(self, *args):
+            return tuple(float(np.asarray(a).reshape(-1)[0]) for a in args)
+
+    class Probe(Component):
+        def __init__(self):
+            Component.__init__(self, inputs=["gym/cte", "gym/speed", "loc/segment", "ai/steering"])
+            self.rows = []
+
+        def step(self, *args):
+            self.rows.append(tuple(float(np.asarray(a).reshape(-1)[0]) if a is not None else 0.0 for a in args))
+
+    ticks = 400
+    cfg = dict(load_golden("config_keys.json")["values"])             # the reference's default config dict (G6)
+    cfg.update(scene_name="generated_track", use_location_tracker=True, spd_ctl_threshold=1.1)
+    pilot = HipKerasPilot(cfg, model_path=FIXTURE, model_type="cnn_2d_speed_control")
+    gym = HipGymInterface(poll_socket_sleep_time=0.01, gym_config=cfg)
+    mux = BatchedControlMultiplexer(cfg, n_cars=1)
+    tracker = LocationTracker(track_data_path=cfg["track_data_file"])
+    store, probe = DataStorage(storage_path=str(tmp_path / "records_1")), Probe()
+    car = Car(loop_hz=1e9, verbose=False)
+    for part in (pilot, Joystick(ticks), mux, Scalars(), gym, tracker, probe, store):
+        car.addComponent(part)
+    car.start()
+    rows = np.array(probe.rows)
+    seg0, seg1 = 1185, int(round(rows[-1, 2] / 10.0 * 1185))          # loc/segment = index / points x 10 (track_data_process.py:103-107); the parts are shut down by now
+    print(f"manage.py drive, trained model, {ticks} ticks: final track point {seg1} of {seg0}, speed {rows[-1, 1]:.2f}, max |cte| {np.abs(rows[:, 0]).max():.3f}, "
+          f"|ai/steering| max {np.abs(rows[:, 3]).max():.3f}, loc/segment {rows[-1, 2]:.2f}")
+    assert len(rows) == ticks
+    assert np.abs(rows[20:, 0]).max() < 1.0                            # on the road all the way (off-track threshold: include/trsim_spec.h)
+    assert rows[-1, 1] > 3.0                                           # at the speed the network asks for
+    assert seg1 > 300                                                  # a third of the 1185 track points behind it
+    assert np.abs(rows[:, 3]).max() > 0.1                              # it steered
+    rec = json.load(open(tmp_path / "records_1" / "record_300.json"))
+    assert list(rec) == load_golden("datastorage_record.json")["records"]["record_0.json"]["keys"]
+    assert os.path.exists(tmp_path / "records_1" / "img_300.jpg") and rec["gym/speed"] > 3.0
