@@ -360,7 +360,8 @@ class phase:
         return False
 
 
-PHASE_S = float(os.environ.get("TRS_BENCH_PHASE_S", "120"))     # how long a rendezvous / barrier / collective may take before the rank gives up
+PHASE_S = float(os.environ.get("TRS_BENCH_PHASE_S", "120"))     # how long a barrier / collective may take before the rank gives up
+RENDEZVOUS_S = 2.0 * PHASE_S                                     # ... and the rendezvous of the process groups: the ranks of a fresh box finish `import torch` up to a minute or two apart
 
 
 def launch_ranks(n_ranks, argv):
@@ -481,8 +482,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if args.share_gpu:
-            with phase("init_process_group(gloo)", PHASE_S):
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=PHASE_S + 30))
+            with phase("init_process_group(gloo)", RENDEZVOUS_S):
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=RENDEZVOUS_S + 30))
             host_group = dist.group.WORLD
         else:
             # device collectives (the one all-gather): nccl = RCCL over xGMI.  Barriers and the MAX over ranks: a gloo group, i.e. host
@@ -491,10 +492,10 @@ def main():
             # world size 1 (scripts/r05_dist_probe.py, profiles/r05_dist_probe.txt): with the EAGER communicator of device_id= the first posted steps
             # after every stream synchronisation ran at 12.0-13.0 us instead of 10.0 and the next 2000 at 10.7 instead of 9.6 (-20 % on the driver's
             # --steps 20 line, -10 % at --steps 2000); created lazily by its first collective the same communicator costs nothing measurable.
-            with phase("init_process_group(nccl)", PHASE_S):
-                dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=PHASE_S + 30))
-            with phase("new_group(gloo)", PHASE_S):
-                host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=PHASE_S + 30))
+            with phase("init_process_group(nccl)", RENDEZVOUS_S):
+                dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=RENDEZVOUS_S + 30))
+            with phase("new_group(gloo)", RENDEZVOUS_S):
+                host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=RENDEZVOUS_S + 30))
         if dist.get_world_size() != args.gpus:
             sys.exit(f"rank {rank}: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
