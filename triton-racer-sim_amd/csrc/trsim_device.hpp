@@ -129,31 +129,45 @@ __device__ __forceinline__ void spec_sincos(float a, float& so, float& co)
 
 __device__ __forceinline__ float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
-// wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.
-// DPP reduction (row_shr 1,2,4,8 then row_bcast15 / row_bcast31): data moves through the VALU's DPP path
-// instead of the LDS crossbar that __shfl (ds_bpermute) uses.  The wave's result ends in lane 63.
+// wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.  The wave's result ends in lane 63.
+// Two reductions through the VALU's DPP path (row_shr 1, 2, 4, 8, then row_bcast15 / row_bcast31; lanes without a source keep their own value):
+// the minimum distance first (two dword moves + one v_min_f64 per step; distances are finite and >= 0), then — among the lanes whose own distance IS
+// that minimum — the lowest index (one v_min_u32 per step).  Until round 5 one reduction carried the pair: a 64-bit compare, an equality test, an
+// index compare and three selects per step, which hipcc laid out as six branchy blocks of ~20 instructions each — a quarter of a physics step's
+// instructions on a chain that cannot overlap with anything (the same lexicographic minimum: results are bit-identical).
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void argmin_dpp_step(double& d, int& i)
+__device__ __forceinline__ void min_f64_dpp_step(double& d)
 {
     const int lo = __double2loint(d), hi = __double2hiint(d);
-    // lanes without a valid source (row edge / masked rows) read their own value: combining with self is a no-op
     const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
     const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
     const double od = __hiloint2double(ohi, olo);
-    const bool take = (od < d) || (od == d && oi < i);
-    d = take ? od : d;
-    i = take ? oi : i;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(od), "v"(d));
 }
-
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void min_u32_dpp_step(unsigned& i)
+{
+    const unsigned oi = (unsigned)__builtin_amdgcn_update_dpp((int)i, (int)i, CTRL, ROW_MASK, 0xf, false);
+    i = oi < i ? oi : i;
+}
 __device__ __forceinline__ void wave_argmin(double& d, int& i)
 {
-    argmin_dpp_step<0x111, 0xf>(d, i);   // row_shr:1
-    argmin_dpp_step<0x112, 0xf>(d, i);   // row_shr:2
-    argmin_dpp_step<0x114, 0xf>(d, i);   // row_shr:4
-    argmin_dpp_step<0x118, 0xf>(d, i);   // row_shr:8   -> lane 15 of each row holds the row's result
-    argmin_dpp_step<0x142, 0xa>(d, i);   // row_bcast:15 into rows 1 and 3
-    argmin_dpp_step<0x143, 0xc>(d, i);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's result
+    const double own = d;
+    min_f64_dpp_step<0x111, 0xf>(d);     // row_shr:1
+    min_f64_dpp_step<0x112, 0xf>(d);     // row_shr:2
+    min_f64_dpp_step<0x114, 0xf>(d);     // row_shr:4
+    min_f64_dpp_step<0x118, 0xf>(d);     // row_shr:8   -> lane 15 of each row holds the row's minimum
+    min_f64_dpp_step<0x142, 0xa>(d);     // row_bcast:15 into rows 1 and 3
+    min_f64_dpp_step<0x143, 0xc>(d);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+    const double dmin = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
+    unsigned k = own == dmin ? (unsigned)i : 0xFFFFFFFFu;    // (indices are < 2^16)
+    min_u32_dpp_step<0x111, 0xf>(k);
+    min_u32_dpp_step<0x112, 0xf>(k);
+    min_u32_dpp_step<0x114, 0xf>(k);
+    min_u32_dpp_step<0x118, 0xf>(k);
+    min_u32_dpp_step<0x142, 0xa>(k);
+    min_u32_dpp_step<0x143, 0xc>(k);
+    i = (int)k;
 }
 
 // wave64 sum of an unsigned per lane by the same DPP steps (lanes without a source add 0); the total ends in lane 63
@@ -231,15 +245,27 @@ __device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned
             const int x_lo = max(cx - 1, 0), x_hi = min(cx + 1, g.nx - 1);
             double best = TRS_LOST_L1;
             int bi = 0;
-            if (x_lo <= x_hi)
-                for (int rz = max(cz - 1, 0); rz <= min(cz + 1, g.nz - 1); ++rz) {
-                    const int lo = gstart[rz * g.nx + x_lo], hi = gstart[rz * g.nx + x_hi + 1];      // the three cells of a row are contiguous
-                    for (int i = lo + lane; i < hi; i += 64) {
-                        const int idx = gpts[i];
-                        const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
-                        if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
-                    }
+            if (x_lo <= x_hi) {
+                // The candidates of the (up to) three rows as ONE list: the six bucket bounds are requested together, then a lane takes candidates
+                // lane, lane + 64, ... of the concatenation — three LDS round trips (bounds, point index, coordinates) where a loop per row made nine.
+                // The minimum over (distance, index) does not depend on the order the candidates are seen in.
+                int lo[3], cnt[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int rz = cz - 1 + k;
+                    const bool in = rz >= 0 && rz <= g.nz - 1;
+                    const int rc = in ? rz : 0;
+                    const int a = gstart[rc * g.nx + x_lo], b = gstart[rc * g.nx + x_hi + 1];       // the three cells of a row are contiguous
+                    lo[k] = a; cnt[k] = in ? b - a : 0;
                 }
+                const int c01 = cnt[0] + cnt[1], total = c01 + cnt[2];
+                for (int k = lane; k < total; k += 64) {
+                    const int i = k < cnt[0] ? lo[0] + k : (k < c01 ? lo[1] + (k - cnt[0]) : lo[2] + (k - c01));
+                    const int idx = gpts[i];
+                    const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
+                    if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
+                }
+            }
             wave_argmin(best, bi);
             const int idx = __builtin_amdgcn_readlane(bi, 63);
             const double bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 63), __builtin_amdgcn_readlane(__double2loint(best), 63));
