@@ -803,11 +803,11 @@ __global__ __launch_bounds__(BLOCK, 1) void trs_conv_frame5_kernel(const Frame5P
 #endif
 struct Fuse12Params {
     const uint8_t* frames; int frames_bytes;
-    const u4v* w1; const float* b1; const int* goff1;      // conv1: [12][32] granules, [32], [12]
+    const u4v* w1; const float* b1;                        // conv1: [12][32] granules, [32]
     const u4v* w2;                                          // conv2: [80][32] granules (kernel rows padded 15 -> 16)
     ConvParams c2;                                          // conv2's output side (out, COUT, relu, nt_out, bias)
     int N, IH, IW, OH1, OW1, OH2, OW2, R2, bands;
-    int off_w2, off_b, off_goff, off_tile, off_stage;       // LDS layout
+    int off_w2, off_b, off_tile;                            // LDS layout
     int tile_bytes;
     int off_band, band_bytes;                               // band kernel: the frame rows under the conv1 tile as fp16 [rows][IW * 3]
     int wsplit, w2p, cpr;                                   // band kernel cut in width: parts per band, conv2 columns per part, 16-byte chunks per staged row
@@ -2170,7 +2170,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         const ConvLayer& l0 = c->L[0]; const ConvLayer& l1 = c->L[1];
         Fuse12Params& q = c->fuse;
         q = Fuse12Params{};
-        q.w1 = l0.w; q.b1 = l0.bias; q.goff1 = l0.goff; q.w2 = l1.w;
+        q.w1 = l0.w; q.b1 = l0.bias; q.w2 = l1.w;
         q.c2 = ConvParams{};
         q.c2.bias = l1.bias; q.c2.COUT = l1.COUT; q.c2.COUT_PAD = l1.COUT_PAD; q.c2.relu = 1; q.c2.oscale = 1.0f;
         q.IH = l0.IH; q.IW = l0.IW; q.OH1 = l0.OH; q.OW1 = l0.OW; q.OH2 = l1.OH; q.OW2 = l1.OW;
@@ -2188,7 +2188,7 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
         const bool shape_ok = l0.G_pad == 12 && l0.COUT_PAD == 32 && l1.G_pad == 80 && l1.COUT_PAD == 32 && l1.COUT == 32 && l1.CIN == 24 && l1.S == 2 && l1.KH == 5;
         const bool band_ok = l0.OW >= 32 && (2 * 8 + 3) * l0.OW < 65536;   // the band kernels split a tile's first pixel on the scalar unit and let a lane wrap once
         c->fuse12 = false; c->no_fuse = T.no_fuse != 0;
-        // band form (conv1's input staged once per band as a fp16 image): tile + band image + 8 wave stages
+        // band form (conv1's input staged once per band as a fp16 image): tile + band image
         // (measured, 1024 frames of 120x160: R2 = 7 / 6 / 5 -> 129 / 114 / 125 us against 131 for the direct form; 512 frames of
         // 240x320, where only R2 = 2 fits: 290 against 272 - bands thinner than 4 rows recompute too much of conv1)
         const int band_r2 = T.fuse_band_r2;                               // 6; 0 = use the direct form
@@ -2198,10 +2198,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
             int off = 12 * 32 * 16;
             q.off_w2 = off; off += 80 * 32 * 16;
             q.off_b = off; off += 16 * 16;
-            q.off_goff = off; off += 64;
             q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * ((l0.OW + 1) / 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;   // two column-parity planes per row
             q.off_band = off; q.band_bytes = rows_in * row_in * 2 + 64; off += q.band_bytes;
-            q.off_stage = off; off += 8 * 2048;
             if (off <= 160 * 1024) { c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2; q.wsplit = 1; break; }
         }
         // the band cut in width (240x320: a whole-width band does not fit): parts of w2p conv2 columns, each with its own conv1 tile and
@@ -2217,10 +2215,8 @@ TRS_EXPORT int trs_pilot_load(trs_env* e, const float* const* arr, int n_arrays)
                 int off = 12 * 32 * 16;
                 q.off_w2 = off; off += 80 * 32 * 16;
                 q.off_b = off; off += 16 * 16;
-                q.off_goff = off; off += 64;
                 q.off_tile = off; q.tile_bytes = (((2 * r2 + 3) * 2 * (w2p + 2) * 48 + 128) + 15) & ~15; off += q.tile_bytes;
                 q.off_band = off; q.band_bytes = rows_in * cpr * 32 + 64; off += q.band_bytes;
-                q.off_stage = off; off += 8 * 2048;
                 if (off > 160 * 1024) continue;
                 c->fuse12 = true; c->fuse_r2 = r2; c->fuse_lds = off; q.R2 = r2; q.bands = (l1.OH + r2 - 1) / r2;
                 q.wsplit = ws; q.w2p = w2p; q.cpr = cpr;
