@@ -127,6 +127,28 @@ __device__ __forceinline__ void spec_sincos(float a, float& so, float& co)
     co = (n == 0) ? c : (n == 1) ? -s : (n == 2) ? -c : s;
 }
 
+// ... the same values with the quadrant as two selects and two sign-bit XORs (a negation IS the sign bit).  Written as a chain of ?: hipcc makes exec-masked
+// branches of the quadrant (three s_and_saveexec per call).  A wave that has its SIMD to itself (the physics-only kernels) is faster without them: its step is a chain of
+// latencies and every exec write stalls it (2.36 -> 1.86 -> 1.74 us per step, profiles/r05_physics_chain.txt); a physics wave that shares its SIMD with two raster waves is
+// faster WITH them — most angles sit in quadrant 0 and the branch skips the work (the same rewrite cost the render kernels 1 % and the hilly step, which calls this per
+// image row, 15 %).  So both forms exist, chosen per kernel at compile time.
+__device__ __forceinline__ void spec_sincos_sel(float a, float& so, float& co)
+{
+    const float q = rintf(a * TRS_TWO_OVER_PI);
+    float r = fmaf(q, -TRS_PIO2_HI, a);
+    r = fmaf(q, -TRS_PIO2_LO, r);
+    const float zz = r * r;
+    const float ps = fmaf(fmaf(TRS_S0, zz, TRS_S1), zz, TRS_S2);
+    const float s = fmaf(r * zz, ps, r);
+    const float pc = fmaf(fmaf(TRS_C0, zz, TRS_C1), zz, TRS_C2);
+    const float c = fmaf(zz * zz, pc, fmaf(zz, -0.5f, 1.0f));
+    const unsigned n = (unsigned)((int)q) & 3u;          // quadrant n: (so, co) = (s, c), (c, -s), (-s, -c), (-c, s)
+    const bool odd = (n & 1u) != 0u;
+    const float ss = odd ? c : s, cc = odd ? s : c;
+    so = __uint_as_float(__float_as_uint(ss) ^ ((n & 2u) << 30));
+    co = __uint_as_float(__float_as_uint(cc) ^ (((n + 1u) & 2u) << 30));
+}
+
 __device__ __forceinline__ float clampf(float a, float lo, float hi) { return a < lo ? lo : (a > hi ? hi : a); }
 
 // wave64 argmin over (distance, index): smaller distance wins, equal distance -> lower index.  The wave's result ends in lane 63.
@@ -230,6 +252,7 @@ __device__ __forceinline__ T coherent_load(const T* ptr)
 // one (include/trsim_spec.h R3), otherwise every point is scanned.  All lanes get the result.
 struct NearParams { int np, off_py, off_pz, off_gstart, off_gpts, nx, nz; double x0, z0; };
 
+template <bool SEL = false>                              // SEL: selects instead of branches (the physics-only kernels, see spec_sincos_sel)
 __device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned char* lphys, double qx, double qy, double qz, int lane,
                                              double& best_out, int& idx_out)
 {
@@ -263,7 +286,12 @@ __device__ __forceinline__ void wave_nearest(const NearParams& g, const unsigned
                     const int i = k < cnt[0] ? lo[0] + k : (k < c01 ? lo[1] + (k - cnt[0]) : lo[2] + (k - c01));
                     const int idx = gpts[i];
                     const double d = (fabs(qx - lpx[idx]) + fabs(qy - lpy[idx])) + fabs(qz - lpz[idx]);
-                    if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
+                    if constexpr (SEL) {
+                        const bool take = d < best || (d == best && idx < bi);
+                        best = take ? d : best; bi = take ? idx : bi;
+                    } else {
+                        if (d < best || (d == best && idx < bi)) { best = d; bi = idx; }
+                    }
                 }
             }
             wave_argmin(best, bi);
@@ -339,7 +367,7 @@ __device__ __forceinline__ void store_out(T* ptr, T v)
 // scalars, the track scan is lane-parallel.  Controls are this step's (already fetched; generated here when `synth`); `rin` =
 // the user's reset request.  Side effects: last_return[e] on a reset, nothing else.
 // STORE_LR: store last_return[e] here on a reset (the resident worker stores it itself, with its other outputs).
-template <bool WT, bool STORE_LR = true>
+template <bool WT, bool STORE_LR = true, bool SEL = false>
 __device__ __forceinline__ void env_advance(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int synth,
                                             float steer, float thr, float brk, uint8_t rin, int lane, StepOut& o, const trsim::HillBlock* hill = nullptr)
 {   // hill: a track with elevation (the HILLS instantiations of the step kernels pass it; nullptr = flat: a compile-time constant at every other call site)
@@ -358,33 +386,45 @@ __device__ __forceinline__ void env_advance(const PParams& p, const unsigned cha
         const int si = (int)(((long long)TRS_START_STRIDE * gid) % p.np);
         x1 = (float)lpx[si]; y0 = (float)lpy[si]; z1 = (float)lpz[si];
         yaw1 = p.start_yaw[si]; v2 = 0.0f; sf = 0.0f;
-        spec_sincos(yaw1, hs, hc);
+        if constexpr (SEL) spec_sincos_sel(yaw1, hs, hc); else spec_sincos(yaw1, hs, hc);
     } else {
         if (synth) synth_controls(p.seed, (uint32_t)gid, t, sf, steer, thr);
         steer = clampf(steer, -1.0f, 1.0f);
         thr = clampf(thr, -1.0f, 1.0f);
         brk = clampf(brk, 0.0f, 1.0f);
         float sd, cd;
-        spec_sincos(steer * p.max_steer, sd, cd);
+        if constexpr (SEL) spec_sincos_sel(steer * p.max_steer, sd, cd); else spec_sincos(steer * p.max_steer, sd, cd);
         const float tan_d = sd / cd;
         const float a = thr * p.accel_max - p.drag_lin * s.v;
         const float v1 = s.v + a * p.dt;
         const float dv = (p.roll_res + brk * p.brake_max) * p.dt;
-        if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
-        else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
-        else v2 = 0.0f;
+        if constexpr (SEL) {                                 // (rolling resistance and brake take speed away but never reverse it)
+            const float tp = v1 - dv, tn = v1 + dv;
+            const float vp = tp < 0.0f ? 0.0f : tp, vn = tn > 0.0f ? 0.0f : tn;
+            v2 = v1 > 0.0f ? vp : (v1 < 0.0f ? vn : 0.0f);
+        } else {
+            if (v1 > 0.0f) { v2 = v1 - dv; if (v2 < 0.0f) v2 = 0.0f; }
+            else if (v1 < 0.0f) { v2 = v1 + dv; if (v2 > 0.0f) v2 = 0.0f; }
+            else v2 = 0.0f;
+        }
         v2 = clampf(v2, -p.v_rev_max, p.v_max);
         yaw1 = s.yaw + ((v2 * tan_d) * p.inv_wheelbase) * p.dt;
-        if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
-        if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
-        spec_sincos(yaw1, hs, hc);
+        if constexpr (SEL) {
+            yaw1 = yaw1 > TRS_PI ? yaw1 - TRS_TWO_PI : yaw1;
+            yaw1 = yaw1 < -TRS_PI ? yaw1 + TRS_TWO_PI : yaw1;
+            spec_sincos_sel(yaw1, hs, hc);
+        } else {
+            if (yaw1 > TRS_PI) yaw1 -= TRS_TWO_PI;
+            if (yaw1 < -TRS_PI) yaw1 += TRS_TWO_PI;
+            spec_sincos(yaw1, hs, hc);
+        }
         x1 = s.x + (v2 * hs) * p.dt;
         z1 = s.z + (v2 * hc) * p.dt;
         y0 = s.y;
     }
     double bestd;
     int idx;
-    wave_nearest(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
+    wave_nearest<SEL>(near_of(p), lphys, (double)x1, (double)y0, (double)z1, lane, bestd, idx);
 
     const float y1 = (float)lpy[idx];
     const float2 tg = p.tan_in_lds ? ltan[idx] : reinterpret_cast<const float2*>(p.tangent_g)[idx];
@@ -414,6 +454,7 @@ __device__ __forceinline__ void env_advance(const PParams& p, const unsigned cha
 
 // ... inside the step kernels: controls from the launch's arrays, camera parameters to the global ring (the next launch's
 // first frame) and to this launch's LDS ring, then the progress counter the raster team waits on.
+template <bool SEL = false>
 __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* lphys, int e, EnvRegs& s, uint32_t t, int k,
                                          float4* cam_out, float4* lcam_slot, int* pprog_j, int lane, const trsim::HillBlock* hill = nullptr, float* lpitch_slot = nullptr)
 {
@@ -424,7 +465,7 @@ __device__ __forceinline__ void env_step(const PParams& p, const unsigned char* 
         steer = p.ctl_steer[ci]; thr = p.ctl_thr[ci]; brk = p.ctl_brk ? p.ctl_brk[ci] : 0.0f;
     }
     StepOut o;
-    env_advance<false>(p, lphys, e, s, t, p.synth, steer, thr, brk, rin, lane, o, hill);
+    env_advance<false, true, SEL>(p, lphys, e, s, t, p.synth, steer, thr, brk, rin, lane, o, hill);
     if (lane == 0) {
         if (p.write_cam) cam_out[e] = o.cam;                // for the next launch (its first frame)
         *lcam_slot = o.cam;                                 // for this launch's raster team

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kPhysBlock) void trs_physics_kernel(const PParams p
     EnvRegs st;
     env_load(p, e, st);
     for (int k = 0; k < p.n_steps; ++k)
-        env_step(p, smem, e, st, p.step_off + (uint32_t)k, k, p.cam, &lsink[wave], &psink[wave], lane);
+        env_step<true>(p, smem, e, st, p.step_off + (uint32_t)k, k, p.cam, &lsink[wave], &psink[wave], lane);   // (no raster wave beside this one: the select forms, see spec_sincos_sel)
     env_store(p, e, st, lane);
 }
 

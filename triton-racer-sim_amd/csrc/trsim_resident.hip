@@ -951,7 +951,7 @@ __global__ __launch_bounds__(kPwBlock) void trs_physics_worker_kernel(const WPar
         for (; owed < clean_below; ++owed) raster_arrive(l, owed, lane);   // lagged arrivals: no drain of their own
         const float epr_before = st.epr;
         StepOut o;
-        env_advance<true, false>(P, smem, e, st, (uint32_t)s, in.synth, in.steer, in.thr, in.brk, in.rin, lane, o);
+        env_advance<true, false, true>(P, smem, e, st, (uint32_t)s, in.synth, in.steer, in.thr, in.brk, in.rin, lane, o);   // (the select forms: see spec_sincos_sel)
         if (o.do_reset) lr = epr_before;
         if (lane == 0) {
             if (o.is_done) atomicAdd(&P.stats[0], 1ull);
