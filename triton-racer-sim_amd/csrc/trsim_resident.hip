@@ -104,6 +104,9 @@ struct WParams {
 constexpr int kDiag = TRS_RESIDENT_DIAG;
 
 constexpr unsigned kDefaultLifeUs = 50000;
+#ifndef TRS_PHYS_PRIO_MAX_ENVS
+#define TRS_PHYS_PRIO_MAX_ENVS 1   /* envs per workgroup up to which a physics wave integrates at raised priority (0 = never: A/B builds) */
+#endif
 constexpr unsigned kRetryMs0 = 100;
 
 struct Resident {
@@ -577,8 +580,13 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                 float lr = q[11];
                 const float epr_before = st.epr;
                 StepOut o;
+                // With ONE env per workgroup (256 envs or fewer per GPU) a step is as long as that env's integration beside the raster waves of its SIMD: there the
+                // integration goes in front of them (256 envs 3.74 -> 3.52 us per step, 128 envs the same).  With two envs per workgroup it changes nothing (512 envs:
+                // 4.97 against 5.01 us), with four the physics team runs ahead anyway and its priority only displaces raster waves (1024 envs: -5 %; profiles/r05_physics_chain.txt).
+                if (n_loc <= TRS_PHYS_PRIO_MAX_ENVS) __builtin_amdgcn_s_setprio(3);
                 env_advance<true, false>(P, lphys, e, st, (uint32_t)s, synth, steer, thr, brk, rin, lane, o,
                                          HILLS ? reinterpret_cast<const trsim::HillBlock*>(p.blob + trsim::hill_block_offset(p.blob_bytes)) : nullptr);
+                if (n_loc <= TRS_PHYS_PRIO_MAX_ENVS) __builtin_amdgcn_s_setprio(0);
                 if (o.do_reset) lr = epr_before;
                 if (lane == 0) {
                     q[0] = st.x; q[1] = st.y; q[2] = st.z; q[3] = st.yaw; q[4] = st.v; q[5] = st.sf; q[6] = st.epr;
