@@ -122,6 +122,7 @@ struct Resident {
                                          // completion flag will ever be written for them — the stream is what to wait for
     bool fell_back = false;              // a launch of the worker was found not co-resident (another process's worker on the GPU): the handle went
                                          // back to TRS_STEP_LAUNCH by itself (trs_last_error() says so); trs_set_step_mode selects resident mode again
+    bool dc_ready = false; uint64_t dc_ready_for = 0;   // the device control block has been zeroed and set up for a launch that starts at this step (handle_exit does it for the NEXT launch)
     std::chrono::steady_clock::time_point t_launch{};   // when the running worker was launched (the host gives up on a launch that never reports in)
     std::chrono::steady_clock::time_point t_fallback{}; // when the handle went back to launches; resident mode is tried again retry_ms later
     unsigned retry_ms = kRetryMs0;                      //   ... doubling up to 2 s while the GPU stays shared
@@ -1064,7 +1065,10 @@ int worker_launch(trs_env* e, uint64_t start)
     wp.lds_off_phys = e->lds_off_phys; wp.lds_off_ctl = R->lds_off_ctl; wp.lds_off_hill = R->lds_off_hill;
     const int grid = e->cfg.render ? (e->n + e->pp.envs_per_wg - 1) / e->pp.envs_per_wg : (e->n + kPwEnvs - 1) / kPwEnvs;
     wp.n_blocks = grid;
-    hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)start);
+    // the control block is set up by a one-workgroup kernel in front of the worker — unless the previous worker's normal exit already did that for exactly this start
+    // (handle_exit): the set-up then sits in the stream's idle time instead of in front of every launch (~4 us per worker start)
+    if (!(R->dc_ready && R->dc_ready_for == start)) hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)start);
+    R->dc_ready = false;
     if (!e->cfg.render) {
         hipLaunchKernelGGL(trs_physics_worker_kernel, dim3(grid), dim3(kPwBlock), R->lds_bytes, e->sP, wp);
         RCHK(hipGetLastError());
@@ -1159,6 +1163,10 @@ int handle_exit(trs_env* e, bool relaunch = true)
     if (consumed > R->seen_done) R->seen_done = consumed;   // the kernel has ended: everything it consumed is complete
     if (host_load(&R->mb->started)) R->retry_ms = kRetryMs0;   // this launch had the GPU: the sharing that caused an earlier fallback is over
     if (consumed < posted && relaunch) return worker_launch(e, consumed);
+    if (consumed == posted) {                               // nothing left to serve: the next launch of this handle starts here — its control block is set up now
+        hipLaunchKernelGGL(trs_worker_init_kernel, dim3(1), dim3(256), 0, e->sP, R->dc, (u64)consumed);
+        if (hipGetLastError() == hipSuccess) { R->dc_ready = true; R->dc_ready_for = consumed; }
+    }
     return TRS_OK;
 }
 
