@@ -547,9 +547,10 @@ __device__ __forceinline__ FrameDesc frame_desc(const RParams& p, uint8_t* img, 
 
 // rows with four equal class colours: one palette read per 4 pixels, no map lookup, no pose
 template <bool DEPTH>
-__device__ __forceinline__ void raster_uniform_rows(const RParams& p, const RasterThread& t, const FrameDesc& f)
+__device__ __forceinline__ void raster_uniform_rows(const RParams& p, const RasterThread& t, const FrameDesc& f, int uni_rows = -1)   // uni_rows: the frame's own count (tracks with elevation)
 {
-    for (int v = t.vstart; v < p.uni_rows; v += p.rows_per_pass) {
+    const int nu = uni_rows < 0 ? p.uni_rows : uni_rows;
+    for (int v = t.vstart; v < nu; v += p.rows_per_pass) {
         const uint32_t c = *(lds_u32p)(uintptr_t)(t.pal_off + ((unsigned)v << 4));
         const u3v px3 = {__builtin_amdgcn_perm(c, c, 0x04020100u), __builtin_amdgcn_perm(c, c, 0x05040201u), __builtin_amdgcn_perm(c, c, 0x06050402u)};
         __builtin_amdgcn_raw_buffer_store_b96(px3, f.rgb, t.col_off + v * t.row_bytes, 0, TRS_STORE_AUX);
@@ -635,7 +636,7 @@ constexpr int kHillRowBytes = 28;
 constexpr int kHillBatchMax = 4;
 __host__ __device__ inline int hill_table_bytes(int H) { return (kHillRowBytes * H + 15) & ~15; }
 __host__ __device__ inline int hill_batch(int H) { const int b = kRasterThreads / (H > 0 ? H : 1); return b < 1 ? 1 : (b > kHillBatchMax ? kHillBatchMax : b); }
-__host__ __device__ inline int hill_lds_bytes(int H) { return hill_batch(H) * hill_table_bytes(H) + 16; }   // the batch's tables + the team-barrier counter
+__host__ __device__ inline int hill_lds_bytes(int H) { return hill_batch(H) * hill_table_bytes(H) + 48; }   // the batch's tables + the team-barrier counter (4 B) + 12 B spare + int first_ground[2][4]: an env's first row that sees the ground, by batch parity
 
 // ImgPreprocessing.__process of ONE colour without dynamic brightness and Canny (img_preprocessing.py:37-74,92-99): the device twin of the host's filter_colour —
 // the same binary32 trim, OpenCV's 8-bit fixed-point HSV with its reciprocal tables, the masks written over their destination channels in filter order.
@@ -672,7 +673,7 @@ __device__ __forceinline__ uint32_t hill_filter_colour(const trsim::HillBlock& h
     return (uint32_t)o0 | ((uint32_t)o1 << 8) | ((uint32_t)o2 << 16);
 }
 
-__device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int v)
+__device__ __forceinline__ float hill_row_build(const RParams& p, unsigned char* lds, unsigned tab_off, float P, int v)   // returns the row's row_k (0: sky or beyond the far plane)
 {
     const trsim::HillBlock hb = *reinterpret_cast<const trsim::HillBlock*>(p.blob + trsim::hill_block_offset(p.blob_bytes));   // (uniform address: scalar loads)
     float sp, cp;
@@ -712,6 +713,7 @@ __device__ __forceinline__ void hill_row_build(const RParams& p, unsigned char* 
     reinterpret_cast<f2v*>(tab)[v] = f2v{lz, kk};
     reinterpret_cast<u4v*>(tab + 8 * p.H)[v] = u4v{c0, c1, c2, c3};
     reinterpret_cast<float*>(tab + 24 * p.H)[v] = dep;
+    return kk;
 }
 
 // the row loops read their tables from the frame's own table at tab_off
@@ -744,18 +746,39 @@ __device__ __forceinline__ bool hill_batch_build(const RParams& p, unsigned char
                                                  int tid, int lane, Bail& bail)
 {
     constexpr int nrw = kRasterThreads / 64;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of the previous batch's tables have returned
+    // first_ground[parity of the batch][env]: the first row of the env's frame that sees the ground (row_k != 0).  The rows above it — sky, beyond the far plane — go
+    // through the tight loop of uniform rows (raster_hill_frame), as the host's uni_rows lets the flat kernels do.  Two sets by batch parity: this batch's set is reset
+    // here, in front of barrier 1, while a slow wave may still be reading the previous batch's.
+    int* const fg = hbar + 4 + 4 * ((done_before / (2 * nrw)) & 1);
+    if (tid < kHillBatchMax) fg[tid] = p.H;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of the previous batch's tables have returned (and the reset is in LDS)
     if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!team_barrier_wait(hbar, done_before + nrw, bail)) return false;
     const unsigned tb = (unsigned)hill_table_bytes(p.H);
     for (int row = tid; row < nb * p.H; row += kRasterThreads) {
         const int bi = row / p.H, v = row - bi * p.H;
         const float Pv = bi == 0 ? P[0] : (bi == 1 ? P[1] : (bi == 2 ? P[2] : P[3]));
-        hill_row_build(p, lds, tab0 + (unsigned)bi * tb, Pv, v);
+        if (hill_row_build(p, lds, tab0 + (unsigned)bi * tb, Pv, v) != 0.0f) __hip_atomic_fetch_min(&fg[bi], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(hbar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     return team_barrier_wait(hbar, done_before + 2 * nrw, bail);
+}
+
+// One env's frame from its table of the current batch (bi = its place in the batch, done_before as in hill_batch_build): the rows above its first ground row as
+// uniform rows, the rest through the ground loop (which still takes a row with row_k == 0 as one colour, should one ever sit below a ground row).
+template <bool DEPTH>
+__device__ __forceinline__ void raster_hill_frame(const RParams& p, const RasterThread& rth, const unsigned char* lds, unsigned tab0, int bi, const int* hbar, int done_before,
+                                                  const FrameDesc& f, const float4 cam)
+{
+    constexpr int nrw = kRasterThreads / 64;
+    const int first_ground = hbar[4 + 4 * ((done_before / (2 * nrw)) & 1) + bi];
+    RasterThread t = raster_use_table(rth, lds, tab0 + (unsigned)(bi * hill_table_bytes(p.H)), p.H);
+    raster_uniform_rows<DEPTH>(p, t, f, first_ground);
+    int vg = t.vstart;
+    if (vg < first_ground) vg += ((first_ground - vg + p.rows_per_pass - 1) / p.rows_per_pass) * p.rows_per_pass;
+    t.vground = vg;
+    raster_ground_rows<DEPTH, true>(p, t, f, cam);
 }
 
 // The colour masks of one pixel (img_preprocessing.py:57-74; OpenCV's 8-bit RGB -> HSV with its fixed-point reciprocal tables, then inRange).

@@ -266,8 +266,7 @@ __global__ __launch_bounds__(kBlock) void trs_step_kernel(const SParams sp)
 #pragma unroll
             for (int bi = 0; bi < kHillBatchMax; ++bi)
                 if (bi < nb)
-                    raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
-                                                    frame_desc<DEPTH>(p, img, dep, e + bi), cams[bi]);
+                    raster_hill_frame<DEPTH>(p, rth, smem, (unsigned)lds_off_hill, bi, hbar, it * 2 * (kRasterThreads / 64), frame_desc<DEPTH>(p, img, dep, e + bi), cams[bi]);
             continue;
         }
         if constexpr (DYN) {

@@ -769,12 +769,12 @@ __global__ __launch_bounds__(kBlock) void trs_worker_kernel(const WParams wp)
                     if (now - t0_bar > wp.safety_ticks) { worker_abort(wp, l, 5u); return true; }
                     return false;
                 };
-                if (!hill_batch_build(p, smem, (unsigned)wp.lds_off_hill, Pv, nb, hbar, (r * nbatch + b0 / HB) * 2 * (kRasterThreads / 64), tid, lane, bail)) return;
+                const int done_before = (r * nbatch + b0 / HB) * 2 * (kRasterThreads / 64);
+                if (!hill_batch_build(p, smem, (unsigned)wp.lds_off_hill, Pv, nb, hbar, done_before, tid, lane, bail)) return;
 #pragma unroll
                 for (int bi = 0; bi < kHillBatchMax; ++bi)
                     if (bi < nb)
-                        raster_ground_rows<DEPTH, true>(p, raster_use_table(rth, smem, (unsigned)wp.lds_off_hill + (unsigned)(bi * hill_table_bytes(p.H)), p.H),
-                                                        frame_desc<DEPTH>(p, img, dep, e_begin + b0 + bi), cams[bi]);
+                        raster_hill_frame<DEPTH>(p, rth, smem, (unsigned)wp.lds_off_hill, bi, hbar, done_before, frame_desc<DEPTH>(p, img, dep, e_begin + b0 + bi), cams[bi]);
                 if (mine_j >= 0 && !(kDiag & 2)) {                    // the step's telemetry of this wave's env of the batch (a wave owns at most one of a batch of <= 4 <= 8)
                     const size_t e = (size_t)(e_begin + mine_j);
                     if (lane < 12) __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(uintptr_t)optr + e, tel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
